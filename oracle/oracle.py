@@ -1,0 +1,268 @@
+"""ctypes front-end of the CPU oracle (oracle/libphastft_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: import this from tests/, ``__graft_entry__.smoke()`` and bench.py's
+``cpu_baseline`` leg -- never from the product package ``phastft_amd``.  See phastft_oracle.h.
+
+Function names mirror the reference's Rust API (lib.rs:143-226, algorithms/r2c.rs:521-895,
+algorithms/bravo.rs:303-324); panics become :class:`OraclePanic` carrying the reference's message.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libphastft_oracle.so")
+
+FORWARD = 1
+REVERSE = -1
+
+
+class OraclePanic(AssertionError):
+    """A reference ``assert!``/``assert_eq!`` would have fired (the Rust code panics)."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(message)
+        self.code = code
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc if the .so is missing or older than its sources."""
+    srcs = [os.path.join(_HERE, f) for f in ("phastft_oracle.c", "dit_impl.inc", "phastft_oracle.h", "Makefile")]
+    stale = force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
+    if stale:
+        subprocess.run(["make", "-C", _HERE, "-B"], check=True, capture_output=True)
+    return _SO
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.pho_strerror.restype = C.c_char_p
+        _lib.pho_time_fft_64_dit.restype = C.c_double
+        _lib.pho_time_fft_64_dit.argtypes = [C.c_size_t, C.c_int, C.c_ulonglong]
+        _lib.pho_time_r2c_fft_f32.restype = C.c_double
+        _lib.pho_time_r2c_fft_f32.argtypes = [C.c_size_t, C.c_int, C.c_ulonglong]
+        for name in ("pho_planner_dit64_stage", "pho_planner_dit32_stage"):
+            getattr(_lib, name).restype = C.c_size_t
+    return _lib
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        raise OraclePanic(rc, lib().pho_strerror(rc).decode())
+
+
+def _p(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _req(a: np.ndarray, dtype) -> np.ndarray:
+    if not (isinstance(a, np.ndarray) and a.dtype == dtype and a.flags.c_contiguous and a.ndim == 1):
+        raise TypeError(f"need a contiguous 1-D {np.dtype(dtype).name} ndarray")
+    return a
+
+
+def _sz(n: int) -> C.c_size_t:
+    return C.c_size_t(n)
+
+
+# ---- options.rs:38-43 ----
+class Options(C.Structure):
+    _fields_ = [("multithreaded_bit_reversal", C.c_int), ("smallest_parallel_chunk_size", C.c_size_t)]
+
+
+def guess_options(input_size: int) -> Options:
+    o = Options()
+    _check(lib().pho_options_guess(_sz(input_size), C.byref(o)))
+    return o
+
+
+# ---- planners (planner.rs) ----
+class _Planner:
+    _new = _free = None
+
+    def __init__(self, n: int):
+        self._h = C.c_void_p()
+        _check(getattr(lib(), self._new)(_sz(n), C.byref(self._h)))
+        self.n = n
+
+    def __del__(self):
+        if getattr(self, "_h", None) and self._h.value:
+            getattr(lib(), self._free)(self._h)
+            self._h = C.c_void_p()
+
+
+class PlannerDit64(_Planner):
+    _new, _free, _dtype = "pho_planner_dit64_new", "pho_planner_dit64_free", np.float64
+
+    def stage_twiddles(self, stage: int):
+        re, im = C.c_void_p(), C.c_void_p()
+        fn = lib().pho_planner_dit64_stage if self._dtype == np.float64 else lib().pho_planner_dit32_stage
+        dist = fn(self._h, _sz(stage), C.byref(re), C.byref(im))
+        if dist == 0:
+            raise IndexError(stage)
+        ct = C.c_double if self._dtype == np.float64 else C.c_float
+        mk = lambda p: np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), shape=(dist,)).copy()
+        return mk(re), mk(im)
+
+
+class PlannerDit32(PlannerDit64):
+    _new, _free, _dtype = "pho_planner_dit32_new", "pho_planner_dit32_free", np.float32
+
+
+class PlannerR2c64(_Planner):
+    _new, _free, _dtype = "pho_planner_r2c64_new", "pho_planner_r2c64_free", np.float64
+
+    def twiddles(self):
+        re, im = C.c_void_p(), C.c_void_p()
+        fn = lib().pho_planner_r2c64_twiddles if self._dtype == np.float64 else lib().pho_planner_r2c32_twiddles
+        fn(self._h, C.byref(re), C.byref(im))
+        ct = C.c_double if self._dtype == np.float64 else C.c_float
+        mk = lambda p: np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), shape=(self.n // 2,)).copy()
+        return mk(re), mk(im)
+
+
+class PlannerR2c32(PlannerR2c64):
+    _new, _free, _dtype = "pho_planner_r2c32_new", "pho_planner_r2c32_free", np.float32
+
+
+# ---- C2C (lib.rs:143-226) ----
+def _fft(name, dtype, reals, imags, direction, planner=None):
+    _req(reals, dtype), _req(imags, dtype)
+    if planner is None:
+        _check(getattr(lib(), name)(_p(reals), _sz(reals.size), _p(imags), _sz(imags.size), C.c_int(direction)))
+    else:
+        _check(getattr(lib(), name + "_with_planner")(_p(reals), _sz(reals.size), _p(imags), _sz(imags.size),
+                                                      C.c_int(direction), planner._h))
+
+
+def fft_64_dit(reals, imags, direction=FORWARD):
+    _fft("pho_fft_64_dit", np.float64, reals, imags, direction)
+
+
+def fft_32_dit(reals, imags, direction=FORWARD):
+    _fft("pho_fft_32_dit", np.float32, reals, imags, direction)
+
+
+def fft_64_dit_with_planner(reals, imags, direction, planner: PlannerDit64):
+    _fft("pho_fft_64_dit", np.float64, reals, imags, direction, planner)
+
+
+def fft_32_dit_with_planner(reals, imags, direction, planner: PlannerDit32):
+    _fft("pho_fft_32_dit", np.float32, reals, imags, direction, planner)
+
+
+# ---- bit reversal (bravo.rs) ----
+def bit_rev_bravo_f64(data, log_n, regime=""):
+    _req(data, np.float64)
+    assert data.size == 1 << log_n, "Data length must be 2^n"
+    getattr(lib(), "pho_bit_rev" + regime + "_f64")(_p(data), C.c_uint(log_n))
+
+
+def bit_rev_bravo_f32(data, log_n, regime=""):
+    _req(data, np.float32)
+    assert data.size == 1 << log_n, "Data length must be 2^n"
+    getattr(lib(), "pho_bit_rev" + regime + "_f32")(_p(data), C.c_uint(log_n))
+
+
+# ---- kernels for the pin tests ----
+def codelet_16_f64(re, im):
+    lib().pho_codelet_16_f64(_p(_req(re, np.float64)), _p(_req(im, np.float64)), _sz(re.size))
+
+
+def codelet_32_f32(re, im):
+    lib().pho_codelet_32_f32(_p(_req(re, np.float32)), _p(_req(im, np.float32)), _sz(re.size))
+
+
+def stage_const(re, im, stage):
+    sfx = "f64" if re.dtype == np.float64 else "f32"
+    getattr(lib(), "pho_stage_const_" + sfx)(_p(re), _p(im), _sz(re.size), C.c_uint(stage))
+
+
+# ---- R2C / C2R (r2c.rs) ----
+def _r2c(sfx, dtype, input_re, output_re, output_im, planner=None):
+    _req(input_re, dtype), _req(output_re, dtype), _req(output_im, dtype)
+    args = [_p(input_re), _sz(input_re.size), _p(output_re), _sz(output_re.size), _p(output_im), _sz(output_im.size)]
+    if planner is None:
+        _check(getattr(lib(), "pho_r2c_fft_" + sfx)(*args))
+    else:
+        _check(getattr(lib(), "pho_r2c_fft_" + sfx + "_with_planner")(*args, planner._h))
+
+
+def r2c_fft_f64(input_re, output_re, output_im):
+    _r2c("f64", np.float64, input_re, output_re, output_im)
+
+
+def r2c_fft_f32(input_re, output_re, output_im):
+    _r2c("f32", np.float32, input_re, output_re, output_im)
+
+
+def r2c_fft_f64_with_planner(input_re, output_re, output_im, planner):
+    _r2c("f64", np.float64, input_re, output_re, output_im, planner)
+
+
+def r2c_fft_f32_with_planner(input_re, output_re, output_im, planner):
+    _r2c("f32", np.float32, input_re, output_re, output_im, planner)
+
+
+def _c2r(sfx, dtype, input_re, input_im, output, planner=None, scratch_re=None, scratch_im=None):
+    _req(input_re, dtype), _req(input_im, dtype), _req(output, dtype)
+    args = [_p(input_re), _sz(input_re.size), _p(input_im), _sz(input_im.size), _p(output), _sz(output.size)]
+    if planner is None:
+        _check(getattr(lib(), "pho_c2r_fft_" + sfx)(*args))
+        return
+    if scratch_re is None:  # r2c.rs:704-725: the allocating form
+        half = planner.n // 2
+        scratch_re, scratch_im = np.zeros(half, dtype), np.zeros(half, dtype)
+    _req(scratch_re, dtype), _req(scratch_im, dtype)
+    _check(getattr(lib(), "pho_c2r_fft_" + sfx + "_with_planner_and_scratch")(
+        *args, planner._h, _p(scratch_re), _sz(scratch_re.size), _p(scratch_im), _sz(scratch_im.size)))
+
+
+def c2r_fft_f64(input_re, input_im, output):
+    _c2r("f64", np.float64, input_re, input_im, output)
+
+
+def c2r_fft_f32(input_re, input_im, output):
+    _c2r("f32", np.float32, input_re, input_im, output)
+
+
+def c2r_fft_f64_with_planner(input_re, input_im, output, planner):
+    _c2r("f64", np.float64, input_re, input_im, output, planner)
+
+
+def c2r_fft_f32_with_planner(input_re, input_im, output, planner):
+    _c2r("f32", np.float32, input_re, input_im, output, planner)
+
+
+def c2r_fft_f64_with_planner_and_scratch(input_re, input_im, output, planner, scratch_re, scratch_im):
+    _c2r("f64", np.float64, input_re, input_im, output, planner, scratch_re, scratch_im)
+
+
+def c2r_fft_f32_with_planner_and_scratch(input_re, input_im, output, planner, scratch_re, scratch_im):
+    _c2r("f32", np.float32, input_re, input_im, output, planner, scratch_re, scratch_im)
+
+
+# ---- synthetic inputs + timing ----
+def fill(n: int, dtype, seed: int = 0xCAFE, transform_id: int = 0):
+    re, im = np.empty(n, dtype), np.empty(n, dtype)
+    sfx = "f64" if np.dtype(dtype) == np.float64 else "f32"
+    getattr(lib(), "pho_fill_" + sfx)(_p(re), _p(im), _sz(n), C.c_ulonglong(seed), C.c_ulonglong(transform_id))
+    return re, im
+
+
+def time_fft_64_dit(n: int, iters: int, seed: int = 0xCAFE) -> float:
+    return lib().pho_time_fft_64_dit(n, iters, seed)
+
+
+def time_r2c_fft_f32(n: int, iters: int, seed: int = 0xCAFE) -> float:
+    return lib().pho_time_r2c_fft_f32(n, iters, seed)
