@@ -1,0 +1,200 @@
+/*
+ * phastft_hip.h -- C ABI of libphastft_hip.so, the MI355X (gfx950) drop-in for PhastFT's planar
+ * power-of-two FFT path.
+ *
+ * The reference (QuState/PhastFT 0.3.0, /root/reference) has no FFI layer: its boundary is the
+ * crate's public Rust API.  Every entry point below is named after, and
+ * cites, the Rust item it replaces; a Rust shim crate binds them 1:1.
+ *
+ *   - plain pointers + explicit lengths (so the library re-validates what the Rust `assert!`s check)
+ *   - `int direction`: +1 = Direction::Forward, -1 = Direction::Reverse  (planner.rs:10-16)
+ *   - return value: PHAST_OK or one status per reference assert; phast_strerror() returns the
+ *     reference's panic text so a shim can `panic!` with it (r2c.rs:1392-1540 tests the strings)
+ *   - host-slice calls (no suffix) take HOST pointers, stage H2D/D2H internally and return with the
+ *     result visible in the caller's slices -- the drop-in semantics of the Rust API
+ *   - `_dev` calls take DEVICE pointers + a hipStream_t (as void*) and are asynchronous on that
+ *     stream; they are what bench.py measures.  `batch` independent transforms, transform b at
+ *     pointer + b*dist elements.
+ *
+ * Planners are immutable after creation and may be shared by concurrent callers on DIFFERENT
+ * data only when each caller uses its own stream AND its own planner scratch; in this version a
+ * planner owns one device scratch buffer, so calls on one planner are serialised by an internal
+ * mutex on the host-slice path and must be stream-ordered by the caller on the _dev path.
+ */
+#ifndef PHASTFT_HIP_H
+#define PHASTFT_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- planner.rs:10-32 ---- */
+#define PHAST_FORWARD 1  /* Direction::Forward */
+#define PHAST_REVERSE (-1) /* Direction::Reverse */
+#define PHAST_MODE_HEURISTIC 0 /* PlannerMode::Heuristic */
+#define PHAST_MODE_TUNE 1      /* PlannerMode::Tune (accepted, ignored -- as planner.rs:65 `_mode`) */
+
+/* ---- status codes: one per reference assert ---- */
+#define PHAST_OK 0
+#define PHAST_ERR_NOT_POW2 1        /* planner.rs:66, algorithms/dit.rs:285,357 */
+#define PHAST_ERR_LEN_MISMATCH 2    /* algorithms/dit.rs:284,356 */
+#define PHAST_ERR_PLANNER_SIZE 3    /* algorithms/dit.rs:289,361 */
+#define PHAST_ERR_R2C_N 4           /* planner.rs:195 */
+#define PHAST_ERR_R2C_INPUT_LEN 5   /* algorithms/r2c.rs:535,615 */
+#define PHAST_ERR_R2C_OUT_RE_LEN 6  /* algorithms/r2c.rs:536-540,616-620 */
+#define PHAST_ERR_R2C_OUT_IM_LEN 7  /* algorithms/r2c.rs:541-545,621-625 */
+#define PHAST_ERR_C2R_OUTPUT_LEN 8  /* algorithms/r2c.rs:737,842 */
+#define PHAST_ERR_C2R_IN_RE_LEN 9   /* algorithms/r2c.rs:738-742,843-847 */
+#define PHAST_ERR_C2R_IN_IM_LEN 10  /* algorithms/r2c.rs:743-747,848-852 */
+#define PHAST_ERR_C2R_SCRATCH_RE 11 /* algorithms/r2c.rs:748,853 */
+#define PHAST_ERR_C2R_SCRATCH_IM 12 /* algorithms/r2c.rs:749,854 */
+#define PHAST_ERR_ALLOC 13          /* host allocation failed */
+#define PHAST_ERR_HIP 14            /* a HIP runtime call failed; see phast_last_hip_error() */
+#define PHAST_ERR_NO_DEVICE 15      /* no gfx950 device visible: the library never falls back to CPU */
+#define PHAST_ERR_INVALID_ARG 16    /* null pointer / bad direction / bit-reversal length != 2^n (bravo.rs:228) */
+
+/* exact panic text of the reference for the code (or a description for the HIP-side codes) */
+const char *phast_strerror(int code);
+/* hipGetErrorString of the last failing HIP call on this thread ("" if none) */
+const char *phast_last_hip_error(void);
+/* library / device identification: returns PHAST_OK and fills what it can */
+int phast_device_info(char *name, size_t name_len, int *compute_units, size_t *lds_per_block,
+                      size_t *global_mem_bytes);
+
+/* ---- options.rs:8-43 ---- */
+typedef struct phast_options {
+    int multithreaded_bit_reversal;      /* options.rs:17; CPU threading hint -- ignored on the GPU */
+    size_t smallest_parallel_chunk_size; /* options.rs:24; ignored on the GPU */
+} phast_options;
+void phast_options_default(phast_options *out);               /* options.rs:26-33 */
+int phast_options_guess(size_t input_size, phast_options *out); /* options.rs:38-43 */
+
+/* ---- planner.rs:34-114 ---- */
+typedef struct phast_planner_dit64 phast_planner_dit64; /* PlannerDit64 */
+typedef struct phast_planner_dit32 phast_planner_dit32; /* PlannerDit32 */
+int phast_planner_dit64_new(size_t num_points, phast_planner_dit64 **out);                 /* planner.rs:55 */
+int phast_planner_dit64_with_mode(size_t num_points, int mode, phast_planner_dit64 **out); /* planner.rs:65 */
+void phast_planner_dit64_free(phast_planner_dit64 *p);
+int phast_planner_dit32_new(size_t num_points, phast_planner_dit32 **out);
+int phast_planner_dit32_with_mode(size_t num_points, int mode, phast_planner_dit32 **out);
+void phast_planner_dit32_free(phast_planner_dit32 *p);
+/* device footprint of a planner (twiddle tables + scratch), and its pass plan as text */
+size_t phast_planner_dit64_device_bytes(const phast_planner_dit64 *p);
+size_t phast_planner_dit32_device_bytes(const phast_planner_dit32 *p);
+int phast_planner_dit64_describe(const phast_planner_dit64 *p, char *buf, size_t buf_len);
+int phast_planner_dit32_describe(const phast_planner_dit32 *p, char *buf, size_t buf_len);
+/* optional: size the scratch for `max_batch` transforms in flight (default 1); realloc on demand otherwise */
+int phast_planner_dit64_reserve_batch(phast_planner_dit64 *p, size_t max_batch);
+int phast_planner_dit32_reserve_batch(phast_planner_dit32 *p, size_t max_batch);
+
+/* ---- planner.rs:164-212 ---- */
+typedef struct phast_planner_r2c64 phast_planner_r2c64; /* PlannerR2c64 */
+typedef struct phast_planner_r2c32 phast_planner_r2c32; /* PlannerR2c32 */
+int phast_planner_r2c64_new(size_t n, phast_planner_r2c64 **out); /* planner.rs:194 */
+void phast_planner_r2c64_free(phast_planner_r2c64 *p);
+int phast_planner_r2c32_new(size_t n, phast_planner_r2c32 **out);
+void phast_planner_r2c32_free(phast_planner_r2c32 *p);
+
+/* ---- C2C, host slices: lib.rs:143-226, algorithms/dit.rs:263,338 ---- */
+int phast_fft_64_dit(double *reals, size_t reals_len, double *imags, size_t imags_len, int direction); /* lib.rs:180 */
+int phast_fft_32_dit(float *reals, size_t reals_len, float *imags, size_t imags_len, int direction);   /* lib.rs:223 */
+int phast_fft_64_dit_with_planner(double *reals, size_t reals_len, double *imags, size_t imags_len,
+                                  int direction, const phast_planner_dit64 *planner); /* lib.rs:143 */
+int phast_fft_32_dit_with_planner(float *reals, size_t reals_len, float *imags, size_t imags_len, int direction,
+                                  const phast_planner_dit32 *planner); /* lib.rs:186 */
+int phast_fft_64_dit_with_planner_and_opts(double *reals, size_t reals_len, double *imags, size_t imags_len,
+                                           int direction, const phast_planner_dit64 *planner,
+                                           const phast_options *opts); /* algorithms/dit.rs:263 */
+int phast_fft_32_dit_with_planner_and_opts(float *reals, size_t reals_len, float *imags, size_t imags_len,
+                                           int direction, const phast_planner_dit32 *planner,
+                                           const phast_options *opts); /* algorithms/dit.rs:338 */
+
+/* ---- C2C, device-resident, batched, asynchronous on `stream` (hipStream_t) ---- */
+int phast_fft_64_dit_dev(double *d_reals, double *d_imags, size_t n, size_t batch, size_t dist, int direction,
+                         const phast_planner_dit64 *planner, void *stream);
+int phast_fft_32_dit_dev(float *d_reals, float *d_imags, size_t n, size_t batch, size_t dist, int direction,
+                         const phast_planner_dit32 *planner, void *stream);
+
+/* ---- bit reversal: algorithms/bravo.rs:303,317 (public with feature bench-internals, lib.rs:20-23) ---- */
+int phast_bit_rev_f64(double *data, size_t len, unsigned log_n); /* host slice */
+int phast_bit_rev_f32(float *data, size_t len, unsigned log_n);
+int phast_bit_rev_f64_dev(double *d_data, unsigned log_n, size_t batch, size_t dist, void *stream);
+int phast_bit_rev_f32_dev(float *d_data, unsigned log_n, size_t batch, size_t dist, void *stream);
+
+/* ---- R2C: algorithms/r2c.rs:521-662 ---- */
+int phast_r2c_fft_f64(const double *input_re, size_t input_len, double *output_re, size_t output_re_len,
+                      double *output_im, size_t output_im_len); /* r2c.rs:521 */
+int phast_r2c_fft_f32(const float *input_re, size_t input_len, float *output_re, size_t output_re_len,
+                      float *output_im, size_t output_im_len); /* r2c.rs:598 */
+int phast_r2c_fft_f64_with_planner(const double *input_re, size_t input_len, double *output_re,
+                                   size_t output_re_len, double *output_im, size_t output_im_len,
+                                   const phast_planner_r2c64 *planner); /* r2c.rs:527 */
+int phast_r2c_fft_f32_with_planner(const float *input_re, size_t input_len, float *output_re, size_t output_re_len,
+                                   float *output_im, size_t output_im_len,
+                                   const phast_planner_r2c32 *planner); /* r2c.rs:607 */
+/* device-resident: input N reals, outputs N/2+1 each; batch b at +b*in_dist / +b*out_dist elements */
+int phast_r2c_fft_f64_dev(const double *d_input, double *d_output_re, double *d_output_im, size_t batch,
+                          size_t in_dist, size_t out_dist, const phast_planner_r2c64 *planner, void *stream);
+int phast_r2c_fft_f32_dev(const float *d_input, float *d_output_re, float *d_output_im, size_t batch,
+                          size_t in_dist, size_t out_dist, const phast_planner_r2c32 *planner, void *stream);
+
+/* ---- C2R: algorithms/r2c.rs:695-895 ---- */
+int phast_c2r_fft_f64(const double *input_re, size_t input_re_len, const double *input_im, size_t input_im_len,
+                      double *output, size_t output_len); /* r2c.rs:695 */
+int phast_c2r_fft_f32(const float *input_re, size_t input_re_len, const float *input_im, size_t input_im_len,
+                      float *output, size_t output_len); /* r2c.rs:800 */
+int phast_c2r_fft_f64_with_planner(const double *input_re, size_t input_re_len, const double *input_im,
+                                   size_t input_im_len, double *output, size_t output_len,
+                                   const phast_planner_r2c64 *planner); /* r2c.rs:704 */
+int phast_c2r_fft_f32_with_planner(const float *input_re, size_t input_re_len, const float *input_im,
+                                   size_t input_im_len, float *output, size_t output_len,
+                                   const phast_planner_r2c32 *planner); /* r2c.rs:809 */
+/* the scratch slices are validated for length exactly as the reference does and otherwise unused:
+ * the device path keeps its workspace in the planner (r2c.rs:727,832) */
+int phast_c2r_fft_f64_with_planner_and_scratch(const double *input_re, size_t input_re_len, const double *input_im,
+                                               size_t input_im_len, double *output, size_t output_len,
+                                               const phast_planner_r2c64 *planner, double *scratch_re,
+                                               size_t scratch_re_len, double *scratch_im, size_t scratch_im_len);
+int phast_c2r_fft_f32_with_planner_and_scratch(const float *input_re, size_t input_re_len, const float *input_im,
+                                               size_t input_im_len, float *output, size_t output_len,
+                                               const phast_planner_r2c32 *planner, float *scratch_re,
+                                               size_t scratch_re_len, float *scratch_im, size_t scratch_im_len);
+int phast_c2r_fft_f64_dev(const double *d_input_re, const double *d_input_im, double *d_output, size_t batch,
+                          size_t in_dist, size_t out_dist, const phast_planner_r2c64 *planner, void *stream);
+int phast_c2r_fft_f32_dev(const float *d_input_re, const float *d_input_im, float *d_output, size_t batch,
+                          size_t in_dist, size_t out_dist, const phast_planner_r2c32 *planner, void *stream);
+
+/* ---- harness support: deterministic on-device inputs and digests ---- */
+/* value(i) = uniform [-1,1) from splitmix64(seed ^ (transform_id << 40) ^ (2*i + is_imag)); transform b of the
+ * batch uses transform_id = first_id + b.  Same generator as oracle/pho_fill_*. */
+int phast_fill_f64_dev(double *d_reals, double *d_imags, size_t n, size_t batch, size_t dist,
+                       unsigned long long seed, unsigned long long first_id, void *stream);
+int phast_fill_f32_dev(float *d_reals, float *d_imags, size_t n, size_t batch, size_t dist,
+                       unsigned long long seed, unsigned long long first_id, void *stream);
+/* per-transform digest {sum re, sum im, sum re^2+im^2, re[probe]} in f64, 4 doubles per transform */
+int phast_digest_f64_dev(const double *d_reals, const double *d_imags, size_t n, size_t batch, size_t dist,
+                         size_t probe, double *d_digest, void *stream);
+int phast_digest_f32_dev(const float *d_reals, const float *d_imags, size_t n, size_t batch, size_t dist,
+                         size_t probe, double *d_digest, void *stream);
+
+/* ---- tuning hook used by bench.py / tests to force a pass plan (0 = heuristic) ----
+ * `log_rows` lists the per-pass tile FFT lengths (log2), `tile_log` the log2 points per tile. */
+int phast_planner_dit64_set_plan(phast_planner_dit64 *p, const unsigned *log_rows, size_t n_passes,
+                                 unsigned tile_log);
+int phast_planner_dit32_set_plan(phast_planner_dit32 *p, const unsigned *log_rows, size_t n_passes,
+                                 unsigned tile_log);
+
+/* ---- measurement hook (bench.py "roofline"): runs `reps` batched forward transforms in place on the given
+ * buffers with hipEvents recorded on `stream` around every pass kernel; pass_ms[i] = average duration of pass i
+ * in milliseconds (sum over batch chunks), *n_passes = number of passes (<= 3).  Blocks until done. ---- */
+int phast_planner_dit64_time_passes(const phast_planner_dit64 *p, double *d_reals, double *d_imags, size_t batch,
+                                    size_t dist, int reps, float *pass_ms, int *n_passes, void *stream);
+int phast_planner_dit32_time_passes(const phast_planner_dit32 *p, float *d_reals, float *d_imags, size_t batch,
+                                    size_t dist, int reps, float *pass_ms, int *n_passes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,516 @@
+"""phastft_amd -- MI355X (gfx950) drop-in for PhastFT's planar power-of-two FFT path.
+
+Host-side mirror of the reference's public Rust API (QuState/PhastFT 0.3.0; citations are relative to
+the reference tree) over the C ABI of ``include/phastft_hip.h``:
+
+    ==============================================  ==========================================
+    reference (Rust)                                here
+    ==============================================  ==========================================
+    Direction, PlannerMode            planner.rs:10  Direction, PlannerMode
+    Options, Options::guess_options   options.rs:10  Options, Options.guess_options
+    PlannerDit64/32::{new,with_mode}  planner.rs:55  PlannerDit64/32(n), .with_mode(n, mode)
+    PlannerR2c64/32::new              planner.rs:194 PlannerR2c64/32(n)
+    fft_64_dit / fft_32_dit           lib.rs:180,223 fft_64_dit / fft_32_dit
+    fft_*_dit_with_planner[_and_opts] lib.rs:143,186 same names
+    r2c_fft_f32/f64[_with_planner]    r2c.rs:521-662 same names
+    c2r_fft_*[_with_planner[_and_scratch]] r2c.rs:695 same names
+    bit_rev_bravo_f32/f64             bravo.rs:303   bit_rev_bravo_f32/f64(data, n)
+    ==============================================  ==========================================
+
+Slices are 1-D contiguous arrays: ``numpy.ndarray`` (host slices -- staged through device memory, the
+Rust drop-in semantics) or ``torch.Tensor`` on ``cuda`` (device-resident, asynchronous on torch's current
+stream; this is the measured path).  All transforms are in place on planar ``reals`` / ``imags``; forward is
+unnormalised and ``Direction.Reverse`` scales by 1/N, as in the reference (README.md:167-172).
+
+The reference signals misuse by panicking; here every reference ``assert!`` raises :class:`PhastPanic`
+carrying the reference's message.  There is NO CPU fallback: without the HIP library or a GPU the calls
+raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+
+__all__ = [
+    "Direction", "PlannerMode", "Options", "PhastPanic", "PhastHipError",
+    "PlannerDit64", "PlannerDit32", "PlannerR2c64", "PlannerR2c32",
+    "fft_64_dit", "fft_32_dit", "fft_64_dit_with_planner", "fft_32_dit_with_planner",
+    "fft_64_dit_with_planner_and_opts", "fft_32_dit_with_planner_and_opts",
+    "r2c_fft_f64", "r2c_fft_f32", "r2c_fft_f64_with_planner", "r2c_fft_f32_with_planner",
+    "c2r_fft_f64", "c2r_fft_f32", "c2r_fft_f64_with_planner", "c2r_fft_f32_with_planner",
+    "c2r_fft_f64_with_planner_and_scratch", "c2r_fft_f32_with_planner_and_scratch",
+    "bit_rev_bravo_f64", "bit_rev_bravo_f32", "fft_dit_batched", "fill_uniform", "digest", "device_info",
+]
+
+
+class Direction(enum.IntEnum):
+    """planner.rs:10-16"""
+
+    Forward = 1
+    Reverse = -1
+
+
+class PlannerMode(enum.IntEnum):
+    """planner.rs:24-32 (``Tune`` is accepted and ignored, as in the reference: planner.rs:65)."""
+
+    Heuristic = 0
+    Tune = 1
+
+
+class PhastPanic(AssertionError):
+    """A reference ``assert!`` / ``assert_eq!`` would have fired; ``str(e)`` is the reference's message."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(message)
+        self.code = code
+
+
+class PhastHipError(RuntimeError):
+    """The HIP runtime failed or no GPU is visible (codes 14/15 of phastft_hip.h)."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(message)
+        self.code = code
+
+
+def _check(rc: int) -> None:
+    if rc == 0:
+        return
+    l = _lib.lib()
+    msg = l.phast_strerror(rc).decode()
+    if rc in (13, 14, 15):
+        raise PhastHipError(rc, f"{msg}: {l.phast_last_hip_error().decode()}")
+    raise PhastPanic(rc, msg)
+
+
+@dataclass
+class Options:
+    """options.rs:8-43.  CPU threading knobs: carried for source compatibility, ignored on the GPU."""
+
+    multithreaded_bit_reversal: bool = False
+    smallest_parallel_chunk_size: int = 16384
+
+    @staticmethod
+    def guess_options(input_size: int) -> "Options":
+        o = _lib.PhastOptions()
+        _check(_lib.lib().phast_options_guess(C.c_size_t(input_size), C.byref(o)))
+        return Options(bool(o.multithreaded_bit_reversal), int(o.smallest_parallel_chunk_size))
+
+    def _c(self) -> _lib.PhastOptions:
+        return _lib.PhastOptions(int(self.multithreaded_bit_reversal), self.smallest_parallel_chunk_size)
+
+
+# ---------------------------------------------------------------------------------------------
+# slices
+# ---------------------------------------------------------------------------------------------
+def _is_torch(x) -> bool:
+    return type(x).__module__.split(".")[0] == "torch"
+
+
+class _Slice:
+    """pointer + length + where it lives, for a numpy array or a torch tensor"""
+
+    __slots__ = ("ptr", "len", "dev", "keep")
+
+    def __init__(self, x, dtype, what: str):
+        if _is_torch(x):
+            import torch
+
+            want = torch.float64 if dtype == np.float64 else torch.float32
+            if x.dtype != want or x.dim() != 1 or not x.is_contiguous():
+                raise TypeError(f"{what}: need a contiguous 1-D {want} tensor")
+            self.dev = x.device.type == "cuda"
+            if not self.dev:
+                raise TypeError(f"{what}: torch tensors must live on the GPU (use numpy arrays for host slices)")
+            self.ptr = C.c_void_p(x.data_ptr())
+            self.len = x.numel()
+        elif isinstance(x, np.ndarray):
+            if x.dtype != dtype or x.ndim != 1 or not x.flags.c_contiguous:
+                raise TypeError(f"{what}: need a contiguous 1-D {np.dtype(dtype).name} ndarray")
+            self.dev = False
+            self.ptr = x.ctypes.data_as(C.c_void_p)
+            self.len = x.size
+        else:
+            raise TypeError(f"{what}: need a numpy.ndarray (host) or a torch cuda tensor (device)")
+        self.keep = x
+
+
+def _stream() -> C.c_void_p:
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _same_place(*slices: _Slice) -> bool:
+    dev = slices[0].dev
+    if any(s.dev != dev for s in slices):
+        raise TypeError("all slices of one call must be host arrays or all device tensors")
+    return dev
+
+
+# ---------------------------------------------------------------------------------------------
+# planners
+# ---------------------------------------------------------------------------------------------
+class _PlannerDit:
+    _sfx = "64"
+    _dtype = np.float64
+
+    def __init__(self, num_points: int, mode: PlannerMode = PlannerMode.Heuristic):
+        self._h = C.c_void_p()
+        l = _lib.lib()
+        _check(getattr(l, f"phast_planner_dit{self._sfx}_with_mode")(C.c_size_t(num_points), C.c_int(int(mode)),
+                                                                     C.byref(self._h)))
+        self.num_points = num_points
+
+    @classmethod
+    def new(cls, num_points: int):
+        """planner.rs:55"""
+        return cls(num_points)
+
+    @classmethod
+    def with_mode(cls, num_points: int, mode: PlannerMode):
+        """planner.rs:65"""
+        return cls(num_points, mode)
+
+    def __del__(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            getattr(_lib.lib(), f"phast_planner_dit{self._sfx}_free")(self._h)
+            self._h = C.c_void_p()
+
+    # ---- MI355X-side extras (no reference counterpart) ----
+    def describe(self) -> str:
+        buf = C.create_string_buffer(1024)
+        _check(getattr(_lib.lib(), f"phast_planner_dit{self._sfx}_describe")(self._h, buf, C.c_size_t(1024)))
+        return buf.value.decode()
+
+    def device_bytes(self) -> int:
+        return int(getattr(_lib.lib(), f"phast_planner_dit{self._sfx}_device_bytes")(self._h))
+
+    def reserve_batch(self, max_batch: int) -> None:
+        _check(getattr(_lib.lib(), f"phast_planner_dit{self._sfx}_reserve_batch")(self._h, C.c_size_t(max_batch)))
+
+    def set_plan(self, log_rows=(), tile_log: int = 12) -> None:
+        """Force the pass factorisation (tuning hook); ``()`` restores the heuristic."""
+        arr = (C.c_uint * max(1, len(log_rows)))(*log_rows)
+        _check(getattr(_lib.lib(), f"phast_planner_dit{self._sfx}_set_plan")(self._h, arr, C.c_size_t(len(log_rows)),
+                                                                             C.c_uint(tile_log)))
+
+
+    def time_passes(self, reals, imags, n: int, reps: int = 10):
+        """Average HIP-event duration (ms) of every pass kernel over ``reps`` forward transforms of the
+        device tensors (``len/n`` transforms, transformed in place).  Measurement hook for bench.py."""
+        re, im = _Slice(reals, self._dtype, "reals"), _Slice(imags, self._dtype, "imags")
+        ms = (C.c_float * 3)()
+        npass = C.c_int()
+        _check(getattr(_lib.lib(), f"phast_planner_dit{self._sfx}_time_passes")(
+            self._h, re.ptr, im.ptr, C.c_size_t(re.len // n), C.c_size_t(n), C.c_int(reps), ms, C.byref(npass),
+            _stream()))
+        return [float(ms[i]) for i in range(npass.value)]
+
+
+class PlannerDit64(_PlannerDit):
+    """planner.rs:34-114 (f64)"""
+
+
+class PlannerDit32(_PlannerDit):
+    """planner.rs:34-114 (f32)"""
+
+    _sfx = "32"
+    _dtype = np.float32
+
+
+class _PlannerR2c:
+    _sfx = "64"
+    _dtype = np.float64
+
+    def __init__(self, n: int):
+        self._h = C.c_void_p()
+        _check(getattr(_lib.lib(), f"phast_planner_r2c{self._sfx}_new")(C.c_size_t(n), C.byref(self._h)))
+        self.n = n
+
+    @classmethod
+    def new(cls, n: int):
+        """planner.rs:194"""
+        return cls(n)
+
+    def __del__(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            getattr(_lib.lib(), f"phast_planner_r2c{self._sfx}_free")(self._h)
+            self._h = C.c_void_p()
+
+
+class PlannerR2c64(_PlannerR2c):
+    """planner.rs:164-212 (f64)"""
+
+
+class PlannerR2c32(_PlannerR2c):
+    """planner.rs:164-212 (f32)"""
+
+    _sfx = "32"
+    _dtype = np.float32
+
+
+# ---------------------------------------------------------------------------------------------
+# C2C  (lib.rs:143-226, algorithms/dit.rs:263,338)
+# ---------------------------------------------------------------------------------------------
+def _fft(sfx, dtype, reals, imags, direction, planner=None, opts=None, need_opts=False):
+    re, im = _Slice(reals, dtype, "reals"), _Slice(imags, dtype, "imags")
+    l = _lib.lib()
+    direction = C.c_int(int(direction))
+    if _same_place(re, im):
+        # device-resident: the Rust asserts are re-checked here, then the batched _dev entry point is used
+        own = planner is None
+        if own:
+            planner = (PlannerDit64 if sfx == "64" else PlannerDit32)(re.len)  # lib.rs:181: planner from reals.len()
+        if re.len != im.len:
+            _check(2)
+        _check(getattr(l, f"phast_fft_{sfx}_dit_dev")(re.ptr, im.ptr, C.c_size_t(re.len), C.c_size_t(1),
+                                                      C.c_size_t(re.len), direction, planner._h, _stream()))
+        if own:
+            import torch
+
+            torch.cuda.current_stream().synchronize()  # the temporary planner's scratch dies with it
+        return
+    args = [re.ptr, C.c_size_t(re.len), im.ptr, C.c_size_t(im.len), direction]
+    if planner is None:
+        _check(getattr(l, f"phast_fft_{sfx}_dit")(*args))
+    elif need_opts:
+        _check(getattr(l, f"phast_fft_{sfx}_dit_with_planner_and_opts")(*args, planner._h, C.byref(opts._c())))
+    else:
+        _check(getattr(l, f"phast_fft_{sfx}_dit_with_planner")(*args, planner._h))
+
+
+def fft_64_dit(reals, imags, direction: Direction) -> None:
+    """lib.rs:180"""
+    _fft("64", np.float64, reals, imags, direction)
+
+
+def fft_32_dit(reals, imags, direction: Direction) -> None:
+    """lib.rs:223"""
+    _fft("32", np.float32, reals, imags, direction)
+
+
+def fft_64_dit_with_planner(reals, imags, direction: Direction, planner: PlannerDit64) -> None:
+    """lib.rs:143"""
+    _fft("64", np.float64, reals, imags, direction, planner)
+
+
+def fft_32_dit_with_planner(reals, imags, direction: Direction, planner: PlannerDit32) -> None:
+    """lib.rs:186"""
+    _fft("32", np.float32, reals, imags, direction, planner)
+
+
+def fft_64_dit_with_planner_and_opts(reals, imags, direction: Direction, planner: PlannerDit64, opts: Options) -> None:
+    """algorithms/dit.rs:263"""
+    _fft("64", np.float64, reals, imags, direction, planner, opts, True)
+
+
+def fft_32_dit_with_planner_and_opts(reals, imags, direction: Direction, planner: PlannerDit32, opts: Options) -> None:
+    """algorithms/dit.rs:338"""
+    _fft("32", np.float32, reals, imags, direction, planner, opts, True)
+
+
+def fft_dit_batched(reals, imags, n: int, direction: Direction, planner) -> None:
+    """Device-resident batch: ``reals``/``imags`` hold ``len/n`` transforms back to back (no reference
+    counterpart; the reference loops over transforms on the CPU)."""
+    dtype, sfx = planner._dtype, planner._sfx
+    re, im = _Slice(reals, dtype, "reals"), _Slice(imags, dtype, "imags")
+    if not _same_place(re, im):
+        raise TypeError("fft_dit_batched needs device tensors")
+    if re.len != im.len:
+        _check(2)
+    if n == 0 or re.len % n:
+        raise ValueError("length must be a multiple of n")
+    _check(getattr(_lib.lib(), f"phast_fft_{sfx}_dit_dev")(re.ptr, im.ptr, C.c_size_t(n), C.c_size_t(re.len // n),
+                                                           C.c_size_t(n), C.c_int(int(direction)), planner._h,
+                                                           _stream()))
+
+
+# ---------------------------------------------------------------------------------------------
+# bit reversal  (algorithms/bravo.rs:303,317; public with feature bench-internals)
+# ---------------------------------------------------------------------------------------------
+def _bit_rev(fs, dtype, data, n):
+    d = _Slice(data, dtype, "data")
+    l = _lib.lib()
+    if d.len != (1 << n):
+        raise PhastPanic(16, "Data length must be 2^n")  # bravo.rs:228
+    if d.dev:
+        _check(getattr(l, f"phast_bit_rev_{fs}_dev")(d.ptr, C.c_uint(n), C.c_size_t(1), C.c_size_t(d.len), _stream()))
+    else:
+        _check(getattr(l, f"phast_bit_rev_{fs}")(d.ptr, C.c_size_t(d.len), C.c_uint(n)))
+
+
+def bit_rev_bravo_f64(data, n: int) -> None:
+    """bravo.rs:317"""
+    _bit_rev("f64", np.float64, data, n)
+
+
+def bit_rev_bravo_f32(data, n: int) -> None:
+    """bravo.rs:303"""
+    _bit_rev("f32", np.float32, data, n)
+
+
+# ---------------------------------------------------------------------------------------------
+# R2C / C2R  (algorithms/r2c.rs:521-895)
+# ---------------------------------------------------------------------------------------------
+def _r2c(fs, dtype, input_re, output_re, output_im, planner=None):
+    i, ore, oim = _Slice(input_re, dtype, "input_re"), _Slice(output_re, dtype, "output_re"), _Slice(
+        output_im, dtype, "output_im")
+    l = _lib.lib()
+    if _same_place(i, ore, oim):
+        own = planner is None
+        if own:
+            planner = (PlannerR2c64 if fs == "f64" else PlannerR2c32)(i.len)  # r2c.rs:522
+        n, half = planner.n, planner.n // 2
+        if i.len != n:
+            _check(5)
+        if ore.len != half + 1:
+            _check(6)
+        if oim.len != half + 1:
+            _check(7)
+        _check(getattr(l, f"phast_r2c_fft_{fs}_dev")(i.ptr, ore.ptr, oim.ptr, C.c_size_t(1), C.c_size_t(n),
+                                                     C.c_size_t(half + 1), planner._h, _stream()))
+        if own:
+            import torch
+
+            torch.cuda.current_stream().synchronize()
+        return
+    args = [i.ptr, C.c_size_t(i.len), ore.ptr, C.c_size_t(ore.len), oim.ptr, C.c_size_t(oim.len)]
+    if planner is None:
+        _check(getattr(l, f"phast_r2c_fft_{fs}")(*args))
+    else:
+        _check(getattr(l, f"phast_r2c_fft_{fs}_with_planner")(*args, planner._h))
+
+
+def r2c_fft_f64(input_re, output_re, output_im) -> None:
+    """r2c.rs:521"""
+    _r2c("f64", np.float64, input_re, output_re, output_im)
+
+
+def r2c_fft_f32(input_re, output_re, output_im) -> None:
+    """r2c.rs:598"""
+    _r2c("f32", np.float32, input_re, output_re, output_im)
+
+
+def r2c_fft_f64_with_planner(input_re, output_re, output_im, planner: PlannerR2c64) -> None:
+    """r2c.rs:527"""
+    _r2c("f64", np.float64, input_re, output_re, output_im, planner)
+
+
+def r2c_fft_f32_with_planner(input_re, output_re, output_im, planner: PlannerR2c32) -> None:
+    """r2c.rs:607"""
+    _r2c("f32", np.float32, input_re, output_re, output_im, planner)
+
+
+def _c2r(fs, dtype, input_re, input_im, output, planner=None, scratch=None):
+    ire, iim, out = _Slice(input_re, dtype, "input_re"), _Slice(input_im, dtype, "input_im"), _Slice(
+        output, dtype, "output")
+    l = _lib.lib()
+    sc = None
+    if scratch is not None:
+        sc = (_Slice(scratch[0], dtype, "scratch_re"), _Slice(scratch[1], dtype, "scratch_im"))
+    if _same_place(ire, iim, out):
+        own = planner is None
+        if own:
+            planner = (PlannerR2c64 if fs == "f64" else PlannerR2c32)(out.len)  # r2c.rs:696
+        n, half = planner.n, planner.n // 2
+        if out.len != n:
+            _check(8)
+        if ire.len != half + 1:
+            _check(9)
+        if iim.len != half + 1:
+            _check(10)
+        if sc is not None and sc[0].len != half:
+            _check(11)
+        if sc is not None and sc[1].len != half:
+            _check(12)
+        _check(getattr(l, f"phast_c2r_fft_{fs}_dev")(ire.ptr, iim.ptr, out.ptr, C.c_size_t(1), C.c_size_t(half + 1),
+                                                     C.c_size_t(n), planner._h, _stream()))
+        if own:
+            import torch
+
+            torch.cuda.current_stream().synchronize()
+        return
+    args = [ire.ptr, C.c_size_t(ire.len), iim.ptr, C.c_size_t(iim.len), out.ptr, C.c_size_t(out.len)]
+    if planner is None:
+        _check(getattr(l, f"phast_c2r_fft_{fs}")(*args))
+    elif sc is None:
+        _check(getattr(l, f"phast_c2r_fft_{fs}_with_planner")(*args, planner._h))
+    else:
+        _check(getattr(l, f"phast_c2r_fft_{fs}_with_planner_and_scratch")(
+            *args, planner._h, sc[0].ptr, C.c_size_t(sc[0].len), sc[1].ptr, C.c_size_t(sc[1].len)))
+
+
+def c2r_fft_f64(input_re, input_im, output) -> None:
+    """r2c.rs:695"""
+    _c2r("f64", np.float64, input_re, input_im, output)
+
+
+def c2r_fft_f32(input_re, input_im, output) -> None:
+    """r2c.rs:800"""
+    _c2r("f32", np.float32, input_re, input_im, output)
+
+
+def c2r_fft_f64_with_planner(input_re, input_im, output, planner: PlannerR2c64) -> None:
+    """r2c.rs:704"""
+    _c2r("f64", np.float64, input_re, input_im, output, planner)
+
+
+def c2r_fft_f32_with_planner(input_re, input_im, output, planner: PlannerR2c32) -> None:
+    """r2c.rs:809"""
+    _c2r("f32", np.float32, input_re, input_im, output, planner)
+
+
+def c2r_fft_f64_with_planner_and_scratch(input_re, input_im, output, planner, scratch_re, scratch_im) -> None:
+    """r2c.rs:727"""
+    _c2r("f64", np.float64, input_re, input_im, output, planner, (scratch_re, scratch_im))
+
+
+def c2r_fft_f32_with_planner_and_scratch(input_re, input_im, output, planner, scratch_re, scratch_im) -> None:
+    """r2c.rs:832"""
+    _c2r("f32", np.float32, input_re, input_im, output, planner, (scratch_re, scratch_im))
+
+
+# ---------------------------------------------------------------------------------------------
+# harness helpers
+# ---------------------------------------------------------------------------------------------
+def fill_uniform(reals, imags, n: int, seed: int = 0xCAFE, first_id: int = 0) -> None:
+    """Fill device tensors holding ``len/n`` transforms with the counter-based uniform [-1, 1) input
+    (``imags`` may be None for real input)."""
+    import torch
+
+    dtype = np.float64 if reals.dtype == torch.float64 else np.float32
+    fs = "f64" if dtype == np.float64 else "f32"
+    re = _Slice(reals, dtype, "reals")
+    im_ptr = _Slice(imags, dtype, "imags").ptr if imags is not None else C.c_void_p(0)
+    _check(getattr(_lib.lib(), f"phast_fill_{fs}_dev")(re.ptr, im_ptr, C.c_size_t(n), C.c_size_t(re.len // n),
+                                                       C.c_size_t(n), C.c_ulonglong(seed), C.c_ulonglong(first_id),
+                                                       _stream()))
+
+
+def digest(reals, imags, n: int, probe: int = 1):
+    """Per-transform digest [sum re, sum im, sum |z|^2, re[probe]] as an f64 tensor of shape (batch, 4)."""
+    import torch
+
+    dtype = np.float64 if reals.dtype == torch.float64 else np.float32
+    fs = "f64" if dtype == np.float64 else "f32"
+    re, im = _Slice(reals, dtype, "reals"), _Slice(imags, dtype, "imags")
+    batch = re.len // n
+    out = torch.empty((batch, 4), dtype=torch.float64, device=reals.device)
+    _check(getattr(_lib.lib(), f"phast_digest_{fs}_dev")(re.ptr, im.ptr, C.c_size_t(n), C.c_size_t(batch),
+                                                         C.c_size_t(n), C.c_size_t(probe), C.c_void_p(out.data_ptr()),
+                                                         _stream()))
+    return out
+
+
+def device_info() -> dict:
+    name = C.create_string_buffer(256)
+    cus, lds, mem = C.c_int(), C.c_size_t(), C.c_size_t()
+    _check(_lib.lib().phast_device_info(name, C.c_size_t(256), C.byref(cus), C.byref(lds), C.byref(mem)))
+    return {"name": name.value.decode(), "compute_units": cus.value, "lds_per_block": lds.value,
+            "global_mem_bytes": mem.value}

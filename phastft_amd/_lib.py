@@ -1,0 +1,70 @@
+"""Loader for libphastft_hip.so (the C ABI of include/phastft_hip.h).
+
+The HIP library IS the product: there is no CPU path behind this module.  If the shared object is
+missing or a call fails, the caller gets an exception -- never a silent fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libphastft_hip.so")
+
+# every symbol include/phastft_hip.h declares (tests/test_abi.py checks this list against the header)
+SYMBOLS = """
+phast_strerror phast_last_hip_error phast_device_info phast_options_default phast_options_guess
+phast_planner_dit64_new phast_planner_dit64_with_mode phast_planner_dit64_free
+phast_planner_dit32_new phast_planner_dit32_with_mode phast_planner_dit32_free
+phast_planner_dit64_device_bytes phast_planner_dit32_device_bytes
+phast_planner_dit64_describe phast_planner_dit32_describe
+phast_planner_dit64_reserve_batch phast_planner_dit32_reserve_batch
+phast_planner_r2c64_new phast_planner_r2c64_free phast_planner_r2c32_new phast_planner_r2c32_free
+phast_fft_64_dit phast_fft_32_dit phast_fft_64_dit_with_planner phast_fft_32_dit_with_planner
+phast_fft_64_dit_with_planner_and_opts phast_fft_32_dit_with_planner_and_opts
+phast_fft_64_dit_dev phast_fft_32_dit_dev
+phast_bit_rev_f64 phast_bit_rev_f32 phast_bit_rev_f64_dev phast_bit_rev_f32_dev
+phast_r2c_fft_f64 phast_r2c_fft_f32 phast_r2c_fft_f64_with_planner phast_r2c_fft_f32_with_planner
+phast_r2c_fft_f64_dev phast_r2c_fft_f32_dev
+phast_c2r_fft_f64 phast_c2r_fft_f32 phast_c2r_fft_f64_with_planner phast_c2r_fft_f32_with_planner
+phast_c2r_fft_f64_with_planner_and_scratch phast_c2r_fft_f32_with_planner_and_scratch
+phast_c2r_fft_f64_dev phast_c2r_fft_f32_dev
+phast_fill_f64_dev phast_fill_f32_dev phast_digest_f64_dev phast_digest_f32_dev
+phast_planner_dit64_set_plan phast_planner_dit32_set_plan
+phast_planner_dit64_time_passes phast_planner_dit32_time_passes
+""".split()
+
+
+class PhastOptions(C.Structure):
+    """`phast_options` (options.rs:10-24)."""
+
+    _fields_ = [("multithreaded_bit_reversal", C.c_int), ("smallest_parallel_chunk_size", C.c_size_t)]
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m phastft_amd.build` (hipcc, gfx950). "
+            "phastft_amd has no CPU fallback.")
+    l = C.CDLL(LIB_PATH)
+    l.phast_strerror.restype = C.c_char_p
+    l.phast_strerror.argtypes = [C.c_int]
+    l.phast_last_hip_error.restype = C.c_char_p
+    l.phast_planner_dit64_device_bytes.restype = C.c_size_t
+    l.phast_planner_dit32_device_bytes.restype = C.c_size_t
+    for name in SYMBOLS:
+        fn = getattr(l, name)  # AttributeError here = header/library mismatch
+        if fn.restype is C.c_int and name not in ("phast_options_default",):
+            pass
+    l.phast_options_default.restype = None
+    for sfx in ("64", "32"):
+        getattr(l, f"phast_planner_dit{sfx}_free").restype = None
+        getattr(l, f"phast_planner_r2c{sfx}_free").restype = None
+    _lib = l
+    return l

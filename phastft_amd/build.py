@@ -1,0 +1,97 @@
+"""Builds phastft_amd/lib/libphastft_hip.so from phastft_amd/csrc/*.hip with hipcc for gfx950.
+
+    python -m phastft_amd.build [--force] [--jobs N]
+
+The library is the product: hand-written HIP kernels + the C ABI of include/phastft_hip.h.  hipcc
+cross-compiles without a GPU, so this runs in the build container and the .so travels to the GPU box.
+"""
+from __future__ import annotations
+
+import argparse
+import concurrent.futures as cf
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "csrc", "build")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIB_DIR, "libphastft_hip.so")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+
+UNITS = ["api", "tile_f64_a", "tile_f64_bc", "tile_f32_a", "tile_f32_bc", "small_fft", "bitrev", "r2c", "fill"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+         "-ffp-contract=fast"]
+
+
+def hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the MI355X library cannot be built without ROCm")
+    return exe
+
+
+def _deps() -> list[str]:
+    return [os.path.join(SRC, f) for f in os.listdir(SRC) if f.endswith((".hpp", ".h"))] + \
+           [os.path.join(INCLUDE, "phastft_hip.h"), os.path.abspath(__file__)]
+
+
+def _stale(target: str, sources: list[str]) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _compile(unit: str, force: bool) -> str:
+    src = os.path.join(SRC, unit + ".hip")
+    obj = os.path.join(OBJ, unit + ".o")
+    if force or _stale(obj, [src] + _deps()):
+        cmd = [hipcc(), *FLAGS, "-I", INCLUDE, "-c", src, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {unit}:\n{r.stdout}\n{r.stderr}")
+    return obj
+
+
+EMU_LIB = os.path.join(LIB_DIR, "libphastft_emu.so")
+
+
+def build_emulator(force: bool = False) -> str:
+    """CPU emulator of the tile kernels (test infrastructure; never loaded by the product package)."""
+    os.makedirs(LIB_DIR, exist_ok=True)
+    src = os.path.join(SRC, "emu.hip")
+    if force or _stale(EMU_LIB, [src] + _deps()):
+        # host code only: the kernels in the headers are compiled for the device but never launched
+        cmd = [hipcc(), *FLAGS, "-I", INCLUDE, "-shared", src, "-o", EMU_LIB]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for emu:\n{r.stdout}\n{r.stderr}")
+    return EMU_LIB
+
+
+def build(force: bool = False, jobs: int | None = None, verbose: bool = False) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(LIB_DIR, exist_ok=True)
+    jobs = jobs or min(len(UNITS), os.cpu_count() or 4)
+    with cf.ThreadPoolExecutor(jobs) as ex:
+        objs = list(ex.map(lambda u: _compile(u, force), UNITS))
+    if force or _stale(LIB, objs):
+        cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    if verbose:
+        print(LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--jobs", type=int, default=None)
+    a = ap.parse_args()
+    build(a.force, a.jobs, verbose=True)
+    sys.exit(0)

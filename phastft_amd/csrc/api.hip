@@ -1,0 +1,829 @@
+// api.hip -- host side of libphastft_hip.so: planners, pass plans, launches and the C ABI of
+// include/phastft_hip.h.  Mirrors PhastFT's public surface (lib.rs:143-226, planner.rs, options.rs,
+// algorithms/r2c.rs:521-895, algorithms/bravo.rs:303-324); see DESIGN.md for the mapping.
+//
+// There is NO CPU fallback in this library: without a gfx950 device every compute entry point returns
+// PHAST_ERR_NO_DEVICE / PHAST_ERR_HIP.
+#include "../../include/phastft_hip.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+#include "plan.hpp"
+#include "tile_dispatch.hpp"
+
+namespace phast {
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_hip_err[256] = "";
+
+static int hip_fail(hipError_t e, const char *what) {
+    std::snprintf(g_hip_err, sizeof g_hip_err, "%s: %s", what, hipGetErrorString(e));
+    return e == hipErrorNoDevice ? PHAST_ERR_NO_DEVICE : PHAST_ERR_HIP;
+}
+#define PHAST_HIP(call)                                     \
+    do {                                                    \
+        hipError_t e_ = (call);                             \
+        if (e_ != hipSuccess) return hip_fail(e_, #call);   \
+    } while (0)
+
+static int g_cus = 0;
+static int ensure_device() {
+    static std::once_flag once;
+    static int status = PHAST_OK;
+    std::call_once(once, [] {
+        int count = 0;
+        hipError_t e = hipGetDeviceCount(&count);
+        if (e != hipSuccess || count == 0) {
+            std::snprintf(g_hip_err, sizeof g_hip_err, "hipGetDeviceCount: %s", hipGetErrorString(e));
+            status = PHAST_ERR_NO_DEVICE;
+            return;
+        }
+        int dev = 0;
+        hipGetDevice(&dev);
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) g_cus = prop.multiProcessorCount;
+        if (g_cus <= 0) g_cus = 256;
+    });
+    return status;
+}
+
+static inline bool is_pow2(size_t n) { return n != 0 && (n & (n - 1)) == 0; }
+static inline unsigned ilog2(size_t n) { return 63u - (unsigned)__builtin_clzll((unsigned long long)n); }
+
+template <typename T> static int upload(const std::vector<cx_t<T>> &h, void **d_out) {
+    void *d = nullptr;
+    PHAST_HIP(hipMalloc(&d, h.size() * sizeof(cx_t<T>)));
+    hipError_t e = hipMemcpy(d, h.data(), h.size() * sizeof(cx_t<T>), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        hipFree(d);
+        return hip_fail(e, "hipMemcpy(twiddles)");
+    }
+    *d_out = d;
+    return PHAST_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// planner
+// ------------------------------------------------------------------------------------------------
+struct PassDesc : PassGeom {
+    void *d_tw3 = nullptr;
+    void *d_twr = nullptr;
+    int blocks_per_cu = 1;
+    size_t lds = 0;
+};
+
+template <typename T> struct Types;
+template <> struct Types<double> {
+    static hipError_t launch_a(int lr, int lc, unsigned g, hipStream_t s, const TileArgs &a, bool q, int *b, size_t *l) {
+        return launch_tile_f64_a(lr, lc, g, s, a, q, b, l);
+    }
+    static hipError_t launch_bc(int lr, int lc, unsigned g, hipStream_t s, const TileArgs &a, bool q, int *b, size_t *l) {
+        return launch_tile_f64_bc(lr, lc, g, s, a, q, b, l);
+    }
+};
+template <> struct Types<float> {
+    static hipError_t launch_a(int lr, int lc, unsigned g, hipStream_t s, const TileArgs &a, bool q, int *b, size_t *l) {
+        return launch_tile_f32_a(lr, lc, g, s, a, q, b, l);
+    }
+    static hipError_t launch_bc(int lr, int lc, unsigned g, hipStream_t s, const TileArgs &a, bool q, int *b, size_t *l) {
+        return launch_tile_f32_bc(lr, lc, g, s, a, q, b, l);
+    }
+};
+
+static size_t scratch_target_bytes() {
+    const char *env = std::getenv("PHAST_SCRATCH_MB");
+    if (env && *env) {
+        long v = std::atol(env);
+        if (v > 0) return (size_t)v << 20;
+    }
+    return (size_t)256 << 20;  // about the Infinity Cache: keeps the inter-pass buffer of a batch chunk on die
+}
+
+// measurement hook: hipEvents recorded on the launch stream around every pass kernel (bench.py "roofline")
+struct PassTimer {
+    std::vector<hipEvent_t> ev;       // start/stop pairs in launch order
+    std::vector<int> pass_of;         // pass index of every pair
+    ~PassTimer() {
+        for (auto e : ev) hipEventDestroy(e);
+    }
+    hipError_t mark(hipStream_t s) {
+        hipEvent_t e;
+        hipError_t rc = hipEventCreate(&e);
+        if (rc != hipSuccess) return rc;
+        ev.push_back(e);
+        return hipEventRecord(e, s);
+    }
+};
+
+template <typename T> struct Planner {
+    size_t n = 0;
+    unsigned log_n = 0;
+    std::vector<PassDesc> passes;  // empty => small path
+    void *d_small_tw = nullptr;
+    mutable T *d_scratch = nullptr;  // [cap][2][n]: re plane then im plane per transform
+    mutable size_t scratch_cap = 0;
+    mutable size_t reserve = 1;
+    mutable std::mutex mu;
+    mutable size_t table_bytes = 0;
+
+    ~Planner() { release(); }
+    void release_passes() {
+        for (auto &p : passes) {
+            if (p.d_tw3) hipFree(p.d_tw3);
+            if (p.d_twr) hipFree(p.d_twr);
+        }
+        passes.clear();
+    }
+    void release() {
+        release_passes();
+        if (d_small_tw) hipFree(d_small_tw);
+        if (d_scratch) hipFree(d_scratch);
+        d_small_tw = nullptr;
+        d_scratch = nullptr;
+        scratch_cap = 0;
+    }
+
+    int set_plan(const std::vector<unsigned> &lrs, unsigned tile_log) {
+        std::vector<PassGeom> geo;
+        if (!make_passes(log_n, lrs, tile_log, geo)) return PHAST_ERR_INVALID_ARG;
+        std::vector<PassDesc> ps(geo.size());
+        for (size_t i = 0; i < geo.size(); ++i) static_cast<PassGeom &>(ps[i]) = geo[i];
+        size_t tb = 0;
+        for (size_t i = 0; i < ps.size(); ++i) {
+            int rc = upload<T>(host_twr<T>(1u << ps[i].lr), &ps[i].d_twr);
+            if (rc == PHAST_OK && ps[i].pre_tw) {
+                rc = upload<T>(host_tw3<T>(ps[i].log_mod(), ps[i].tw_bits), &ps[i].d_tw3);
+                tb += ((size_t)3 << ps[i].tw_bits) * sizeof(cx_t<T>);
+            }
+            tb += 64 * sizeof(cx_t<T>);
+            if (rc == PHAST_OK) {
+                TileArgs ta{};
+                ta.tw_bits = ps[i].tw_bits;
+                hipError_t e = ps[i].transpose
+                                   ? Types<T>::launch_a(ps[i].lr, ps[i].lc, 0, nullptr, ta, true, &ps[i].blocks_per_cu, &ps[i].lds)
+                                   : Types<T>::launch_bc(ps[i].lr, ps[i].lc, 0, nullptr, ta, true, &ps[i].blocks_per_cu, &ps[i].lds);
+                if (e != hipSuccess) rc = hip_fail(e, "occupancy query");
+                if (ps[i].blocks_per_cu < 1) ps[i].blocks_per_cu = 1;
+            }
+            if (rc != PHAST_OK) {
+                for (auto &p : ps) {
+                    if (p.d_tw3) hipFree(p.d_tw3);
+                    if (p.d_twr) hipFree(p.d_twr);
+                }
+                return rc;
+            }
+        }
+        std::lock_guard<std::mutex> lk(mu);
+        release_passes();
+        passes = std::move(ps);
+        table_bytes = tb;
+        return PHAST_OK;
+    }
+
+    int init(size_t num_points) {
+        n = num_points;
+        log_n = ilog2(n);
+        int rc = ensure_device();
+        if (rc) return rc;
+        if (log_n <= kSmallMaxLog) {
+            std::vector<cx_t<T>> h = host_small_tw<T>(n);
+            table_bytes = h.size() * sizeof(cx_t<T>);
+            return upload<T>(h, &d_small_tw);
+        }
+        std::vector<unsigned> lrs;
+        unsigned tile_log;
+        heuristic_plan<T>(log_n, lrs, tile_log);
+        return set_plan(lrs, tile_log);
+    }
+
+    // scratch for `want` transforms in flight (capped by the target footprint, at least 1)
+    int ensure_scratch(size_t batch, size_t *cap_out) const {
+        if (passes.empty()) {
+            *cap_out = batch;
+            return PHAST_OK;
+        }
+        std::lock_guard<std::mutex> lk(mu);
+        const size_t per = 2 * n * sizeof(T);
+        size_t want = scratch_target_bytes() / per;
+        if (want < 1) want = 1;
+        if (want < reserve) want = reserve;
+        if (want > batch && batch >= reserve) want = batch;
+        if (scratch_cap < want) {
+            if (d_scratch) {
+                hipDeviceSynchronize();
+                hipFree(d_scratch);
+                d_scratch = nullptr;
+                scratch_cap = 0;
+            }
+            void *d = nullptr;
+            PHAST_HIP(hipMalloc(&d, want * per));
+            d_scratch = reinterpret_cast<T *>(d);
+            scratch_cap = want;
+        }
+        *cap_out = scratch_cap;
+        return PHAST_OK;
+    }
+
+    size_t device_bytes() const { return table_bytes + scratch_cap * 2 * n * sizeof(T); }
+
+    std::string describe() const {
+        char buf[512];
+        if (passes.empty()) {
+            std::snprintf(buf, sizeof buf, "n=2^%u small-lds (1 kernel)", log_n);
+            return buf;
+        }
+        std::string s = "n=2^" + std::to_string(log_n) + " passes=" + std::to_string(passes.size());
+        for (auto &p : passes) {
+            std::snprintf(buf, sizeof buf, " [%ux%u %s lds=%zuB wg/cu=%d tw_bits=%u]", 1u << p.lr, 1u << p.lc,
+                          p.transpose ? "A" : "BC", p.lds, p.blocks_per_cu, p.tw_bits);
+            s += buf;
+        }
+        return s;
+    }
+
+    // One batched transform: in -> out (may alias for the planar in-place case), forward arithmetic,
+    // output scaled by `scale`.  in_mode/out_mode: 0 planar, 1 interleaved (re,im), 2 interleaved (im,re).
+    int exec(const void *in_re, const void *in_im, size_t in_dist, unsigned in_mode, void *out_re, void *out_im,
+             size_t out_dist, unsigned out_mode, size_t batch, double scale, hipStream_t stream,
+             PassTimer *timer = nullptr) const {
+        if (batch == 0) return PHAST_OK;
+        if (passes.empty()) {
+            for (size_t b0 = 0; b0 < batch; b0 += 0x7fffffffu) {
+                SmallArgs sa{};
+                const size_t nb = batch - b0 < 0x7fffffffu ? batch - b0 : 0x7fffffffu;
+                const size_t isz = in_mode ? 2 * sizeof(T) : sizeof(T), osz = out_mode ? 2 * sizeof(T) : sizeof(T);
+                sa.in_re = (const char *)in_re + b0 * in_dist * isz;
+                sa.in_im = in_im ? (const char *)in_im + b0 * in_dist * isz : nullptr;
+                sa.out_re = (char *)out_re + b0 * out_dist * osz;
+                sa.out_im = out_im ? (char *)out_im + b0 * out_dist * osz : nullptr;
+                sa.tw = d_small_tw;
+                sa.in_dist = in_dist;
+                sa.out_dist = out_dist;
+                sa.log_n = log_n;
+                sa.batch = (unsigned)nb;
+                sa.in_interleaved = in_mode;
+                sa.out_interleaved = out_mode;
+                sa.scale = scale;
+                if (timer) PHAST_HIP(timer->mark(stream));
+                PHAST_HIP(launch_small_fft<T>(sa, stream));
+                if (timer) {
+                    PHAST_HIP(timer->mark(stream));
+                    timer->pass_of.push_back(0);
+                }
+            }
+            return PHAST_OK;
+        }
+        size_t cap = 0;
+        int rc = ensure_scratch(batch, &cap);
+        if (rc) return rc;
+        T *s_re = d_scratch;               // plane layout: all re planes, then all im planes
+        T *s_im = d_scratch + cap * n;
+        const size_t np = passes.size();
+        for (size_t b0 = 0; b0 < batch; b0 += cap) {
+            const size_t nb = batch - b0 < cap ? batch - b0 : cap;
+            for (size_t i = 0; i < np; ++i) {
+                const PassDesc &p = passes[i];
+                TileArgs ta{};
+                const bool first = i == 0, last = i + 1 == np;
+                if (first) {
+                    const size_t isz = in_mode ? 2 * sizeof(T) : sizeof(T);
+                    ta.in_re = (const char *)in_re + b0 * in_dist * isz;
+                    ta.in_im = in_im ? (const char *)in_im + b0 * in_dist * isz : nullptr;
+                    ta.in_dist = in_dist;
+                    ta.in_interleaved = in_mode;
+                } else {
+                    ta.in_re = s_re;
+                    ta.in_im = s_im;
+                    ta.in_dist = n;
+                }
+                if (last) {
+                    const size_t osz = out_mode ? 2 * sizeof(T) : sizeof(T);
+                    ta.out_re = (char *)out_re + b0 * out_dist * osz;
+                    ta.out_im = out_im ? (char *)out_im + b0 * out_dist * osz : nullptr;
+                    ta.out_dist = out_dist;
+                    ta.out_interleaved = out_mode;
+                    ta.scale = scale;
+                } else {
+                    ta.out_re = s_re;
+                    ta.out_im = s_im;
+                    ta.out_dist = n;
+                    ta.scale = 1.0;
+                }
+                ta.tw3 = p.d_tw3;
+                ta.twr = p.d_twr;
+                if (((unsigned long long)nb << (log_n - p.lr - p.lc)) > 0xffffffffull) return PHAST_ERR_INVALID_ARG;
+                geom_to_args(p, log_n, nb, ta);
+                unsigned grid = (unsigned)p.blocks_per_cu * (unsigned)g_cus;
+                if (grid > ta.tiles_total) grid = ta.tiles_total;
+                if (grid >= 8) grid &= ~7u;  // keep tile%8 == workgroup%8 (XCD affinity of the tile order)
+                if (timer) PHAST_HIP(timer->mark(stream));
+                hipError_t e = p.transpose ? Types<T>::launch_a(p.lr, p.lc, grid, stream, ta, false, nullptr, nullptr)
+                                           : Types<T>::launch_bc(p.lr, p.lc, grid, stream, ta, false, nullptr, nullptr);
+                if (e != hipSuccess) return hip_fail(e, "tile_fft launch");
+                if (timer) {
+                    PHAST_HIP(timer->mark(stream));
+                    timer->pass_of.push_back((int)i);
+                }
+            }
+        }
+        return PHAST_OK;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// R2C planner (planner.rs:164-212)
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct PlannerR2c {
+    size_t n = 0;
+    Planner<T> dit;
+    void *d_tw3 = nullptr;  // W_N^e three-level table for the untangle / c2r-preprocess passes
+    unsigned tw_bits = 1;
+    mutable T *d_z = nullptr;  // C2R workspace [cap][2][n/2]
+    mutable size_t z_cap = 0;
+    mutable std::mutex mu;
+    ~PlannerR2c() {
+        if (d_tw3) hipFree(d_tw3);
+        if (d_z) hipFree(d_z);
+    }
+    int init(size_t n_) {
+        n = n_;
+        int rc = dit.init(n / 2);
+        if (rc) return rc;
+        tw_bits = tw3_bits_for(ilog2(n));
+        return upload<T>(host_tw3<T>(ilog2(n), tw_bits), &d_tw3);
+    }
+    int ensure_z(size_t batch, size_t *cap_out) const {
+        std::lock_guard<std::mutex> lk(mu);
+        const size_t per = n * sizeof(T);  // 2 planes of n/2
+        size_t want = scratch_target_bytes() / per;
+        if (want < 1) want = 1;
+        if (want > batch) want = batch;
+        if (z_cap < want) {
+            if (d_z) {
+                hipDeviceSynchronize();
+                hipFree(d_z);
+                d_z = nullptr;
+                z_cap = 0;
+            }
+            void *d = nullptr;
+            PHAST_HIP(hipMalloc(&d, want * per));
+            d_z = reinterpret_cast<T *>(d);
+            z_cap = want;
+        }
+        *cap_out = z_cap;
+        return PHAST_OK;
+    }
+
+    // r2c.rs:527-593 / 607-662 on device pointers
+    int r2c(const T *d_in, T *d_ore, T *d_oim, size_t batch, size_t in_dist, size_t out_dist, hipStream_t s) const {
+        const size_t half = n / 2;
+        if (in_dist & 1) return PHAST_ERR_INVALID_ARG;  // the input is read as (even, odd) pairs
+        int rc = dit.exec(d_in, nullptr, in_dist / 2, 1, d_ore, d_oim, out_dist, 0, batch, 1.0, s);
+        if (rc) return rc;
+        for (size_t b0 = 0; b0 < batch; b0 += 65535) {
+            UntangleArgs ua{};
+            ua.re = d_ore + b0 * out_dist;
+            ua.im = d_oim + b0 * out_dist;
+            ua.tw3 = d_tw3;
+            ua.dist = out_dist;
+            ua.half = (unsigned)half;
+            ua.tw_bits = tw_bits;
+            ua.batch = (unsigned)(batch - b0 < 65535 ? batch - b0 : 65535);
+            PHAST_HIP(launch_untangle<T>(ua, s));
+        }
+        return PHAST_OK;
+    }
+
+    // r2c.rs:727-790 / 832-895 on device pointers
+    int c2r(const T *d_ire, const T *d_iim, T *d_out, size_t batch, size_t in_dist, size_t out_dist,
+            hipStream_t s) const {
+        const size_t half = n / 2;
+        if (out_dist & 1) return PHAST_ERR_INVALID_ARG;
+        size_t cap = 0;
+        int rc = ensure_z(batch, &cap);
+        if (rc) return rc;
+        for (size_t b0 = 0; b0 < batch; b0 += cap) {
+            const size_t nb = batch - b0 < cap ? batch - b0 : cap;
+            T *z_re = d_z, *z_im = d_z + cap * half;
+            C2rPreArgs pa{};
+            pa.in_re = d_ire + b0 * in_dist;
+            pa.in_im = d_iim + b0 * in_dist;
+            pa.z_re = z_re;
+            pa.z_im = z_im;
+            pa.tw3 = d_tw3;
+            pa.in_dist = in_dist;
+            pa.z_dist = half;
+            pa.half = (unsigned)half;
+            pa.tw_bits = tw_bits;
+            pa.batch = (unsigned)nb;
+            PHAST_HIP(launch_c2r_preprocess<T>(pa, s));
+            // inverse by the swap trick (algorithms/dit.rs:297-300): forward FFT of (z_im, z_re), 1/half scale,
+            // and the (positional re, positional im) = (caller im, caller re) pair is stored as (im, re)
+            rc = dit.exec(z_im, z_re, half, 0, d_out + b0 * out_dist, nullptr, out_dist / 2, 2, nb,
+                          1.0 / (double)half, s);
+            if (rc) return rc;
+        }
+        return PHAST_OK;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// helpers shared by the C entry points
+// ------------------------------------------------------------------------------------------------
+template <typename P> static int planner_new(size_t n, P **out) {  // P = Planner<T> or the C-ABI struct over it
+    if (!out) return PHAST_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!is_pow2(n)) return PHAST_ERR_NOT_POW2;  // planner.rs:66
+    auto *p = new (std::nothrow) P();
+    if (!p) return PHAST_ERR_ALLOC;
+    int rc = p->init(n);
+    if (rc) {
+        delete p;
+        return rc;
+    }
+    *out = p;
+    return PHAST_OK;
+}
+
+template <typename P> static int r2c_planner_new(size_t n, P **out) {
+    if (!out) return PHAST_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (n < 4 || !is_pow2(n)) return PHAST_ERR_R2C_N;  // planner.rs:195
+    auto *p = new (std::nothrow) P();
+    if (!p) return PHAST_ERR_ALLOC;
+    int rc = p->init(n);
+    if (rc) {
+        delete p;
+        return rc;
+    }
+    *out = p;
+    return PHAST_OK;
+}
+
+// algorithms/dit.rs:276-332: asserts, swap trick, transform, 1/N scale -- on device pointers
+template <typename T>
+static int fft_dev(T *d_re, T *d_im, size_t n, size_t batch, size_t dist, int direction, const Planner<T> *pl,
+                   hipStream_t s) {
+    if (!pl || !d_re || !d_im) return PHAST_ERR_INVALID_ARG;
+    if (direction != PHAST_FORWARD && direction != PHAST_REVERSE) return PHAST_ERR_INVALID_ARG;
+    if (!is_pow2(n)) return PHAST_ERR_NOT_POW2;
+    if (ilog2(n) != pl->log_n) return PHAST_ERR_PLANNER_SIZE;
+    if (batch > 1 && dist < n) return PHAST_ERR_INVALID_ARG;
+    if (direction == PHAST_REVERSE) return pl->exec(d_im, d_re, dist, 0, d_im, d_re, dist, 0, batch, 1.0 / (double)n, s);
+    return pl->exec(d_re, d_im, dist, 0, d_re, d_im, dist, 0, batch, 1.0, s);
+}
+
+// average kernel duration of every pass over `reps` forward transforms of the same buffers
+template <typename T>
+static int time_passes(const Planner<T> *pl, T *d_re, T *d_im, size_t batch, size_t dist, int reps, float *pass_ms,
+                       int *n_passes, hipStream_t s) {
+    if (!pl || !d_re || !d_im || !pass_ms || !n_passes || reps < 1) return PHAST_ERR_INVALID_ARG;
+    const int np = pl->passes.empty() ? 1 : (int)pl->passes.size();
+    double acc[3] = {0, 0, 0};
+    for (int r = 0; r < reps; ++r) {
+        PassTimer tm;
+        int rc = pl->exec(d_re, d_im, dist, 0, d_re, d_im, dist, 0, batch, 1.0, s, &tm);
+        if (rc) return rc;
+        PHAST_HIP(hipStreamSynchronize(s));
+        for (size_t i = 0; i < tm.pass_of.size(); ++i) {
+            float ms = 0;
+            PHAST_HIP(hipEventElapsedTime(&ms, tm.ev[2 * i], tm.ev[2 * i + 1]));
+            acc[tm.pass_of[i]] += ms;
+        }
+    }
+    for (int i = 0; i < np; ++i) pass_ms[i] = (float)(acc[i] / reps);
+    *n_passes = np;
+    return PHAST_OK;
+}
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() {
+        if (p) hipFree(p);
+    }
+    int alloc(size_t bytes) {
+        PHAST_HIP(hipMalloc(&p, bytes ? bytes : 1));
+        return PHAST_OK;
+    }
+};
+
+// lib.rs:143-226 on host slices: validate as the reference asserts, stage through device memory
+template <typename T>
+static int fft_host(T *re, size_t re_len, T *im, size_t im_len, int direction, const Planner<T> *pl) {
+    if (!pl || (!re && re_len) || (!im && im_len)) return PHAST_ERR_INVALID_ARG;
+    if (direction != PHAST_FORWARD && direction != PHAST_REVERSE) return PHAST_ERR_INVALID_ARG;
+    if (re_len != im_len) return PHAST_ERR_LEN_MISMATCH;     // dit.rs:284
+    if (!is_pow2(re_len)) return PHAST_ERR_NOT_POW2;          // dit.rs:285
+    if (ilog2(re_len) != pl->log_n) return PHAST_ERR_PLANNER_SIZE;  // dit.rs:289
+    const size_t n = re_len, bytes = n * sizeof(T);
+    DevBuf buf;
+    int rc = buf.alloc(2 * bytes);
+    if (rc) return rc;
+    T *d_re = reinterpret_cast<T *>(buf.p), *d_im = d_re + n;
+    PHAST_HIP(hipMemcpy(d_re, re, bytes, hipMemcpyHostToDevice));
+    PHAST_HIP(hipMemcpy(d_im, im, bytes, hipMemcpyHostToDevice));
+    rc = fft_dev<T>(d_re, d_im, n, 1, n, direction, pl, nullptr);
+    if (rc) return rc;
+    PHAST_HIP(hipStreamSynchronize(nullptr));
+    PHAST_HIP(hipMemcpy(re, d_re, bytes, hipMemcpyDeviceToHost));
+    PHAST_HIP(hipMemcpy(im, d_im, bytes, hipMemcpyDeviceToHost));
+    return PHAST_OK;
+}
+
+template <typename T> static int fft_host_noplanner(T *re, size_t re_len, T *im, size_t im_len, int direction) {
+    // lib.rs:180-183: the planner is built from reals.len() first, so a bad length panics in the planner
+    Planner<T> *pl = nullptr;
+    int rc = planner_new(re_len, &pl);
+    if (rc) return rc;
+    rc = fft_host<T>(re, re_len, im, im_len, direction, pl);
+    delete pl;
+    return rc;
+}
+
+template <typename T>
+static int r2c_host(const T *in, size_t in_len, T *ore, size_t ore_len, T *oim, size_t oim_len,
+                    const PlannerR2c<T> *pl) {
+    if (!pl || !in || !ore || !oim) return PHAST_ERR_INVALID_ARG;
+    const size_t n = pl->n, half = n / 2;
+    if (in_len != n) return PHAST_ERR_R2C_INPUT_LEN;
+    if (ore_len != half + 1) return PHAST_ERR_R2C_OUT_RE_LEN;
+    if (oim_len != half + 1) return PHAST_ERR_R2C_OUT_IM_LEN;
+    DevBuf bin, bout;
+    int rc = bin.alloc(n * sizeof(T));
+    if (!rc) rc = bout.alloc(2 * (half + 1) * sizeof(T));
+    if (rc) return rc;
+    T *d_in = reinterpret_cast<T *>(bin.p), *d_ore = reinterpret_cast<T *>(bout.p), *d_oim = d_ore + half + 1;
+    PHAST_HIP(hipMemcpy(d_in, in, n * sizeof(T), hipMemcpyHostToDevice));
+    rc = pl->r2c(d_in, d_ore, d_oim, 1, n, half + 1, nullptr);
+    if (rc) return rc;
+    PHAST_HIP(hipStreamSynchronize(nullptr));
+    PHAST_HIP(hipMemcpy(ore, d_ore, (half + 1) * sizeof(T), hipMemcpyDeviceToHost));
+    PHAST_HIP(hipMemcpy(oim, d_oim, (half + 1) * sizeof(T), hipMemcpyDeviceToHost));
+    return PHAST_OK;
+}
+
+template <typename T>
+static int c2r_host(const T *ire, size_t ire_len, const T *iim, size_t iim_len, T *out, size_t out_len,
+                    const PlannerR2c<T> *pl, bool check_scratch, size_t sre_len, size_t sim_len) {
+    if (!pl || !ire || !iim || !out) return PHAST_ERR_INVALID_ARG;
+    const size_t n = pl->n, half = n / 2;
+    if (out_len != n) return PHAST_ERR_C2R_OUTPUT_LEN;
+    if (ire_len != half + 1) return PHAST_ERR_C2R_IN_RE_LEN;
+    if (iim_len != half + 1) return PHAST_ERR_C2R_IN_IM_LEN;
+    if (check_scratch && sre_len != half) return PHAST_ERR_C2R_SCRATCH_RE;
+    if (check_scratch && sim_len != half) return PHAST_ERR_C2R_SCRATCH_IM;
+    DevBuf bin, bout;
+    int rc = bin.alloc(2 * (half + 1) * sizeof(T));
+    if (!rc) rc = bout.alloc(n * sizeof(T));
+    if (rc) return rc;
+    T *d_ire = reinterpret_cast<T *>(bin.p), *d_iim = d_ire + half + 1, *d_out = reinterpret_cast<T *>(bout.p);
+    PHAST_HIP(hipMemcpy(d_ire, ire, (half + 1) * sizeof(T), hipMemcpyHostToDevice));
+    PHAST_HIP(hipMemcpy(d_iim, iim, (half + 1) * sizeof(T), hipMemcpyHostToDevice));
+    rc = pl->c2r(d_ire, d_iim, d_out, 1, half + 1, n, nullptr);
+    if (rc) return rc;
+    PHAST_HIP(hipStreamSynchronize(nullptr));
+    PHAST_HIP(hipMemcpy(out, d_out, n * sizeof(T), hipMemcpyDeviceToHost));
+    return PHAST_OK;
+}
+
+template <typename T> static int bitrev_host(T *data, size_t len, unsigned log_n) {
+    if (!data && len) return PHAST_ERR_INVALID_ARG;
+    if (log_n > 40 || len != ((size_t)1 << log_n)) return PHAST_ERR_INVALID_ARG;  // bravo.rs:228
+    int rc = ensure_device();
+    if (rc) return rc;
+    if (log_n > 31) return PHAST_ERR_INVALID_ARG;
+    DevBuf buf;
+    rc = buf.alloc(len * sizeof(T));
+    if (rc) return rc;
+    PHAST_HIP(hipMemcpy(buf.p, data, len * sizeof(T), hipMemcpyHostToDevice));
+    PHAST_HIP(launch_bitrev<T>(reinterpret_cast<T *>(buf.p), log_n, 1, len, nullptr));
+    PHAST_HIP(hipStreamSynchronize(nullptr));
+    PHAST_HIP(hipMemcpy(data, buf.p, len * sizeof(T), hipMemcpyDeviceToHost));
+    return PHAST_OK;
+}
+
+template <typename T> static int describe_to(const Planner<T> *p, char *buf, size_t len) {
+    if (!p || !buf || !len) return PHAST_ERR_INVALID_ARG;
+    std::string s = p->describe();
+    std::snprintf(buf, len, "%s", s.c_str());
+    return PHAST_OK;
+}
+
+template <typename T>
+static int set_plan_c(Planner<T> *p, const unsigned *log_rows, size_t n_passes, unsigned tile_log) {
+    if (!p) return PHAST_ERR_INVALID_ARG;
+    if (p->log_n <= kSmallMaxLog) return n_passes == 0 ? PHAST_OK : PHAST_ERR_INVALID_ARG;
+    std::vector<unsigned> lrs;
+    if (n_passes == 0) {
+        heuristic_plan<T>(p->log_n, lrs, tile_log);
+    } else {
+        if (!log_rows) return PHAST_ERR_INVALID_ARG;
+        lrs.assign(log_rows, log_rows + n_passes);
+    }
+    return p->set_plan(lrs, tile_log);
+}
+
+}  // namespace phast
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+using namespace phast;
+
+struct phast_planner_dit64 : Planner<double> {};
+struct phast_planner_dit32 : Planner<float> {};
+struct phast_planner_r2c64 : PlannerR2c<double> {};
+struct phast_planner_r2c32 : PlannerR2c<float> {};
+
+extern "C" {
+
+const char *phast_strerror(int code) {
+    switch (code) {
+    case PHAST_OK: return "ok";
+    case PHAST_ERR_NOT_POW2: return "assertion failed: num_points > 0 && num_points.is_power_of_two()";
+    case PHAST_ERR_LEN_MISMATCH: return "assertion `left == right` failed: reals.len() == imags.len()";
+    case PHAST_ERR_PLANNER_SIZE: return "assertion `left == right` failed: log_n == planner.log_n";
+    case PHAST_ERR_R2C_N: return "n must be a power of 2 >= 4";
+    case PHAST_ERR_R2C_INPUT_LEN: return "input length must match planner size";
+    case PHAST_ERR_R2C_OUT_RE_LEN: return "output_re must have length N/2 + 1";
+    case PHAST_ERR_R2C_OUT_IM_LEN: return "output_im must have length N/2 + 1";
+    case PHAST_ERR_C2R_OUTPUT_LEN: return "output length must match planner size";
+    case PHAST_ERR_C2R_IN_RE_LEN: return "input_re must have length N/2 + 1";
+    case PHAST_ERR_C2R_IN_IM_LEN: return "input_im must have length N/2 + 1";
+    case PHAST_ERR_C2R_SCRATCH_RE: return "scratch_re must have length N/2";
+    case PHAST_ERR_C2R_SCRATCH_IM: return "scratch_im must have length N/2";
+    case PHAST_ERR_ALLOC: return "host allocation failed";
+    case PHAST_ERR_HIP: return "HIP runtime error (see phast_last_hip_error)";
+    case PHAST_ERR_NO_DEVICE: return "no HIP device visible: libphastft_hip has no CPU fallback";
+    case PHAST_ERR_INVALID_ARG: return "invalid argument";
+    default: return "unknown error";
+    }
+}
+
+const char *phast_last_hip_error(void) { return g_hip_err; }
+
+int phast_device_info(char *name, size_t name_len, int *compute_units, size_t *lds_per_block,
+                      size_t *global_mem_bytes) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    int dev = 0;
+    PHAST_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    PHAST_HIP(hipGetDeviceProperties(&prop, dev));
+    if (name && name_len) std::snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (lds_per_block) *lds_per_block = prop.sharedMemPerBlock;
+    if (global_mem_bytes) *global_mem_bytes = prop.totalGlobalMem;
+    return PHAST_OK;
+}
+
+void phast_options_default(phast_options *out) {
+    if (!out) return;
+    out->multithreaded_bit_reversal = 0;
+    out->smallest_parallel_chunk_size = 16384;
+}
+
+int phast_options_guess(size_t input_size, phast_options *out) {
+    if (!out) return PHAST_ERR_INVALID_ARG;
+    if (input_size == 0) return PHAST_ERR_NOT_POW2;  // usize::ilog2(0) panics (options.rs:40)
+    phast_options_default(out);
+    out->multithreaded_bit_reversal = ilog2(input_size) >= 16;
+    return PHAST_OK;
+}
+
+#define PHAST_PLANNER_API(SFX, T)                                                                                  \
+    int phast_planner_dit##SFX##_new(size_t n, phast_planner_dit##SFX **out) {                                     \
+        return planner_new(n, out);                                                                                \
+    }                                                                                                              \
+    int phast_planner_dit##SFX##_with_mode(size_t n, int mode, phast_planner_dit##SFX **out) {                     \
+        if (mode != PHAST_MODE_HEURISTIC && mode != PHAST_MODE_TUNE) return PHAST_ERR_INVALID_ARG;                 \
+        return planner_new(n, out);                                                                                \
+    }                                                                                                              \
+    void phast_planner_dit##SFX##_free(phast_planner_dit##SFX *p) { delete p; }                                    \
+    size_t phast_planner_dit##SFX##_device_bytes(const phast_planner_dit##SFX *p) {                                \
+        return p ? p->device_bytes() : 0;                                                                          \
+    }                                                                                                              \
+    int phast_planner_dit##SFX##_describe(const phast_planner_dit##SFX *p, char *buf, size_t len) {                \
+        return describe_to<T>(p, buf, len);                                                                        \
+    }                                                                                                              \
+    int phast_planner_dit##SFX##_reserve_batch(phast_planner_dit##SFX *p, size_t max_batch) {                      \
+        if (!p || max_batch == 0) return PHAST_ERR_INVALID_ARG;                                                    \
+        p->reserve = max_batch;                                                                                    \
+        size_t cap;                                                                                                \
+        return p->ensure_scratch(max_batch, &cap);                                                                 \
+    }                                                                                                              \
+    int phast_planner_dit##SFX##_set_plan(phast_planner_dit##SFX *p, const unsigned *lr, size_t np, unsigned tl) { \
+        return set_plan_c<T>(p, lr, np, tl);                                                                       \
+    }                                                                                                              \
+    int phast_planner_dit##SFX##_time_passes(const phast_planner_dit##SFX *p, T *d_re, T *d_im, size_t batch,       \
+                                             size_t dist, int reps, float *pass_ms, int *n_passes, void *stream) { \
+        return time_passes<T>(p, d_re, d_im, batch, dist, reps, pass_ms, n_passes,                                 \
+                              static_cast<hipStream_t>(stream));                                                   \
+    }                                                                                                              \
+    int phast_planner_r2c##SFX##_new(size_t n, phast_planner_r2c##SFX **out) {                                     \
+        return r2c_planner_new(n, out);                                                                            \
+    }                                                                                                              \
+    void phast_planner_r2c##SFX##_free(phast_planner_r2c##SFX *p) { delete p; }
+
+PHAST_PLANNER_API(64, double)
+PHAST_PLANNER_API(32, float)
+
+#define PHAST_FFT_API(SFX, FS, T)                                                                                   \
+    int phast_fft_##SFX##_dit(T *re, size_t re_len, T *im, size_t im_len, int direction) {                          \
+        return fft_host_noplanner<T>(re, re_len, im, im_len, direction);                                            \
+    }                                                                                                               \
+    int phast_fft_##SFX##_dit_with_planner(T *re, size_t re_len, T *im, size_t im_len, int direction,               \
+                                           const phast_planner_dit##SFX *pl) {                                      \
+        return fft_host<T>(re, re_len, im, im_len, direction, pl);                                                  \
+    }                                                                                                               \
+    int phast_fft_##SFX##_dit_with_planner_and_opts(T *re, size_t re_len, T *im, size_t im_len, int direction,      \
+                                                    const phast_planner_dit##SFX *pl, const phast_options *opts) {  \
+        if (!opts) return PHAST_ERR_INVALID_ARG;                                                                    \
+        return fft_host<T>(re, re_len, im, im_len, direction, pl);                                                  \
+    }                                                                                                               \
+    int phast_fft_##SFX##_dit_dev(T *d_re, T *d_im, size_t n, size_t batch, size_t dist, int direction,             \
+                                  const phast_planner_dit##SFX *pl, void *stream) {                                 \
+        return fft_dev<T>(d_re, d_im, n, batch, dist, direction, pl, static_cast<hipStream_t>(stream));             \
+    }                                                                                                               \
+    int phast_bit_rev_##FS(T *data, size_t len, unsigned log_n) { return bitrev_host<T>(data, len, log_n); }        \
+    int phast_bit_rev_##FS##_dev(T *d, unsigned log_n, size_t batch, size_t dist, void *stream) {                   \
+        if (!d || log_n > 31 || (batch > 1 && dist < ((size_t)1 << log_n))) return PHAST_ERR_INVALID_ARG;           \
+        int rc = ensure_device();                                                                                   \
+        if (rc) return rc;                                                                                          \
+        PHAST_HIP(launch_bitrev<T>(d, log_n, batch, dist, static_cast<hipStream_t>(stream)));                       \
+        return PHAST_OK;                                                                                            \
+    }                                                                                                               \
+    int phast_r2c_fft_##FS(const T *in, size_t in_len, T *ore, size_t ore_len, T *oim, size_t oim_len) {            \
+        PlannerR2c<T> *pl = nullptr;                                                                                \
+        int rc = r2c_planner_new(in_len, &pl);   /* r2c.rs:522: planner from input_re.len() */                     \
+        if (rc) return rc;                                                                                          \
+        rc = r2c_host<T>(in, in_len, ore, ore_len, oim, oim_len, pl);                                               \
+        delete pl;                                                                                                  \
+        return rc;                                                                                                  \
+    }                                                                                                               \
+    int phast_r2c_fft_##FS##_with_planner(const T *in, size_t in_len, T *ore, size_t ore_len, T *oim,               \
+                                          size_t oim_len, const phast_planner_r2c##SFX *pl) {                       \
+        return r2c_host<T>(in, in_len, ore, ore_len, oim, oim_len, pl);                                             \
+    }                                                                                                               \
+    int phast_r2c_fft_##FS##_dev(const T *d_in, T *d_ore, T *d_oim, size_t batch, size_t in_dist, size_t out_dist,  \
+                                 const phast_planner_r2c##SFX *pl, void *stream) {                                  \
+        if (!pl || !d_in || !d_ore || !d_oim) return PHAST_ERR_INVALID_ARG;                                         \
+        if (batch > 1 && (in_dist < pl->n || out_dist < pl->n / 2 + 1)) return PHAST_ERR_INVALID_ARG;               \
+        return pl->r2c(d_in, d_ore, d_oim, batch, in_dist, out_dist, static_cast<hipStream_t>(stream));             \
+    }                                                                                                               \
+    int phast_c2r_fft_##FS(const T *ire, size_t ire_len, const T *iim, size_t iim_len, T *out, size_t out_len) {    \
+        PlannerR2c<T> *pl = nullptr;                                                                                \
+        int rc = r2c_planner_new(out_len, &pl);   /* r2c.rs:696: planner from output.len() */                      \
+        if (rc) return rc;                                                                                          \
+        rc = c2r_host<T>(ire, ire_len, iim, iim_len, out, out_len, pl, false, 0, 0);                                \
+        delete pl;                                                                                                  \
+        return rc;                                                                                                  \
+    }                                                                                                               \
+    int phast_c2r_fft_##FS##_with_planner(const T *ire, size_t ire_len, const T *iim, size_t iim_len, T *out,       \
+                                          size_t out_len, const phast_planner_r2c##SFX *pl) {                       \
+        return c2r_host<T>(ire, ire_len, iim, iim_len, out, out_len, pl, false, 0, 0);                              \
+    }                                                                                                               \
+    int phast_c2r_fft_##FS##_with_planner_and_scratch(const T *ire, size_t ire_len, const T *iim, size_t iim_len,   \
+                                                      T *out, size_t out_len, const phast_planner_r2c##SFX *pl,     \
+                                                      T *sre, size_t sre_len, T *sim, size_t sim_len) {             \
+        (void)sre;                                                                                                  \
+        (void)sim;                                                                                                  \
+        return c2r_host<T>(ire, ire_len, iim, iim_len, out, out_len, pl, true, sre_len, sim_len);                   \
+    }                                                                                                               \
+    int phast_c2r_fft_##FS##_dev(const T *d_ire, const T *d_iim, T *d_out, size_t batch, size_t in_dist,            \
+                                 size_t out_dist, const phast_planner_r2c##SFX *pl, void *stream) {                 \
+        if (!pl || !d_ire || !d_iim || !d_out) return PHAST_ERR_INVALID_ARG;                                        \
+        if (batch > 1 && (in_dist < pl->n / 2 + 1 || out_dist < pl->n)) return PHAST_ERR_INVALID_ARG;               \
+        return pl->c2r(d_ire, d_iim, d_out, batch, in_dist, out_dist, static_cast<hipStream_t>(stream));            \
+    }                                                                                                               \
+    int phast_fill_##FS##_dev(T *d_re, T *d_im, size_t n, size_t batch, size_t dist, unsigned long long seed,       \
+                              unsigned long long first_id, void *stream) {                                          \
+        if (!d_re) return PHAST_ERR_INVALID_ARG;                                                                    \
+        int rc = ensure_device();                                                                                   \
+        if (rc) return rc;                                                                                          \
+        PHAST_HIP(launch_fill<T>(d_re, d_im, n, batch, dist, seed, first_id, static_cast<hipStream_t>(stream)));    \
+        return PHAST_OK;                                                                                            \
+    }                                                                                                               \
+    int phast_digest_##FS##_dev(const T *d_re, const T *d_im, size_t n, size_t batch, size_t dist, size_t probe,    \
+                                double *d_digest, void *stream) {                                                   \
+        if (!d_re || !d_im || !d_digest) return PHAST_ERR_INVALID_ARG;                                              \
+        int rc = ensure_device();                                                                                   \
+        if (rc) return rc;                                                                                          \
+        PHAST_HIP(launch_digest<T>(d_re, d_im, n, batch, dist, probe, d_digest, static_cast<hipStream_t>(stream))); \
+        return PHAST_OK;                                                                                            \
+    }
+
+PHAST_FFT_API(64, f64, double)
+PHAST_FFT_API(32, f32, float)
+
+}  // extern "C"

@@ -1,0 +1,98 @@
+// common.hpp -- shared device helpers and launch-argument structs of libphastft_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <type_traits>
+
+#define PHAST_HD __host__ __device__ __forceinline__
+
+namespace phast {
+
+// ---- complex pair type: one 8/16-byte LDS or global access per twiddle ----
+template <typename T> struct Cx;
+template <> struct Cx<float> { using type = float2; };
+template <> struct Cx<double> { using type = double2; };
+template <typename T> using cx_t = typename Cx<T>::type;
+
+// compile-time loop: f(std::integral_constant<int, I>{}) for I in [B, E)
+template <int B, int E, typename F> PHAST_HD void static_for(F &&f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+constexpr int bitrev_c(int x, int bits) {
+    int r = 0;
+    for (int i = 0; i < bits; ++i) r |= ((x >> i) & 1) << (bits - 1 - i);
+    return r;
+}
+constexpr int ilog2_c(int x) { return x <= 1 ? 0 : 1 + ilog2_c(x >> 1); }
+
+// (re, im) *= (wr, wi)
+template <typename T> PHAST_HD void cmul(T &re, T &im, T wr, T wi) {
+    T r = re * wr - im * wi;
+    T i = re * wi + im * wr;
+    re = r;
+    im = i;
+}
+
+// Three-level twiddle lookup: W_{2^log_mod}^e = T0[e & m] * T1[(e >> B) & m] * T2[(e >> 2B) & m],
+// tables laid out [3][1 << B] (built on the host in long double, plan.cpp).  `tab` may be LDS or global.
+template <typename T>
+PHAST_HD void tw3_lookup(const cx_t<T> *tab, unsigned bits, unsigned e, T &wr, T &wi) {
+    const unsigned m = (1u << bits) - 1u;
+    cx_t<T> a = tab[e & m];
+    cx_t<T> b = tab[(1u << bits) + ((e >> bits) & m)];
+    cx_t<T> c = tab[(2u << bits) + ((e >> (2 * bits)) & m)];
+    T r = a.x * b.x - a.y * b.y;
+    T i = a.x * b.y + a.y * b.x;
+    wr = r * c.x - i * c.y;
+    wi = r * c.y + i * c.x;
+}
+
+// splitmix64-based synthetic input shared with oracle/pho_fill_* 
+__host__ __device__ inline unsigned long long splitmix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__host__ __device__ inline double uniform_pm1(unsigned long long seed, unsigned long long id, unsigned long long idx) {
+    unsigned long long u = splitmix64(seed ^ (id << 40) ^ idx);
+    return (double)(u >> 11) * 0x1.0p-52 - 1.0;
+}
+
+// ---- launch arguments of one tiled FFT pass (tile_fft.hpp) ----
+// A pass does ROWS-point FFTs along a strided axis of a 2^L array, COLS adjacent columns per tile.
+//   input  element (row n, column g): in  + xform*in_dist  + in_col(g)  + n*2^log_s_in
+//   output element (row k, column g): out + xform*out_dist + out_col(g) + k*out_row_stride
+//   in_col(g)  = ((g >> log_s_in) << (log_s_in + LR)) | (g & (2^log_s_in - 1))
+//   out_col(g) = (g & (2^out_lo_bits - 1)) * out_s1 + (g >> out_lo_bits) * out_s2
+struct TileArgs {
+    const void *in_re;
+    const void *in_im;   // unused when in_interleaved
+    void *out_re;
+    void *out_im;        // unused when out_interleaved
+    const void *tw3;     // [3][1 << tw_bits] complex: W_{ROWS * 2^log_s_in}^e  (pre-twiddle passes)
+    const void *twr;     // [2][32] complex: W_ROWS^e two-level (e = e1*32 + e0)
+    unsigned long long in_dist;
+    unsigned long long out_dist;
+    unsigned long long out_s1;
+    unsigned long long out_s2;
+    unsigned long long out_row_stride;
+    unsigned tiles_per_xform;
+    unsigned tiles_total;
+    unsigned log_s_in;
+    unsigned out_lo_bits;
+    unsigned tw_bits;
+    unsigned in_interleaved;   // input is one array of (re, im) pairs (R2C deinterleave fused into the load)
+    unsigned out_interleaved;  // 1: output is one array of (re, im) pairs (C2R interleave fused into the store);
+                               // 2: pairs stored as (im, re) -- the swap-trick inverse (algorithms/dit.rs:297-300)
+    double scale;              // 1/N on the last pass of an inverse transform, else 1
+};
+
+}  // namespace phast

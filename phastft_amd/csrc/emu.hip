@@ -1,0 +1,168 @@
+// emu.hip -- CPU emulation of the multi-pass tile FFT.  TEST INFRASTRUCTURE (libphastft_emu.so), not
+// part of libphastft_hip.so: it runs the SAME TileBody phase functions and the SAME plan geometry on
+// host memory, thread by thread, so the kernels' index arithmetic, LDS layouts, twiddle tables and
+// pass plans can be checked against the oracle in the GPU-less build container
+// (tests/test_emulator.py).  It is never loaded by the product package.
+#include <cstring>
+#include <vector>
+
+#include "plan.hpp"
+#include "tile_fft.hpp"
+
+namespace phast {
+
+template <typename T> static bool emu_pass(const PassGeom &p, const TileArgs &a) {
+#define PHAST_EMU(LR_, LC_)                                                        \
+    if (p.lr == LR_ && p.lc == LC_) {                                              \
+        if (p.transpose)                                                           \
+            emulate_tile_pass<T, LR_, LC_, false, true>(a);                        \
+        else                                                                       \
+            emulate_tile_pass<T, LR_, LC_, true, false>(a);                        \
+        return true;                                                               \
+    }
+    PHAST_TILE_SHAPES(PHAST_EMU)
+#undef PHAST_EMU
+    return false;
+}
+
+// in -> out through the same pass sequence as Planner<T>::exec (api.hip)
+template <typename T>
+static int emu_exec(const void *in_re, const void *in_im, unsigned in_mode, void *out_re, void *out_im,
+                    unsigned out_mode, unsigned log_n, size_t batch, size_t in_dist, size_t out_dist, double scale,
+                    const unsigned *lrs_in, size_t np_in, unsigned tile_log) {
+    const size_t n = (size_t)1 << log_n;
+    std::vector<unsigned> lrs(lrs_in, lrs_in + np_in);
+    if (lrs.empty()) heuristic_plan<T>(log_n, lrs, tile_log);
+    std::vector<PassGeom> ps;
+    if (!make_passes(log_n, lrs, tile_log, ps)) return 1;
+    std::vector<T> s_re(n * batch), s_im(n * batch);
+    for (size_t i = 0; i < ps.size(); ++i) {
+        const PassGeom &p = ps[i];
+        std::vector<cx_t<T>> twr = host_twr<T>(1u << p.lr), tw3;
+        if (p.pre_tw) tw3 = host_tw3<T>(p.log_mod(), p.tw_bits);
+        TileArgs ta{};
+        const bool first = i == 0, last = i + 1 == ps.size();
+        ta.in_re = first ? in_re : s_re.data();
+        ta.in_im = first ? in_im : s_im.data();
+        ta.in_dist = first ? in_dist : n;
+        ta.in_interleaved = first ? in_mode : 0;
+        ta.out_re = last ? out_re : s_re.data();
+        ta.out_im = last ? out_im : s_im.data();
+        ta.out_dist = last ? out_dist : n;
+        ta.out_interleaved = last ? out_mode : 0;
+        ta.scale = last ? scale : 1.0;
+        ta.tw3 = tw3.data();
+        ta.twr = twr.data();
+        geom_to_args(p, log_n, batch, ta);
+        if (!emu_pass<T>(p, ta)) return 2;
+    }
+    return 0;
+}
+
+}  // namespace phast
+
+namespace phast {
+
+// LDS audit of one tile shape: every exchange must (1) stay inside the buffer, (2) write each used word exactly
+// once, (3) read only written words; and the worst-case bank-conflict degree per wave instruction is
+// reported using the gfx950 rules of MI355X_MICROARCH.md section LDS (reads: 32-lane groups, 32 cells of
+// sizeof(T) [b32] or 8 bytes [b64]; b64 writes: 16-lane groups; b32 writes: 32-lane groups).
+template <typename T, int LR, int LC, bool PRE_TW, bool TRANSPOSE> static int audit_shape(int *max_read_ways, int *max_write_ways) {
+    using Body = TileBody<T, LR, LC, PRE_TW, TRANSPOSE>;
+    constexpr int NT = Body::NT;
+    int errors = 0, rw = 1, ww = 1;
+    auto audit = [&](auto e) {
+        constexpr int E = decltype(e)::value;
+        std::vector<int> written(Body::EXCH, 0);
+        std::vector<std::vector<int>> wa(16, std::vector<int>(NT)), ra(16, std::vector<int>(NT));
+        for (int t = 0; t < NT; ++t)
+            static_for<0, 16>([&](auto P) {
+                wa[P][t] = Body::template waddr<E, decltype(P)::value>(t);
+                ra[P][t] = Body::template raddr<E, decltype(P)::value>(t);
+            });
+        for (int p = 0; p < 16; ++p)
+            for (int t = 0; t < NT; ++t) {
+                if (wa[p][t] < 0 || wa[p][t] >= Body::EXCH) { ++errors; continue; }
+                if (written[wa[p][t]]++) ++errors;
+            }
+        for (int p = 0; p < 16; ++p)
+            for (int t = 0; t < NT; ++t)
+                if (ra[p][t] < 0 || ra[p][t] >= Body::EXCH || !written[ra[p][t]]) ++errors;
+        auto ways = [&](const std::vector<int> &addr, int group) {
+            int worst = 1;
+            for (int base = 0; base < NT; base += group) {
+                int cnt[32] = {0};
+                std::vector<int> seen;
+                for (int l = 0; l < group; ++l) {
+                    const int a = addr[base + l];
+                    bool dup = false;
+                    for (int s_ : seen) dup |= (s_ == a);
+                    if (dup) continue;  // identical addresses broadcast
+                    seen.push_back(a);
+                    const int w = ++cnt[a & 31];
+                    if (w > worst) worst = w;
+                }
+            }
+            return worst;
+        };
+        for (int p = 0; p < 16; ++p) {
+            const int r_ = ways(ra[p], 32), w_ = ways(wa[p], sizeof(T) == 8 ? 16 : 32);
+            if (r_ > rw) rw = r_;
+            if (w_ > ww) ww = w_;
+        }
+    };
+    audit(std::integral_constant<int, 1>{});
+    if constexpr (Body::THREE) audit(std::integral_constant<int, 2>{});
+    if constexpr (TRANSPOSE) audit(std::integral_constant<int, 3>{});
+    *max_read_ways = rw;
+    *max_write_ways = ww;
+    return errors;
+}
+
+}  // namespace phast
+
+extern "C" int phast_emu_audit_lds(int is_f64, unsigned lr, unsigned lc, int transpose, int *max_read_ways,
+                                   int *max_write_ways) {
+#define PHAST_AUD(LR_, LC_)                                                                                         \
+    if (lr == LR_ && lc == LC_) {                                                                                   \
+        if (is_f64)                                                                                                 \
+            return transpose ? phast::audit_shape<double, LR_, LC_, false, true>(max_read_ways, max_write_ways)      \
+                             : phast::audit_shape<double, LR_, LC_, true, false>(max_read_ways, max_write_ways);     \
+        return transpose ? phast::audit_shape<float, LR_, LC_, false, true>(max_read_ways, max_write_ways)           \
+                         : phast::audit_shape<float, LR_, LC_, true, false>(max_read_ways, max_write_ways);          \
+    }
+    PHAST_TILE_SHAPES(PHAST_AUD)
+#undef PHAST_AUD
+    return -1;
+}
+
+extern "C" {
+// planar in-place forward / inverse (swap trick + 1/N as algorithms/dit.rs:297-300,325-331)
+int phast_emu_fft_f64(double *re, double *im, unsigned log_n, size_t batch, int direction, const unsigned *lrs,
+                      size_t np, unsigned tile_log) {
+    const size_t n = (size_t)1 << log_n;
+    if (direction < 0) return phast::emu_exec<double>(im, re, 0, im, re, 0, log_n, batch, n, n, 1.0 / (double)n, lrs, np, tile_log);
+    return phast::emu_exec<double>(re, im, 0, re, im, 0, log_n, batch, n, n, 1.0, lrs, np, tile_log);
+}
+int phast_emu_fft_f32(float *re, float *im, unsigned log_n, size_t batch, int direction, const unsigned *lrs,
+                      size_t np, unsigned tile_log) {
+    const size_t n = (size_t)1 << log_n;
+    if (direction < 0) return phast::emu_exec<float>(im, re, 0, im, re, 0, log_n, batch, n, n, 1.0 / (double)n, lrs, np, tile_log);
+    return phast::emu_exec<float>(re, im, 0, re, im, 0, log_n, batch, n, n, 1.0, lrs, np, tile_log);
+}
+// interleaved input -> planar output (the R2C inner transform) and planar -> interleaved (im, re) (C2R)
+int phast_emu_fft_f32_modes(const float *in_re, const float *in_im, unsigned in_mode, float *out_re, float *out_im,
+                            unsigned out_mode, unsigned log_n, double scale, const unsigned *lrs, size_t np,
+                            unsigned tile_log) {
+    const size_t n = (size_t)1 << log_n;
+    return phast::emu_exec<float>(in_re, in_im, in_mode, out_re, out_im, out_mode, log_n, 1, n, n, scale, lrs, np, tile_log);
+}
+// the default plan of the library for (type, log_n): fills lrs[3], returns the number of passes
+int phast_emu_default_plan(int is_f64, unsigned log_n, unsigned *lrs, unsigned *tile_log) {
+    std::vector<unsigned> v;
+    if (is_f64) phast::heuristic_plan<double>(log_n, v, *tile_log);
+    else phast::heuristic_plan<float>(log_n, v, *tile_log);
+    for (size_t i = 0; i < v.size(); ++i) lrs[i] = v[i];
+    return (int)v.size();
+}
+}

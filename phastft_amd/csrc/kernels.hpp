@@ -1,0 +1,63 @@
+// kernels.hpp -- host-callable launchers of every HIP kernel in libphastft_hip.so.
+#pragma once
+
+#include "common.hpp"
+
+namespace phast {
+
+// ---- small_fft.hip: one workgroup per transform, whole transform in LDS (N <= 2048) ----
+struct SmallArgs {
+    const void *in_re;
+    const void *in_im;
+    void *out_re;
+    void *out_im;
+    const void *tw;  // [N/2] complex W_N^j
+    unsigned long long in_dist;
+    unsigned long long out_dist;
+    unsigned log_n;
+    unsigned batch;
+    unsigned in_interleaved;
+    unsigned out_interleaved;  // 1 = (re, im), 2 = (im, re)
+    double scale;
+};
+constexpr unsigned kSmallMaxLog = 11;
+template <typename T> hipError_t launch_small_fft(const SmallArgs &a, hipStream_t stream);
+
+// ---- bitrev.hip: in-place bit-reversal permutation of `batch` arrays of 2^log_n elements ----
+template <typename T> hipError_t launch_bitrev(T *data, unsigned log_n, size_t batch, size_t dist, hipStream_t stream);
+
+// ---- r2c.hip ----
+struct UntangleArgs {
+    void *re;  // [half + 1], in place
+    void *im;
+    const void *tw3;  // [3][1 << tw_bits]: W_N^e, N = 2*half
+    unsigned long long dist;
+    unsigned half;
+    unsigned tw_bits;
+    unsigned batch;
+};
+template <typename T> hipError_t launch_untangle(const UntangleArgs &a, hipStream_t stream);
+
+struct C2rPreArgs {
+    const void *in_re;  // [half + 1]
+    const void *in_im;
+    void *z_re;  // [half]
+    void *z_im;
+    const void *tw3;
+    unsigned long long in_dist;
+    unsigned long long z_dist;
+    unsigned half;
+    unsigned tw_bits;
+    unsigned batch;
+};
+template <typename T> hipError_t launch_c2r_preprocess(const C2rPreArgs &a, hipStream_t stream);
+
+// ---- fill.hip ----
+template <typename T>
+hipError_t launch_fill(T *re, T *im, size_t n, size_t batch, size_t dist, unsigned long long seed,
+                       unsigned long long first_id, hipStream_t stream);
+template <typename T>
+hipError_t launch_digest(const T *re, const T *im, size_t n, size_t batch, size_t dist, size_t probe, double *digest,
+                         hipStream_t stream);
+
+}  // namespace phast

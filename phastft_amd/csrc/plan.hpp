@@ -1,0 +1,197 @@
+// plan.hpp -- host-only planning shared by the library (api.hip) and the CPU emulator (emu.hip):
+// twiddle tables in long double, the factorisation of N = 2^L into tile passes, and the address
+// geometry of every pass.  GPU counterpart of PlannerDit*::with_mode (planner.rs:65-100) -- but the
+// tables here are O(N^(1/3)) small (three-level factored twiddles) instead of the reference's 2(N-64)
+// scalars, because a streamed N-entry table would add ~50 % HBM traffic to a bandwidth-bound pass.
+#pragma once
+
+#include <cmath>
+#include <vector>
+
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace phast {
+
+// ---- W_m^e = exp(-2*pi*i*e/m) in long double with exact octant symmetry ----
+inline void twiddle_ld(unsigned long long e, unsigned long long m, long double &wr, long double &wi) {
+    e %= m;
+    const unsigned long long k = (8 * e) / m;   // octant
+    const unsigned long long r = 8 * e - k * m;  // in [0, m): position inside the octant, units of (pi/4)/m
+    const long double quarter_pi = 0.785398163397448309615660845819875721L;
+    long double a, b;  // cos / sin of the reduced angle phi in [0, pi/4]
+    const unsigned long long num = (k & 1) ? (m - r) : r;
+    if (num == 0) {
+        a = 1.0L;
+        b = 0.0L;
+    } else if (num == m) {
+        a = b = 0.707106781186547524400844362104849039L;
+    } else {
+        const long double phi = quarter_pi * ((long double)num / (long double)m);
+        a = cosl(phi);
+        b = sinl(phi);
+    }
+    long double c, s;  // cos(theta), sin(theta), theta = 2*pi*e/m
+    switch (k) {
+    case 0: c = a; s = b; break;
+    case 1: c = b; s = a; break;
+    case 2: c = -b; s = a; break;
+    case 3: c = -a; s = b; break;
+    case 4: c = -a; s = -b; break;
+    case 5: c = -b; s = -a; break;
+    case 6: c = b; s = -a; break;
+    default: c = a; s = -b; break;
+    }
+    wr = c;
+    wi = -s;
+    if (wr == 0.0L) wr = 0.0L;  // no negative zeros in the tables
+    if (wi == 0.0L) wi = 0.0L;
+}
+
+template <typename T> inline cx_t<T> twiddle_t(unsigned long long e, unsigned long long m) {
+    long double wr, wi;
+    twiddle_ld(e, m, wr, wi);
+    cx_t<T> v;
+    v.x = (T)wr;
+    v.y = (T)wi;
+    return v;
+}
+
+inline unsigned tw3_bits_for(unsigned log_mod) {
+    unsigned b = (log_mod + 2) / 3;
+    return b ? b : 1;
+}
+
+// [3][1 << bits]: level l entry j = W_{2^log_mod}^{j << (l*bits)}   (tw3_lookup, common.hpp)
+template <typename T> inline std::vector<cx_t<T>> host_tw3(unsigned log_mod, unsigned bits) {
+    const unsigned long long m = 1ull << log_mod;
+    std::vector<cx_t<T>> h((size_t)3 << bits);
+    for (unsigned l = 0; l < 3; ++l)
+        for (unsigned j = 0; j < (1u << bits); ++j) {
+            const unsigned shift = l * bits;
+            const unsigned long long e = shift >= 63 ? 0 : (((unsigned long long)j << shift) % m);
+            h[((size_t)l << bits) + j] = twiddle_t<T>(e, m);
+        }
+    return h;
+}
+
+// [2][32]: W_rows^j and W_rows^(32 j)   (TileBody::twr_lookup)
+template <typename T> inline std::vector<cx_t<T>> host_twr(unsigned rows) {
+    std::vector<cx_t<T>> h(64);
+    for (unsigned j = 0; j < 32; ++j) {
+        h[j] = twiddle_t<T>(j, rows);
+        h[32 + j] = twiddle_t<T>(32ull * j, rows);
+    }
+    return h;
+}
+
+// [n/2]: W_n^j   (small_fft.hip)
+template <typename T> inline std::vector<cx_t<T>> host_small_tw(size_t n) {
+    std::vector<cx_t<T>> h(n / 2 ? n / 2 : 1);
+    for (size_t j = 0; j < h.size(); ++j) h[j] = twiddle_t<T>(j, n);
+    return h;
+}
+
+// ---- tile shapes that exist as kernels: log2(rows), log2(cols) ----
+// 4096-point tiles (256 threads) and 8192-point tiles (512 threads)
+#define PHAST_TILE_SHAPES(X) X(6, 6) X(7, 5) X(8, 4) X(9, 3) X(8, 5) X(9, 4) X(10, 3)
+
+inline bool shape_exists(unsigned lr, unsigned lc) {
+#define PHAST_CHK(LR_, LC_) \
+    if (lr == LR_ && lc == LC_) return true;
+    PHAST_TILE_SHAPES(PHAST_CHK)
+#undef PHAST_CHK
+    return false;
+}
+
+// ---- geometry of one pass (see TileArgs in common.hpp) ----
+struct PassGeom {
+    unsigned lr = 0, lc = 0;
+    bool pre_tw = false, transpose = false;
+    unsigned log_s_in = 0, out_lo_bits = 0, tw_bits = 1;
+    unsigned long long out_s1 = 0, out_s2 = 0, out_row_stride = 0;
+    unsigned log_mod() const { return lr + log_s_in; }  // the inter-pass twiddle is W_{2^log_mod}^{row*lo}
+};
+
+// Default factorisation of L = log2 N (L > kSmallMaxLog); tuned on MI355X.
+template <typename T> inline void heuristic_plan(unsigned L, std::vector<unsigned> &lrs, unsigned &tile_log) {
+    lrs.clear();
+    tile_log = 12;
+    if (L <= kSmallMaxLog) return;
+    const unsigned max12 = sizeof(T) == 8 ? 9 : 8;  // keep COLS*sizeof(T) >= 64-byte segments
+    unsigned np;
+    if (L <= 2 * max12) {
+        np = 2;
+    } else if (L <= 2 * (max12 + 1)) {
+        np = 2;
+        tile_log = 13;
+    } else if (L <= 3 * max12) {
+        np = 3;
+    } else {
+        np = 3;
+        tile_log = 13;
+    }
+    for (unsigned i = 0; i < np; ++i) lrs.push_back(L / np + (i < L % np ? 1 : 0));  // balanced, larger first
+}
+
+// N = 2^L as 2 passes (a, b) or 3 passes (a, b, c):
+//   x[p][r][u] --A: FFT over p, runs out--> S[u][r][q] --B: FFT over r, in place--> S[u][kb][q]
+//              --C: FFT over u--> x[kc][kb][q]            (2 passes: S[r][q] --B--> x[kb][q])
+inline bool make_passes(unsigned L, const std::vector<unsigned> &lrs, unsigned tile_log, std::vector<PassGeom> &ps) {
+    unsigned sum = 0;
+    for (unsigned lr : lrs) sum += lr;
+    if (lrs.size() < 2 || lrs.size() > 3 || sum != L) return false;
+    for (unsigned lr : lrs)
+        if (lr > tile_log || !shape_exists(lr, tile_log - lr)) return false;
+    ps.assign(lrs.size(), PassGeom());
+    const unsigned a = lrs[0], b = lrs[1], c = lrs.size() == 3 ? lrs[2] : 0;
+    for (size_t i = 0; i < lrs.size(); ++i) {
+        ps[i].lr = lrs[i];
+        ps[i].lc = tile_log - lrs[i];
+    }
+    ps[0].transpose = true;  // FFT over the top `a` index bits; every column leaves as one contiguous run
+    ps[0].log_s_in = L - a;
+    ps[0].out_row_stride = 1;
+    if (lrs.size() == 2) {
+        ps[0].out_lo_bits = L - a;  // out_col(g) = g * 2^a
+        ps[0].out_s1 = 1ull << a;
+        ps[0].out_s2 = 0;
+    } else {
+        ps[0].out_lo_bits = c;  // g = r*2^c + u  ->  u*2^(a+b) + r*2^a
+        ps[0].out_s1 = 1ull << (a + b);
+        ps[0].out_s2 = 1ull << a;
+    }
+    // pass B: FFT over r (stride 2^a); columns (u, q); twiddle modulus 2^(a+b); same pattern in and out
+    ps[1].pre_tw = true;
+    ps[1].log_s_in = a;
+    ps[1].out_lo_bits = a;
+    ps[1].out_s1 = 1;
+    ps[1].out_s2 = 1ull << (a + b);
+    ps[1].out_row_stride = 1ull << a;
+    ps[1].tw_bits = tw3_bits_for(a + b);
+    if (lrs.size() == 3) {  // pass C: FFT over u (stride 2^(a+b)); columns (kb, q); modulus 2^L
+        ps[2].pre_tw = true;
+        ps[2].log_s_in = a + b;
+        ps[2].out_lo_bits = a + b;
+        ps[2].out_s1 = 1;
+        ps[2].out_s2 = 1ull << L;
+        ps[2].out_row_stride = 1ull << (a + b);
+        ps[2].tw_bits = tw3_bits_for(L);
+    }
+    for (auto &p : ps)
+        if (p.lc > p.log_s_in) return false;  // a tile needs COLS adjacent columns sharing the row stride
+    return true;
+}
+
+inline void geom_to_args(const PassGeom &p, unsigned log_n, size_t n_xforms, TileArgs &ta) {
+    ta.out_s1 = p.out_s1;
+    ta.out_s2 = p.out_s2;
+    ta.out_row_stride = p.out_row_stride;
+    ta.log_s_in = p.log_s_in;
+    ta.out_lo_bits = p.out_lo_bits;
+    ta.tw_bits = p.tw_bits;
+    ta.tiles_per_xform = 1u << (log_n - p.lr - p.lc);
+    ta.tiles_total = (unsigned)((size_t)ta.tiles_per_xform * n_xforms);
+}
+
+}  // namespace phast

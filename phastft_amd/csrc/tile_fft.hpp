@@ -1,0 +1,428 @@
+// tile_fft.hpp -- one pass of the multi-pass power-of-two FFT for gfx950 (MI355X).
+//
+// Replaces, on the GPU, the reference's per-stage sweeps: kernels/dit.rs:971-1115
+// (fft_dit_chunk_n_*), kernels/dit.rs:132-967 (chunk 8..64), kernels/codelets.rs:34-498, the
+// recursion of algorithms/dit.rs:33-164 and -- in the first pass -- the bit-reversal permutation of
+// algorithms/bravo.rs (the permutation is folded into the first pass's store pattern).
+//
+// Design.  N = 2^L is factored into 2 or 3 passes N = R_A * R_B (* R_C).  A pass
+// runs ROWS-point FFTs along a strided axis; a workgroup owns a tile of ROWS x COLS points (COLS
+// adjacent columns => every global access of a wave covers COLS*sizeof(T)-byte contiguous segments).
+// Each thread holds 16 complex points in registers.  Inside the tile the ROWS-point FFT is a
+// decimation-in-frequency Cooley-Tukey split 16 x R2 (x R3); the radix-16/8/4/2 butterflies run in
+// registers with literal twiddles, and data moves between the radix steps through LDS:
+//     exchange 1 layout [n'][k1]  (row = n'*16 + k1, low bits XOR-swizzled by n' against bank conflicts)
+//     exchange 2 layout [n3][k2][k1]
+// Lanes are (column fastest, butterfly index); both exchanges are bank-conflict free for reads
+// (32-lane groups see G = 32/COLS consecutive rows) and writes.
+// Pass A (TRANSPOSE) additionally transposes through LDS (exchange 3, [col][k], padded) so that each
+// column's ROWS outputs leave as one contiguous run: this is where the digit reversal happens.  Later
+// passes (PRE_TW) multiply by the inter-pass twiddle W_{ROWS*S}^{row*lo} on load, looked up as a product
+// of three small LDS tables.  No MFMA: 6 FMA-class ops per 64 B moved per radix-2 stage -- HBM-bound.
+//
+// The per-thread work is written as __host__ __device__ phase functions (TileBody) so that the very
+// same index arithmetic is executed thread-by-thread on the CPU by csrc/emu.hip (tests/test_emulator.py)
+// -- the build container has no GPU.
+#pragma once
+
+#include "common.hpp"
+
+namespace phast {
+
+// ---- literal twiddles: (re, im) *= W_N^J = exp(-2*pi*i*J/N), N in {2,4,8,16}, 0 <= J < N/2 ----
+template <typename T, int N, int J> PHAST_HD void mul_w(T &re, T &im) {
+    constexpr T S = (T)0.70710678118654752440L;
+    if constexpr (J == 0) {
+    } else if constexpr (4 * J == N) {  // -i
+        T t = re;
+        re = im;
+        im = -t;
+    } else if constexpr (8 * J == N) {  // (1 - i)/sqrt2
+        T r = (re + im) * S;
+        T i = (im - re) * S;
+        re = r;
+        im = i;
+    } else if constexpr (8 * J == 3 * N) {  // (-1 - i)/sqrt2
+        T r = (im - re) * S;
+        T i = -(re + im) * S;
+        re = r;
+        im = i;
+    } else {
+        static_assert(N == 16, "general twiddle only for N=16");
+        constexpr T C1 = (T)0.92387953251128675613L;  // cos(pi/8)
+        constexpr T S1 = (T)0.38268343236508977173L;  // sin(pi/8)
+        constexpr T c = (J == 1) ? C1 : (J == 3) ? S1 : (J == 5) ? -S1 : -C1;
+        constexpr T s = (J == 1 || J == 7) ? S1 : C1;
+        T r = re * c + im * s;
+        T i = im * c - re * s;
+        re = r;
+        im = i;
+    }
+}
+
+// In-register radix-R decimation-in-frequency FFT on regs [OFF, OFF+R).
+// Afterwards position OFF+p holds X[bitrev(p)].
+template <typename T, int R, int OFF> PHAST_HD void fft_reg_dif(T (&re)[16], T (&im)[16]) {
+    static_for<0, ilog2_c(R)>([&](auto st) {
+        constexpr int SPAN = R >> (decltype(st)::value + 1);
+        static_for<0, R / 2>([&](auto bi) {
+            constexpr int B = decltype(bi)::value;
+            constexpr int J = B % SPAN;
+            constexpr int I0 = OFF + (B / SPAN) * 2 * SPAN + J;
+            constexpr int I1 = I0 + SPAN;
+            T ar = re[I0], ai = im[I0], br = re[I1], bi_ = im[I1];
+            re[I0] = ar + br;
+            im[I0] = ai + bi_;
+            T dr = ar - br, di = ai - bi_;
+            mul_w<T, 2 * SPAN, J>(dr, di);
+            re[I1] = dr;
+            im[I1] = di;
+        });
+    });
+}
+
+template <typename T, int LR, int LC, bool PRE_TW, bool TRANSPOSE> struct TileBody {
+    using cx = cx_t<T>;
+    static constexpr int ROWS = 1 << LR;
+    static constexpr int COLS = 1 << LC;
+    static constexpr int NT = ROWS * COLS / 16;  // threads per workgroup, 16 points each
+    static constexpr int M = ROWS / 16;          // threads per column
+    static constexpr int G = COLS >= 32 ? 1 : 32 / COLS;  // rows seen by one 32-lane LDS access group
+    static constexpr bool THREE = LR > 8;        // 16 x 16 x R3, else 16 x R2
+    static constexpr int R2 = THREE ? 16 : M;
+    static constexpr int R3 = THREE ? M / 16 : 1;
+    static constexpr bool PLANE_SEQ = sizeof(T) == 8;  // exchange re and im one after the other (half the LDS)
+    static constexpr int CS = ROWS + G;                // padded column stride of the transposing exchange
+    static constexpr int EXCH = TRANSPOSE ? COLS * CS : ROWS * COLS;
+    static_assert(LR >= 6 && LR <= 10, "tile FFT length 64..1024");
+    static_assert(G <= 16, "swizzle must stay inside the k1 nibble");
+
+    static size_t lds_bytes(unsigned tw_bits) {
+        size_t exch = (size_t)EXCH * sizeof(T) * (PLANE_SEQ ? 1 : 2);
+        size_t tw3 = PRE_TW ? (size_t)(3u << tw_bits) * sizeof(cx) : 0;
+        return exch + tw3 + 64 * sizeof(cx);
+    }
+
+    // what a workgroup shares (LDS on the GPU, plain host arrays in the emulator);
+    // ex_im == ex_re when PLANE_SEQ
+    struct Shared {
+        T *ex_re;
+        T *ex_im;
+        const cx *tw3;
+        const cx *twr;
+    };
+    // what a thread keeps in registers across barriers
+    struct Regs {
+        T re[16], im[16];
+        unsigned xform, g0;
+    };
+
+    PHAST_HD static int col_of(int tid) { return tid & (COLS - 1); }
+    PHAST_HD static int tau_of(int tid) { return tid >> LC; }
+
+    // tile index -> (transform, first column).  XCD-aware order: workgroup b runs on XCD b%8 (observed);
+    // each XCD gets one contiguous run of tiles so that neighbouring column groups -- which share DRAM
+    // pages and L2 lines -- meet in one L2.
+    PHAST_HD static void locate(const TileArgs &a, unsigned t, Regs &r) {
+        const unsigned tile = ((a.tiles_total & 7u) == 0u) ? (t & 7u) * (a.tiles_total >> 3) + (t >> 3) : t;
+        r.xform = tile / a.tiles_per_xform;
+        r.g0 = (tile - r.xform * a.tiles_per_xform) << LC;
+    }
+
+    // ---------------- load rows n = n1*M + tau, apply the inter-pass twiddle ----------------
+    PHAST_HD static void load(const TileArgs &a, const Shared &sh, int tid, Regs &r) {
+        const int col = col_of(tid), tau = tau_of(tid);
+        const unsigned g = r.g0 + col;
+        const unsigned lo = g & ((1u << a.log_s_in) - 1u);
+        const size_t in_col = ((size_t)(g >> a.log_s_in) << (a.log_s_in + LR)) | lo;
+        if (!a.in_interleaved) {
+            const T *pr = reinterpret_cast<const T *>(a.in_re) + (size_t)r.xform * a.in_dist + in_col;
+            const T *pi = reinterpret_cast<const T *>(a.in_im) + (size_t)r.xform * a.in_dist + in_col;
+            static_for<0, 16>([&](auto n1) {
+                const size_t off = (size_t)(decltype(n1)::value * M + tau) << a.log_s_in;
+                r.re[n1] = pr[off];
+                r.im[n1] = pi[off];
+            });
+        } else {
+            const cx *pz = reinterpret_cast<const cx *>(a.in_re) + (size_t)r.xform * a.in_dist + in_col;
+            static_for<0, 16>([&](auto n1) {
+                const size_t off = (size_t)(decltype(n1)::value * M + tau) << a.log_s_in;
+                cx v = pz[off];
+                r.re[n1] = v.x;
+                r.im[n1] = v.y;
+            });
+        }
+        if constexpr (PRE_TW) {
+            static_for<0, 16>([&](auto n1) {
+                const unsigned row = decltype(n1)::value * M + tau;
+                T wr, wi;
+                tw3_lookup<T>(sh.tw3, a.tw_bits, row * lo, wr, wi);
+                cmul(r.re[n1], r.im[n1], wr, wi);
+            });
+        }
+    }
+
+    PHAST_HD static void twr_lookup(const Shared &sh, unsigned e, T &wr, T &wi) {  // W_ROWS^e, e < ROWS
+        cx w0 = sh.twr[e & 31u], w1 = sh.twr[32u + (e >> 5)];
+        wr = w0.x * w1.x - w0.y * w1.y;
+        wi = w0.x * w1.y + w0.y * w1.x;
+    }
+
+    // ---------------- step 1: radix-16 over n1; register p then holds k1 = bitrev4(p) ----------------
+    PHAST_HD static void step1(const Shared &sh, int tid, Regs &r) {
+        const int tau = tau_of(tid);
+        fft_reg_dif<T, 16, 0>(r.re, r.im);
+        static_for<1, 16>([&](auto p) {
+            constexpr int K1 = bitrev_c(decltype(p)::value, 4);
+            T wr, wi;
+            twr_lookup(sh, (unsigned)tau * K1, wr, wi);  // W_ROWS^(n' * k1), n' = tau
+            cmul(r.re[p], r.im[p], wr, wi);
+        });
+    }
+
+    // ---------------- step 2 ----------------
+    // two-level tiles: 16/R2 radix-R2 butterflies per thread, butterfly i has k1 = tau + R2*i (final step)
+    // three-level tiles: one radix-16 over n2 for (k1, n3) = (tau & 15, tau >> 4), then W_{16*R3}^{n3*k2}
+    PHAST_HD static void step2(const Shared &sh, int tid, Regs &r) {
+        if constexpr (!THREE) {
+            static_for<0, 16 / R2>([&](auto i) { fft_reg_dif<T, R2, decltype(i)::value * R2>(r.re, r.im); });
+        } else {
+            const int n3 = tau_of(tid) >> 4;
+            fft_reg_dif<T, 16, 0>(r.re, r.im);
+            static_for<1, 16>([&](auto p) {
+                constexpr int K2 = bitrev_c(decltype(p)::value, 4);
+                T wr, wi;
+                twr_lookup(sh, 16u * (unsigned)n3 * K2, wr, wi);
+                cmul(r.re[p], r.im[p], wr, wi);
+            });
+        }
+    }
+
+    // ---------------- step 3 (three-level only): 16/R3 radix-R3 butterflies, k2 = (tau >> 4) + R3*i ----------------
+    PHAST_HD static void step3(Regs &r) {
+        if constexpr (THREE)
+            static_for<0, 16 / R3>([&](auto i) { fft_reg_dif<T, R3, decltype(i)::value * R3>(r.re, r.im); });
+    }
+
+    // frequency index (row of the tile FFT output) held by register P after the last step
+    template <int P> PHAST_HD static unsigned krow(int tid) {
+        const int tau = tau_of(tid);
+        if constexpr (!THREE) {
+            constexpr int I = P / R2, PP = P % R2;
+            return (unsigned)(tau + R2 * I) + 16u * bitrev_c(PP, ilog2_c(R2));
+        } else {
+            constexpr int I = P / R3, PP = P % R3;
+            return (unsigned)(tau & 15) + 16u * (unsigned)((tau >> 4) + R3 * I) + 256u * bitrev_c(PP, ilog2_c(R3));
+        }
+    }
+
+    // ---------------- LDS exchange addresses; E = 1, 2 (three-level only), 3 (transpose only) ----------------
+    template <int E, int P> PHAST_HD static int waddr(int tid) {
+        const int col = col_of(tid), tau = tau_of(tid);
+        if constexpr (E == 1) {  // logical row n'*16 + k1 with n' = tau, k1 = bitrev4(P)
+            constexpr int K1 = bitrev_c(P, 4);
+            return ((tau * 16 + (K1 ^ (tau & (G - 1)))) << LC) + col;
+        } else if constexpr (E == 2) {  // [n3][k2][k1]
+            constexpr int K2 = bitrev_c(P, 4);
+            return ((((tau >> 4) * 16 + K2) * 16 + (tau & 15)) << LC) + col;
+        } else {  // [col][k]
+            return col * CS + (int)krow<P>(tid);
+        }
+    }
+    template <int E, int P> PHAST_HD static int raddr(int tid) {
+        const int col = col_of(tid), tau = tau_of(tid);
+        if constexpr (E == 1) {
+            if constexpr (!THREE) {
+                constexpr int I = P / R2, N2 = P % R2;  // n' = n2
+                const int k1 = tau + R2 * I;
+                return ((N2 * 16 + (k1 ^ (N2 & (G - 1)))) << LC) + col;
+            } else {
+                const int np = P * R3 + (tau >> 4);  // n' = n2*R3 + n3
+                return ((np * 16 + ((tau & 15) ^ (np & (G - 1)))) << LC) + col;
+            }
+        } else if constexpr (E == 2) {
+            constexpr int I = P / R3, N3 = P % R3;
+            const int k2 = (tau >> 4) + R3 * I;
+            return (((N3 * 16 + k2) * 16 + (tau & 15)) << LC) + col;
+        } else {
+            const int f = P * NT + tid;
+            return (f >> LR) * CS + (f & (ROWS - 1));
+        }
+    }
+    // plane 0 = real parts through ex_re, plane 1 = imaginary parts through ex_im
+    template <int E> PHAST_HD static void ex_write(const Shared &sh, int tid, const Regs &r, int plane) {
+        T *dst = plane ? sh.ex_im : sh.ex_re;
+        static_for<0, 16>([&](auto P) { dst[waddr<E, decltype(P)::value>(tid)] = plane ? r.im[P] : r.re[P]; });
+    }
+    template <int E> PHAST_HD static void ex_read(const Shared &sh, int tid, Regs &r, int plane) {
+        const T *src = plane ? sh.ex_im : sh.ex_re;
+        static_for<0, 16>([&](auto P) {
+            const T v = src[raddr<E, decltype(P)::value>(tid)];
+            if (plane)
+                r.im[P] = v;
+            else
+                r.re[P] = v;
+        });
+    }
+
+    // ---------------- store ----------------
+    PHAST_HD static size_t out_col(const TileArgs &a, unsigned g, unsigned xform) {
+        return (size_t)(g & ((1u << a.out_lo_bits) - 1u)) * a.out_s1 + (size_t)(g >> a.out_lo_bits) * a.out_s2 +
+               (size_t)xform * a.out_dist;
+    }
+    PHAST_HD static void put(const TileArgs &a, size_t off, T re, T im) {
+        const T scale = (T)a.scale;
+        if (!a.out_interleaved) {
+            reinterpret_cast<T *>(a.out_re)[off] = re * scale;
+            reinterpret_cast<T *>(a.out_im)[off] = im * scale;
+        } else {
+            cx v;
+            v.x = (a.out_interleaved == 2 ? im : re) * scale;
+            v.y = (a.out_interleaved == 2 ? re : im) * scale;
+            reinterpret_cast<cx *>(a.out_re)[off] = v;
+        }
+    }
+    PHAST_HD static void store(const TileArgs &a, int tid, const Regs &r) {
+        if constexpr (!TRANSPOSE) {  // register P holds row krow<P> of column g0 + col
+            const size_t base = out_col(a, r.g0 + col_of(tid), r.xform);
+            static_for<0, 16>([&](auto P) {
+                put(a, base + (size_t)krow<decltype(P)::value>(tid) * a.out_row_stride, r.re[P], r.im[P]);
+            });
+        } else {  // after exchange 3: register P holds flat element f = P*NT + tid of the [col][k] tile
+            static_for<0, 16>([&](auto P) {
+                const int f = decltype(P)::value * NT + tid;
+                const size_t off = out_col(a, r.g0 + (unsigned)(f >> LR), r.xform) +
+                                   (size_t)(f & (ROWS - 1)) * a.out_row_stride;
+                put(a, off, r.re[P], r.im[P]);
+            });
+        }
+    }
+};
+
+template <typename T, int LR, int LC, bool PRE_TW, bool TRANSPOSE>
+__global__ void __launch_bounds__(1 << (LR + LC - 4)) tile_fft_kernel(const TileArgs a) {
+    using Body = TileBody<T, LR, LC, PRE_TW, TRANSPOSE>;
+    using cx = cx_t<T>;
+    constexpr int NT = Body::NT;
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T *ex_re = reinterpret_cast<T *>(smem);
+    cx *l_tw3 = reinterpret_cast<cx *>(smem + (size_t)Body::EXCH * sizeof(T) * (Body::PLANE_SEQ ? 1 : 2));
+    cx *l_twr = l_tw3 + (PRE_TW ? (3u << a.tw_bits) : 0u);
+    const typename Body::Shared sh{ex_re, Body::PLANE_SEQ ? ex_re : ex_re + Body::EXCH, l_tw3, l_twr};
+
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 64; i += NT) l_twr[i] = reinterpret_cast<const cx *>(a.twr)[i];
+    if constexpr (PRE_TW)
+        for (unsigned i = tid; i < (3u << a.tw_bits); i += NT) l_tw3[i] = reinterpret_cast<const cx *>(a.tw3)[i];
+    __syncthreads();
+
+    // one exchange: barrier (previous readers done), write, barrier, read -- per plane when PLANE_SEQ
+    auto exchange = [&](auto e, typename Body::Regs &r) {
+        constexpr int E = decltype(e)::value;
+        if constexpr (!Body::PLANE_SEQ) {
+            __syncthreads();
+            Body::template ex_write<E>(sh, tid, r, 0);
+            Body::template ex_write<E>(sh, tid, r, 1);
+            __syncthreads();
+            Body::template ex_read<E>(sh, tid, r, 0);
+            Body::template ex_read<E>(sh, tid, r, 1);
+        } else {
+            for (int plane = 0; plane < 2; ++plane) {
+                __syncthreads();
+                Body::template ex_write<E>(sh, tid, r, plane);
+                __syncthreads();
+                Body::template ex_read<E>(sh, tid, r, plane);
+            }
+        }
+    };
+
+    for (unsigned t = blockIdx.x; t < a.tiles_total; t += gridDim.x) {
+        typename Body::Regs r;
+        Body::locate(a, t, r);
+        Body::load(a, sh, tid, r);
+        Body::step1(sh, tid, r);
+        exchange(std::integral_constant<int, 1>{}, r);
+        Body::step2(sh, tid, r);
+        if constexpr (Body::THREE) {
+            exchange(std::integral_constant<int, 2>{}, r);
+            Body::step3(r);
+        }
+        if constexpr (TRANSPOSE) exchange(std::integral_constant<int, 3>{}, r);
+        Body::store(a, tid, r);
+    }
+}
+
+// host-side launcher for one (T, LR, LC, mode) instantiation
+template <typename T, int LR, int LC, bool PRE_TW, bool TRANSPOSE>
+hipError_t launch_tile_inst(unsigned grid, hipStream_t stream, const TileArgs &a, bool query_only, int *blocks_per_cu,
+                            size_t *lds_out) {
+    using Body = TileBody<T, LR, LC, PRE_TW, TRANSPOSE>;
+    auto kern = tile_fft_kernel<T, LR, LC, PRE_TW, TRANSPOSE>;
+    const size_t lds = Body::lds_bytes(a.tw_bits);
+    if (lds_out) *lds_out = lds;
+    // raise the dynamic-LDS limit only when it grows: the steady state issues no runtime call besides the
+    // launch itself, so a launch sequence can be captured into a HIP graph
+    static size_t lds_limit = 0;
+    if (lds > lds_limit) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        lds_limit = lds;
+    }
+    if (query_only) {
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, reinterpret_cast<const void *>(kern),
+                                                            Body::NT, lds);
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(Body::NT), lds, stream, a);
+    return hipGetLastError();
+}
+
+// Thread-by-thread host execution of one pass: the same TileBody phases, barriers replaced by
+// "every thread finishes the phase".  Test infrastructure for the GPU-less build container.
+template <typename T, int LR, int LC, bool PRE_TW, bool TRANSPOSE> void emulate_tile_pass(const TileArgs &a) {
+    using Body = TileBody<T, LR, LC, PRE_TW, TRANSPOSE>;
+    using Regs = typename Body::Regs;
+    constexpr int NT = Body::NT;
+    T *ex = new T[(size_t)Body::EXCH * 2];
+    const typename Body::Shared sh{ex, Body::PLANE_SEQ ? ex : ex + Body::EXCH,
+                                   reinterpret_cast<const cx_t<T> *>(a.tw3), reinterpret_cast<const cx_t<T> *>(a.twr)};
+    Regs *regs = new Regs[NT];
+    auto exchange = [&](auto e) {
+        constexpr int E = decltype(e)::value;
+        if constexpr (!Body::PLANE_SEQ) {
+            for (int t = 0; t < NT; ++t) {
+                Body::template ex_write<E>(sh, t, regs[t], 0);
+                Body::template ex_write<E>(sh, t, regs[t], 1);
+            }
+            for (int t = 0; t < NT; ++t) {
+                Body::template ex_read<E>(sh, t, regs[t], 0);
+                Body::template ex_read<E>(sh, t, regs[t], 1);
+            }
+        } else {
+            for (int plane = 0; plane < 2; ++plane) {
+                for (int t = 0; t < NT; ++t) Body::template ex_write<E>(sh, t, regs[t], plane);
+                for (int t = 0; t < NT; ++t) Body::template ex_read<E>(sh, t, regs[t], plane);
+            }
+        }
+    };
+    for (unsigned tile = 0; tile < a.tiles_total; ++tile) {
+        for (int t = 0; t < NT; ++t) {
+            Body::locate(a, tile, regs[t]);
+            Body::load(a, sh, t, regs[t]);
+            Body::step1(sh, t, regs[t]);
+        }
+        exchange(std::integral_constant<int, 1>{});
+        for (int t = 0; t < NT; ++t) Body::step2(sh, t, regs[t]);
+        if constexpr (Body::THREE) {
+            exchange(std::integral_constant<int, 2>{});
+            for (int t = 0; t < NT; ++t) Body::step3(regs[t]);
+        }
+        if constexpr (TRANSPOSE) exchange(std::integral_constant<int, 3>{});
+        for (int t = 0; t < NT; ++t) Body::store(a, t, regs[t]);
+    }
+    delete[] regs;
+    delete[] ex;
+}
+
+}  // namespace phast

@@ -1,0 +1,339 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI (phastft_amd -> libphastft_hip.so),
+against the CPU oracle on the same seeded inputs.  Ports the reference's own tests
+(lib.rs:238-461, bravo.rs:373-407, r2c.rs:914-1540) and adds the BASELINE.json sizes.
+
+Tolerances: bit reversal exact; C2C f64 rel-L2 <= 1e-13; f32 rel-L2 <= 1e-5;
+round trip 1e-10 (f64) / 1e-6 (f32) absolute on unit-norm inputs (lib.rs:398,421).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+F64_REL = 1e-13
+F32_REL = 1e-5
+
+
+def rel_l2(got_re, got_im, ref_re, ref_im):
+    num = np.sqrt(np.sum((got_re.astype(np.float64) - ref_re) ** 2 + (got_im.astype(np.float64) - ref_im) ** 2))
+    den = np.sqrt(np.sum(ref_re.astype(np.float64) ** 2 + ref_im.astype(np.float64) ** 2))
+    return num / den if den else num
+
+
+def dev(x):
+    import torch
+
+    return torch.from_numpy(x).cuda()
+
+
+# ---------------------------------------------------------------- bit reversal (bravo.rs:373-407)
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_bit_reversal_exact_all_regimes(gpu, oracle, dtype):
+    fn = gpu.bit_rev_bravo_f64 if dtype == np.float64 else gpu.bit_rev_bravo_f32
+    ofn = oracle.bit_rev_bravo_f64 if dtype == np.float64 else oracle.bit_rev_bravo_f32
+    for n in range(0, 24):
+        big_n = 1 << n
+        data = np.arange(big_n).astype(dtype)  # data[i] = i as the reference's test
+        d = dev(data.copy())
+        fn(d, n)
+        expect = data.copy()
+        if n >= 1:
+            ofn(expect, n)
+        got = d.cpu().numpy()
+        assert np.array_equal(got.view(np.uint64 if dtype == np.float64 else np.uint32),
+                              expect.view(np.uint64 if dtype == np.float64 else np.uint32)), n
+    # host-slice entry point, and involution on random bits incl. NaN payloads
+    rng = np.random.default_rng(7)
+    for n in (3, 10, 13):
+        raw = rng.integers(0, 2**63, size=1 << n, dtype=np.uint64)
+        data = raw.view(np.float64).copy() if dtype == np.float64 else raw.view(np.uint32)[: 1 << n].view(np.float32).copy()
+        orig = data.copy()
+        fn(data, n)
+        fn(data, n)
+        assert np.array_equal(data.view(np.uint8), orig.view(np.uint8))
+
+
+def test_bit_reversal_large_involution_and_checksum(gpu):
+    import torch
+
+    n = 26
+    x = torch.arange(1 << n, dtype=torch.float64, device="cuda")
+    gpu.bit_rev_bravo_f64(x, n)
+    # spot-check the permutation: x[i] == rev(i) for sampled i, and the multiset is preserved
+    idx = torch.tensor([0, 1, 2, 3, 5, (1 << n) - 1, (1 << 25) + 12345, 987654], device="cuda")
+    rev = torch.zeros_like(idx)
+    for b in range(n):
+        rev |= ((idx >> b) & 1) << (n - 1 - b)
+    assert torch.equal(x[idx].to(torch.int64), rev)
+    assert float(x.sum()) == float((1 << n) * ((1 << n) - 1) // 2)
+    gpu.bit_rev_bravo_f64(x, n)
+    assert torch.equal(x, torch.arange(1 << n, dtype=torch.float64, device="cuda"))
+
+
+# ---------------------------------------------------------------- C2C vs the oracle
+@pytest.mark.parametrize("k", list(range(0, 23)))
+def test_fft_64_vs_oracle(gpu, oracle, k):
+    n = 1 << k
+    re, im = oracle.fill(n, np.float64, seed=0xCAFE, transform_id=k)
+    d_re, d_im = dev(re.copy()), dev(im.copy())
+    gpu.fft_64_dit(d_re, d_im, gpu.Direction.Forward)
+    oracle.fft_64_dit(re, im, oracle.FORWARD)
+    assert rel_l2(d_re.cpu().numpy(), d_im.cpu().numpy(), re, im) <= F64_REL
+
+
+@pytest.mark.parametrize("k", list(range(0, 23)))
+def test_fft_32_vs_oracle(gpu, oracle, k):
+    n = 1 << k
+    re, im = oracle.fill(n, np.float32, seed=0xCAFE, transform_id=k)
+    d_re, d_im = dev(re.copy()), dev(im.copy())
+    gpu.fft_32_dit(d_re, d_im, gpu.Direction.Forward)
+    oracle.fft_32_dit(re, im, oracle.FORWARD)
+    assert rel_l2(d_re.cpu().numpy(), d_im.cpu().numpy(), re, im) <= F32_REL
+
+
+def test_fft_correctness_ramp_like_reference(gpu):
+    """lib.rs:298-338: re = im = 1..N vs an independent FFT, abs 0.01 (f64 N=2^4..2^16, f32 2^4..2^8)."""
+    for k in range(4, 17):
+        n = 1 << k
+        ramp = np.arange(1, n + 1, dtype=np.float64)
+        re, im = ramp.copy(), ramp.copy()
+        gpu.fft_64_dit(re, im, gpu.Direction.Forward)  # host slices
+        ref = np.fft.fft(ramp + 1j * ramp)
+        assert np.max(np.abs(re - ref.real)) < 0.01 and np.max(np.abs(im - ref.imag)) < 0.01, k
+    for k in range(4, 9):
+        n = 1 << k
+        ramp = np.arange(1, n + 1, dtype=np.float32)
+        re, im = ramp.copy(), ramp.copy()
+        gpu.fft_32_dit(re, im, gpu.Direction.Forward)
+        ref = np.fft.fft(ramp.astype(np.float64) * (1 + 1j))
+        assert np.max(np.abs(re - ref.real)) < 0.01 and np.max(np.abs(im - ref.imag)) < 0.01, k
+
+
+def test_roundtrip_like_reference(gpu):
+    """lib.rs:381-425: forward then inverse on unit-norm random signals, 1e-10 / 1e-7."""
+    rng = np.random.default_rng(3)
+    for k in range(4, 12):
+        n = 1 << k
+        re, im = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+        s = 1.0 / np.sqrt(np.sum(re * re + im * im))
+        re, im = re * s, im * s
+        r, m = re.copy(), im.copy()
+        gpu.fft_64_dit(r, m, gpu.Direction.Forward)
+        gpu.fft_64_dit(r, m, gpu.Direction.Reverse)
+        assert np.max(np.abs(r - re)) < 1e-10 and np.max(np.abs(m - im)) < 1e-10
+        r32, m32 = re.astype(np.float32), im.astype(np.float32)
+        o_r, o_m = r32.copy(), m32.copy()
+        gpu.fft_32_dit(r32, m32, gpu.Direction.Forward)
+        gpu.fft_32_dit(r32, m32, gpu.Direction.Reverse)
+        assert np.max(np.abs(r32 - o_r)) < 1e-7 and np.max(np.abs(m32 - o_m)) < 1e-7
+
+
+def test_inverse_matches_oracle(gpu, oracle):
+    for k in (3, 9, 14, 20):
+        n = 1 << k
+        re, im = oracle.fill(n, np.float64, transform_id=100 + k)
+        d_re, d_im = dev(re.copy()), dev(im.copy())
+        gpu.fft_64_dit(d_re, d_im, gpu.Direction.Reverse)
+        oracle.fft_64_dit(re, im, oracle.REVERSE)
+        assert rel_l2(d_re.cpu().numpy(), d_im.cpu().numpy(), re, im) <= F64_REL
+
+
+@pytest.mark.parametrize("plan", [((10, 10), 13), ((7, 7, 6), 12), ((9, 8, 3), 12)])
+def test_forced_plans_agree_2p20(gpu, oracle, plan):
+    n = 1 << 20
+    lrs, tl = plan
+    planner = gpu.PlannerDit64(n)
+    try:
+        planner.set_plan(lrs, tl)
+    except gpu.PhastPanic:
+        pytest.skip(f"plan {plan} not instantiable")
+    re, im = oracle.fill(n, np.float64, transform_id=5)
+    d_re, d_im = dev(re.copy()), dev(im.copy())
+    gpu.fft_64_dit_with_planner(d_re, d_im, gpu.Direction.Forward, planner)
+    oracle.fft_64_dit(re, im, oracle.FORWARD)
+    assert rel_l2(d_re.cpu().numpy(), d_im.cpu().numpy(), re, im) <= F64_REL, planner.describe()
+
+
+def test_config3_2p26_roundtrip_and_sampled_bins(gpu):
+    """BASELINE config 3: N=2^26 f64 forward+inverse on 1 GPU; size-independent properties instead of a
+    full oracle run: (a) sampled output bins vs a direct O(N) long-double-free DFT in f64 with compensated
+    phase, (b) Parseval, (c) round trip <= 1e-10 * scale."""
+    import torch
+
+    n = 1 << 26
+    re = torch.empty(n, dtype=torch.float64, device="cuda")
+    im = torch.empty(n, dtype=torch.float64, device="cuda")
+    gpu.fill_uniform(re, im, n, seed=0xCAFE, first_id=0)
+    re0, im0 = re.clone(), im.clone()
+    planner = gpu.PlannerDit64(n)
+    gpu.fft_64_dit_with_planner(re, im, gpu.Direction.Forward, planner)
+    # (b) Parseval: sum |X|^2 = N sum |x|^2
+    e_in = float((re0 * re0 + im0 * im0).sum())
+    e_out = float((re * re + im * im).sum())
+    assert abs(e_out / (n * e_in) - 1.0) < 1e-12
+    # (a) direct DFT of sampled bins; the phase k*j/N is reduced exactly in integers before the sincos
+    j = torch.arange(n, dtype=torch.int64, device="cuda")
+    for k in (0, 1, 12345, n // 2, n - 1, 3 * (n // 8) + 7):
+        ph = (j * k) % n
+        ang = ph.to(torch.float64) * (-2.0 * np.pi / n)
+        c, s = torch.cos(ang), torch.sin(ang)
+        xr = float((re0 * c - im0 * s).sum())
+        xi = float((re0 * s + im0 * c).sum())
+        scale = np.sqrt(n * e_in)  # ||X||_2
+        assert abs(float(re[k]) - xr) < 1e-11 * scale and abs(float(im[k]) - xi) < 1e-11 * scale, k
+    del j, ph, ang, c, s
+    # (c) round trip
+    gpu.fft_64_dit_with_planner(re, im, gpu.Direction.Reverse, planner)
+    assert float((re - re0).abs().max()) < 1e-10 and float((im - im0).abs().max()) < 1e-10
+
+
+def test_batched_matches_single(gpu, oracle):
+    import torch
+
+    n, batch = 1 << 14, 37
+    re = torch.empty(n * batch, dtype=torch.float64, device="cuda")
+    im = torch.empty_like(re)
+    gpu.fill_uniform(re, im, n, seed=0xCAFE, first_id=1000)
+    planner = gpu.PlannerDit64(n)
+    gpu.fft_dit_batched(re, im, n, gpu.Direction.Forward, planner)
+    for b in (0, 1, 17, 36):
+        r, m = oracle.fill(n, np.float64, seed=0xCAFE, transform_id=1000 + b)
+        oracle.fft_64_dit(r, m, oracle.FORWARD)
+        assert rel_l2(re[b * n:(b + 1) * n].cpu().numpy(), im[b * n:(b + 1) * n].cpu().numpy(), r, m) <= F64_REL, b
+
+
+# ---------------------------------------------------------------- planner misuse (lib.rs:238-296)
+def test_panics_like_reference(gpu):
+    with pytest.raises(gpu.PhastPanic):
+        gpu.PlannerDit64(5)
+    with pytest.raises(gpu.PhastPanic):
+        gpu.PlannerDit32(5)
+    planner = gpu.PlannerDit64(16)
+    re, im = np.zeros(1 << 16), np.zeros(1 << 16)
+    with pytest.raises(gpu.PhastPanic):
+        gpu.fft_64_dit_with_planner_and_opts(re, im, gpu.Direction.Forward, planner, gpu.Options.guess_options(re.size))
+    with pytest.raises(gpu.PhastPanic):
+        gpu.fft_64_dit(np.zeros(8), np.zeros(16), gpu.Direction.Forward)
+    for n in range(5, 15):  # tune_mode_does_not_panic, lib.rs:428-437
+        gpu.PlannerDit64.with_mode(1 << n, gpu.PlannerMode.Tune)
+        gpu.PlannerDit32.with_mode(1 << n, gpu.PlannerMode.Tune)
+
+
+# ---------------------------------------------------------------- R2C / C2R (r2c.rs tests)
+@pytest.mark.parametrize("k", list(range(2, 21)))
+def test_r2c_f64_vs_oracle_and_c2c(gpu, oracle, k):
+    n = 1 << k
+    x, _ = oracle.fill(n, np.float64, transform_id=k)
+    ore, oim = np.full(n // 2 + 1, 7.0), np.full(n // 2 + 1, 7.0)
+    gpu.r2c_fft_f64(x, ore, oim)
+    ref_re, ref_im = np.zeros(n // 2 + 1), np.zeros(n // 2 + 1)
+    oracle.r2c_fft_f64(x, ref_re, ref_im)
+    assert rel_l2(ore, oim, ref_re, ref_im) <= 1e-12
+    out = np.zeros(n)
+    gpu.c2r_fft_f64(ore, oim, out)
+    assert np.max(np.abs(out - x)) < 1e-6  # r2c.rs:958-976
+
+
+@pytest.mark.parametrize("k", list(range(2, 21)))
+def test_r2c_f32_vs_oracle(gpu, oracle, k):
+    n = 1 << k
+    x, _ = oracle.fill(n, np.float32, transform_id=k)
+    ore, oim = np.zeros(n // 2 + 1, np.float32), np.zeros(n // 2 + 1, np.float32)
+    gpu.r2c_fft_f32(x, ore, oim)
+    ref_re, ref_im = np.zeros(n // 2 + 1, np.float32), np.zeros(n // 2 + 1, np.float32)
+    oracle.r2c_fft_f32(x, ref_re, ref_im)
+    assert rel_l2(ore, oim, ref_re, ref_im) <= F32_REL
+    out = np.zeros(n, np.float32)
+    gpu.c2r_fft_f32(ore, oim, out)
+    assert np.max(np.abs(out - x)) < 1e-5
+
+
+def test_config4_r2c_f32_2p24(gpu, oracle):
+    """BASELINE config 4: r2c_fft_f32 at N=2^24 on device tensors vs the oracle."""
+    import torch
+
+    n = 1 << 24
+    x = torch.empty(n, dtype=torch.float32, device="cuda")
+    gpu.fill_uniform(x, None, n, seed=0xCAFE, first_id=4)
+    ore = torch.empty(n // 2 + 1, dtype=torch.float32, device="cuda")
+    oim = torch.empty_like(ore)
+    planner = gpu.PlannerR2c32(n)
+    gpu.r2c_fft_f32_with_planner(x, ore, oim, planner)
+    hx, _ = oracle.fill(n, np.float32, seed=0xCAFE, transform_id=4)
+    assert np.array_equal(hx, x.cpu().numpy())  # the two generators are bit-identical
+    ref_re, ref_im = np.zeros(n // 2 + 1, np.float32), np.zeros(n // 2 + 1, np.float32)
+    oracle.r2c_fft_f32(hx, ref_re, ref_im)
+    assert rel_l2(ore.cpu().numpy(), oim.cpu().numpy(), ref_re, ref_im) <= F32_REL
+    back = torch.empty(n, dtype=torch.float32, device="cuda")
+    gpu.c2r_fft_f32_with_planner(ore, oim, back, planner)
+    assert float((back - x).abs().max()) < 1e-4
+
+
+def test_r2c_known_answers(gpu):
+    """r2c.rs:1235-1386: dc_only, nyquist_only, single_tone, all_zeros (pre-filled outputs), dc_and_nyquist_real."""
+    for dtype, fn, tol in ((np.float64, gpu.r2c_fft_f64, 1e-10), (np.float32, gpu.r2c_fft_f32, 1e-4)):
+        n, half = 16, 8
+        ore, oim = np.zeros(half + 1, dtype), np.zeros(half + 1, dtype)
+        fn(np.ones(n, dtype), ore, oim)
+        assert abs(ore[0] - n) < tol and np.all(np.abs(ore[1:]) < tol) and np.all(np.abs(oim) < tol)
+        x = np.array([1.0 if i % 2 == 0 else -1.0 for i in range(n)], dtype)
+        fn(x, ore, oim)
+        assert abs(ore[half] - n) < tol and np.all(np.abs(ore[:half]) < tol) and np.all(np.abs(oim) < tol)
+        n, half = 32, 16
+        ore, oim = np.zeros(half + 1, dtype), np.zeros(half + 1, dtype)
+        fn(np.cos(2 * np.pi * np.arange(n) / n).astype(dtype), ore, oim)
+        exp = np.zeros(half + 1)
+        exp[1] = n / 2
+        assert np.all(np.abs(ore - exp) < 10 * tol) and np.all(np.abs(oim) < 10 * tol)
+        n, half = 16, 8
+        ore, oim = np.ones(half + 1, dtype), np.ones(half + 1, dtype)
+        fn(np.zeros(n, dtype), ore, oim)
+        assert np.all(ore == 0) and np.all(oim == 0)
+        n, half = 64, 32
+        ore, oim = np.zeros(half + 1, dtype), np.zeros(half + 1, dtype)
+        fn(np.arange(1, n + 1).astype(dtype), ore, oim)
+        assert abs(oim[0]) < tol and abs(oim[half]) < tol
+
+
+def test_r2c_panic_messages(gpu):
+    """r2c.rs:1392-1540: exact panic strings."""
+    P = gpu
+    cases = [
+        (lambda: P.PlannerR2c64(6), "n must be a power of 2 >= 4"),
+        (lambda: P.PlannerR2c32(2), "n must be a power of 2 >= 4"),
+        (lambda: P.r2c_fft_f64(np.zeros(16), np.zeros(8), np.zeros(9)), "output_re must have length N/2 + 1"),
+        (lambda: P.r2c_fft_f64(np.zeros(16), np.zeros(9), np.zeros(8)), "output_im must have length N/2 + 1"),
+        (lambda: P.r2c_fft_f32_with_planner(np.zeros(8, np.float32), np.zeros(9, np.float32), np.zeros(9, np.float32),
+                                            P.PlannerR2c32(16)), "input length must match planner size"),
+        (lambda: P.c2r_fft_f64(np.zeros(8), np.zeros(9), np.zeros(16)), "input_re must have length N/2 + 1"),
+        (lambda: P.c2r_fft_f64(np.zeros(9), np.zeros(8), np.zeros(16)), "input_im must have length N/2 + 1"),
+        (lambda: P.c2r_fft_f64_with_planner(np.zeros(9), np.zeros(9), np.zeros(8), P.PlannerR2c64(16)),
+         "output length must match planner size"),
+        (lambda: P.c2r_fft_f64_with_planner_and_scratch(np.zeros(9), np.zeros(9), np.zeros(16), P.PlannerR2c64(16),
+                                                        np.zeros(7), np.zeros(8)), "scratch_re must have length N/2"),
+        (lambda: P.c2r_fft_f64_with_planner_and_scratch(np.zeros(9), np.zeros(9), np.zeros(16), P.PlannerR2c64(16),
+                                                        np.zeros(8), np.zeros(7)), "scratch_im must have length N/2"),
+    ]
+    for fn, msg in cases:
+        with pytest.raises(P.PhastPanic) as ei:
+            fn()
+        assert str(ei.value) == msg
+
+
+def test_determinism_across_entry_points(gpu):
+    """r2c.rs:978-1131: planner vs convenience entry points give bit-identical results."""
+    n = 1024
+    x = np.arange(1, n + 1, dtype=np.float64)
+    a_re, a_im = np.zeros(n // 2 + 1), np.zeros(n // 2 + 1)
+    b_re, b_im = np.zeros(n // 2 + 1), np.zeros(n // 2 + 1)
+    gpu.r2c_fft_f64(x, a_re, a_im)
+    gpu.r2c_fft_f64_with_planner(x, b_re, b_im, gpu.PlannerR2c64(n))
+    assert np.array_equal(a_re, b_re) and np.array_equal(a_im, b_im)
+    re1, im1 = x.copy(), x.copy()
+    re2, im2 = x.copy(), x.copy()
+    gpu.fft_64_dit(re1, im1, gpu.Direction.Forward)
+    gpu.fft_64_dit_with_planner(re2, im2, gpu.Direction.Forward, gpu.PlannerDit64(n))
+    assert np.array_equal(re1, re2) and np.array_equal(im1, im2)
+    d1, d2 = dev(x.copy()), dev(x.copy())
+    gpu.fft_64_dit(d1, d2, gpu.Direction.Forward)  # device path == host path
+    assert np.array_equal(d1.cpu().numpy(), re1) and np.array_equal(d2.cpu().numpy(), im1)
