@@ -179,12 +179,18 @@ int phast_digest_f64_dev(const double *d_reals, const double *d_imags, size_t n,
 int phast_digest_f32_dev(const float *d_reals, const float *d_imags, size_t n, size_t batch, size_t dist,
                          size_t probe, double *d_digest, void *stream);
 
-/* ---- tuning hook used by bench.py / tests to force a pass plan (0 = heuristic) ----
- * `log_rows` lists the per-pass tile FFT lengths (log2), `tile_log` the log2 points per tile. */
-int phast_planner_dit64_set_plan(phast_planner_dit64 *p, const unsigned *log_rows, size_t n_passes,
-                                 unsigned tile_log);
-int phast_planner_dit32_set_plan(phast_planner_dit32 *p, const unsigned *log_rows, size_t n_passes,
-                                 unsigned tile_log);
+/* ---- tuning hook used by tools/ and tests to force a pass plan (n_passes = 0 restores the heuristic) ----
+ * log_rows[i] = log2 of pass i's tile FFT length, tile_logs[i] = log2 of the points per tile of pass i
+ * (12, 13 or 14: 256, 512 or 1024 threads per workgroup).  Returns PHAST_ERR_INVALID_ARG when the
+ * factorisation is not realisable with the compiled tile shapes. */
+int phast_planner_dit64_set_plan(phast_planner_dit64 *p, const unsigned *log_rows, const unsigned *tile_logs,
+                                 size_t n_passes);
+int phast_planner_dit32_set_plan(phast_planner_dit32 *p, const unsigned *log_rows, const unsigned *tile_logs,
+                                 size_t n_passes);
+
+/* tuning hook: force the number of resident workgroups per CU the tile passes are launched with (0 = planner's own
+ * residency estimate).  Process-wide; for sweeps in tools/ only. */
+void phast_debug_set_wg_per_cu(int wg_per_cu);
 
 /* ---- measurement hook (bench.py "roofline"): runs `reps` batched forward transforms in place on the given
  * buffers with hipEvents recorded on `stream` around every pass kernel; pass_ms[i] = average duration of pass i

@@ -31,7 +31,7 @@ phast_c2r_fft_f64_with_planner_and_scratch phast_c2r_fft_f32_with_planner_and_sc
 phast_c2r_fft_f64_dev phast_c2r_fft_f32_dev
 phast_fill_f64_dev phast_fill_f32_dev phast_digest_f64_dev phast_digest_f32_dev
 phast_planner_dit64_set_plan phast_planner_dit32_set_plan
-phast_planner_dit64_time_passes phast_planner_dit32_time_passes
+phast_planner_dit64_time_passes phast_planner_dit32_time_passes phast_debug_set_wg_per_cu
 """.split()
 
 
@@ -52,6 +52,13 @@ def lib() -> C.CDLL:
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -m phastft_amd.build` (hipcc, gfx950). "
             "phastft_amd has no CPU fallback.")
+    # One HIP runtime per process: torch bundles its own libamdhip64.so.7 (same SONAME as /opt/rocm's).  Whichever
+    # copy is loaded first serves both, and mixing the two leaves the second user without a device.  The package
+    # works on torch device tensors and torch streams, so torch's runtime must be the one: import it first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # a torch-less process (e.g. a C or Rust host) simply uses /opt/rocm's runtime
+        pass
     l = C.CDLL(LIB_PATH)
     l.phast_strerror.restype = C.c_char_p
     l.phast_strerror.argtypes = [C.c_int]
@@ -63,6 +70,7 @@ def lib() -> C.CDLL:
         if fn.restype is C.c_int and name not in ("phast_options_default",):
             pass
     l.phast_options_default.restype = None
+    l.phast_debug_set_wg_per_cu.restype = None
     for sfx in ("64", "32"):
         getattr(l, f"phast_planner_dit{sfx}_free").restype = None
         getattr(l, f"phast_planner_r2c{sfx}_free").restype = None

@@ -37,6 +37,7 @@ static int hip_fail(hipError_t e, const char *what) {
     } while (0)
 
 static int g_cus = 0;
+static int g_wg_per_cu_override = 0;  // tuning hook (phast_debug_set_wg_per_cu)
 static int ensure_device() {
     static std::once_flag once;
     static int status = PHAST_OK;
@@ -128,7 +129,9 @@ struct PassTimer {
 template <typename T> struct Planner {
     size_t n = 0;
     unsigned log_n = 0;
-    std::vector<PassDesc> passes;  // empty => small path
+    std::vector<PassDesc> passes;      // throughput plan; empty => small path
+    std::vector<PassDesc> passes_lat;  // latency plan (one small transform); may equal `passes`
+    static constexpr size_t kLatencyWork = (size_t)1 << 22;  // batch*n below this uses the latency plan
     void *d_small_tw = nullptr;
     mutable T *d_scratch = nullptr;  // [cap][2][n]: re plane then im plane per transform
     mutable size_t scratch_cap = 0;
@@ -137,12 +140,16 @@ template <typename T> struct Planner {
     mutable size_t table_bytes = 0;
 
     ~Planner() { release(); }
-    void release_passes() {
-        for (auto &p : passes) {
+    static void free_passes(std::vector<PassDesc> &v) {
+        for (auto &p : v) {
             if (p.d_tw3) hipFree(p.d_tw3);
             if (p.d_twr) hipFree(p.d_twr);
         }
-        passes.clear();
+        v.clear();
+    }
+    void release_passes() {
+        free_passes(passes);
+        free_passes(passes_lat);
     }
     void release() {
         release_passes();
@@ -153,9 +160,10 @@ template <typename T> struct Planner {
         scratch_cap = 0;
     }
 
-    int set_plan(const std::vector<unsigned> &lrs, unsigned tile_log) {
+    // which: 0 = both plans, 1 = throughput plan only, 2 = latency plan only
+    int set_plan(const std::vector<unsigned> &lrs, const std::vector<unsigned> &tls, int which = 0) {
         std::vector<PassGeom> geo;
-        if (!make_passes(log_n, lrs, tile_log, geo)) return PHAST_ERR_INVALID_ARG;
+        if (!make_passes(log_n, lrs, tls, geo)) return PHAST_ERR_INVALID_ARG;
         std::vector<PassDesc> ps(geo.size());
         for (size_t i = 0; i < geo.size(); ++i) static_cast<PassGeom &>(ps[i]) = geo[i];
         size_t tb = 0;
@@ -174,6 +182,7 @@ template <typename T> struct Planner {
                                    : Types<T>::launch_bc(ps[i].lr, ps[i].lc, 0, nullptr, ta, true, &ps[i].blocks_per_cu, &ps[i].lds);
                 if (e != hipSuccess) rc = hip_fail(e, "occupancy query");
                 if (ps[i].blocks_per_cu < 1) ps[i].blocks_per_cu = 1;
+                if (rc == PHAST_OK && ps[i].lds > 160 * 1024) rc = PHAST_ERR_INVALID_ARG;  // tile does not fit one CU's LDS
             }
             if (rc != PHAST_OK) {
                 for (auto &p : ps) {
@@ -184,8 +193,14 @@ template <typename T> struct Planner {
             }
         }
         std::lock_guard<std::mutex> lk(mu);
-        release_passes();
-        passes = std::move(ps);
+        if (which == 2) {
+            free_passes(passes_lat);
+            passes_lat = std::move(ps);
+        } else {
+            free_passes(passes);
+            passes = std::move(ps);
+            if (which == 0) free_passes(passes_lat);  // one plan for every batch size
+        }
         table_bytes = tb;
         return PHAST_OK;
     }
@@ -200,10 +215,13 @@ template <typename T> struct Planner {
             table_bytes = h.size() * sizeof(cx_t<T>);
             return upload<T>(h, &d_small_tw);
         }
-        std::vector<unsigned> lrs;
-        unsigned tile_log;
-        heuristic_plan<T>(log_n, lrs, tile_log);
-        return set_plan(lrs, tile_log);
+        std::vector<unsigned> lrs, tls, lrs_l, tls_l;
+        heuristic_plan<T>(log_n, false, lrs, tls);
+        rc = set_plan(lrs, tls, 1);
+        if (rc) return rc;
+        heuristic_plan<T>(log_n, true, lrs_l, tls_l);
+        if (lrs_l != lrs || tls_l != tls) rc = set_plan(lrs_l, tls_l, 2);
+        return rc;
     }
 
     // scratch for `want` transforms in flight (capped by the target footprint, at least 1)
@@ -242,12 +260,17 @@ template <typename T> struct Planner {
             std::snprintf(buf, sizeof buf, "n=2^%u small-lds (1 kernel)", log_n);
             return buf;
         }
-        std::string s = "n=2^" + std::to_string(log_n) + " passes=" + std::to_string(passes.size());
-        for (auto &p : passes) {
-            std::snprintf(buf, sizeof buf, " [%ux%u %s lds=%zuB wg/cu=%d tw_bits=%u]", 1u << p.lr, 1u << p.lc,
-                          p.transpose ? "A" : "BC", p.lds, p.blocks_per_cu, p.tw_bits);
-            s += buf;
-        }
+        std::string s = "n=2^" + std::to_string(log_n);
+        auto add = [&](const char *tag, const std::vector<PassDesc> &v) {
+            s += std::string(" ") + tag + "=" + std::to_string(v.size()) + "p";
+            for (auto &p : v) {
+                std::snprintf(buf, sizeof buf, "[%ux%u%s lds=%zu wg/cu=%d]", 1u << p.lr, 1u << p.lc,
+                              p.transpose ? "A" : "", p.lds, p.blocks_per_cu);
+                s += buf;
+            }
+        };
+        add("throughput", passes);
+        if (!passes_lat.empty()) add("latency", passes_lat);
         return s;
     }
 
@@ -288,6 +311,7 @@ template <typename T> struct Planner {
         if (rc) return rc;
         T *s_re = d_scratch;               // plane layout: all re planes, then all im planes
         T *s_im = d_scratch + cap * n;
+        const std::vector<PassDesc> &passes = (!passes_lat.empty() && batch * n < kLatencyWork) ? passes_lat : this->passes;
         const size_t np = passes.size();
         for (size_t b0 = 0; b0 < batch; b0 += cap) {
             const size_t nb = batch - b0 < cap ? batch - b0 : cap;
@@ -323,7 +347,7 @@ template <typename T> struct Planner {
                 ta.twr = p.d_twr;
                 if (((unsigned long long)nb << (log_n - p.lr - p.lc)) > 0xffffffffull) return PHAST_ERR_INVALID_ARG;
                 geom_to_args(p, log_n, nb, ta);
-                unsigned grid = (unsigned)p.blocks_per_cu * (unsigned)g_cus;
+                unsigned grid = (unsigned)(g_wg_per_cu_override > 0 ? g_wg_per_cu_override : p.blocks_per_cu) * (unsigned)g_cus;
                 if (grid > ta.tiles_total) grid = ta.tiles_total;
                 if (grid >= 8) grid &= ~7u;  // keep tile%8 == workgroup%8 (XCD affinity of the tile order)
                 if (timer) PHAST_HIP(timer->mark(stream));
@@ -488,7 +512,8 @@ template <typename T>
 static int time_passes(const Planner<T> *pl, T *d_re, T *d_im, size_t batch, size_t dist, int reps, float *pass_ms,
                        int *n_passes, hipStream_t s) {
     if (!pl || !d_re || !d_im || !pass_ms || !n_passes || reps < 1) return PHAST_ERR_INVALID_ARG;
-    const int np = pl->passes.empty() ? 1 : (int)pl->passes.size();
+    const bool lat = !pl->passes_lat.empty() && batch * pl->n < Planner<T>::kLatencyWork;
+    const int np = pl->passes.empty() ? 1 : (int)(lat ? pl->passes_lat.size() : pl->passes.size());
     double acc[3] = {0, 0, 0};
     for (int r = 0; r < reps; ++r) {
         PassTimer tm;
@@ -620,17 +645,23 @@ template <typename T> static int describe_to(const Planner<T> *p, char *buf, siz
 }
 
 template <typename T>
-static int set_plan_c(Planner<T> *p, const unsigned *log_rows, size_t n_passes, unsigned tile_log) {
+static int set_plan_c(Planner<T> *p, const unsigned *log_rows, const unsigned *tile_logs, size_t n_passes) {
     if (!p) return PHAST_ERR_INVALID_ARG;
     if (p->log_n <= kSmallMaxLog) return n_passes == 0 ? PHAST_OK : PHAST_ERR_INVALID_ARG;
-    std::vector<unsigned> lrs;
+    std::vector<unsigned> lrs, tls;
     if (n_passes == 0) {
-        heuristic_plan<T>(p->log_n, lrs, tile_log);
+        heuristic_plan<T>(p->log_n, false, lrs, tls);
+        int rc = p->set_plan(lrs, tls, 1);
+        if (rc) return rc;
+        std::vector<unsigned> lrs_l, tls_l;
+        heuristic_plan<T>(p->log_n, true, lrs_l, tls_l);
+        return (lrs_l != lrs || tls_l != tls) ? p->set_plan(lrs_l, tls_l, 2) : PHAST_OK;
     } else {
-        if (!log_rows) return PHAST_ERR_INVALID_ARG;
+        if (!log_rows || !tile_logs) return PHAST_ERR_INVALID_ARG;
         lrs.assign(log_rows, log_rows + n_passes);
+        tls.assign(tile_logs, tile_logs + n_passes);
     }
-    return p->set_plan(lrs, tile_log);
+    return p->set_plan(lrs, tls);
 }
 
 }  // namespace phast
@@ -671,6 +702,8 @@ const char *phast_strerror(int code) {
 }
 
 const char *phast_last_hip_error(void) { return g_hip_err; }
+
+void phast_debug_set_wg_per_cu(int wg_per_cu) { g_wg_per_cu_override = wg_per_cu; }
 
 int phast_device_info(char *name, size_t name_len, int *compute_units, size_t *lds_per_block,
                       size_t *global_mem_bytes) {
@@ -722,8 +755,9 @@ int phast_options_guess(size_t input_size, phast_options *out) {
         size_t cap;                                                                                                \
         return p->ensure_scratch(max_batch, &cap);                                                                 \
     }                                                                                                              \
-    int phast_planner_dit##SFX##_set_plan(phast_planner_dit##SFX *p, const unsigned *lr, size_t np, unsigned tl) { \
-        return set_plan_c<T>(p, lr, np, tl);                                                                       \
+    int phast_planner_dit##SFX##_set_plan(phast_planner_dit##SFX *p, const unsigned *lr, const unsigned *tl,       \
+                                          size_t np) {                                                             \
+        return set_plan_c<T>(p, lr, tl, np);                                                                       \
     }                                                                                                              \
     int phast_planner_dit##SFX##_time_passes(const phast_planner_dit##SFX *p, T *d_re, T *d_im, size_t batch,       \
                                              size_t dist, int reps, float *pass_ms, int *n_passes, void *stream) { \

@@ -31,10 +31,10 @@ static int emu_exec(const void *in_re, const void *in_im, unsigned in_mode, void
                     unsigned out_mode, unsigned log_n, size_t batch, size_t in_dist, size_t out_dist, double scale,
                     const unsigned *lrs_in, size_t np_in, unsigned tile_log) {
     const size_t n = (size_t)1 << log_n;
-    std::vector<unsigned> lrs(lrs_in, lrs_in + np_in);
-    if (lrs.empty()) heuristic_plan<T>(log_n, lrs, tile_log);
+    std::vector<unsigned> lrs(lrs_in, lrs_in + np_in), tls(1, tile_log);
+    if (lrs.empty()) heuristic_plan<T>(log_n, tile_log == 0, lrs, tls);  // tile_log 0 = latency plan
     std::vector<PassGeom> ps;
-    if (!make_passes(log_n, lrs, tile_log, ps)) return 1;
+    if (!make_passes(log_n, lrs, tls, ps)) return 1;
     std::vector<T> s_re(n * batch), s_im(n * batch);
     for (size_t i = 0; i < ps.size(); ++i) {
         const PassGeom &p = ps[i];
@@ -158,10 +158,11 @@ int phast_emu_fft_f32_modes(const float *in_re, const float *in_im, unsigned in_
     return phast::emu_exec<float>(in_re, in_im, in_mode, out_re, out_im, out_mode, log_n, 1, n, n, scale, lrs, np, tile_log);
 }
 // the default plan of the library for (type, log_n): fills lrs[3], returns the number of passes
-int phast_emu_default_plan(int is_f64, unsigned log_n, unsigned *lrs, unsigned *tile_log) {
-    std::vector<unsigned> v;
-    if (is_f64) phast::heuristic_plan<double>(log_n, v, *tile_log);
-    else phast::heuristic_plan<float>(log_n, v, *tile_log);
+int phast_emu_default_plan(int is_f64, int latency, unsigned log_n, unsigned *lrs, unsigned *tile_log) {
+    std::vector<unsigned> v, tl;
+    if (is_f64) phast::heuristic_plan<double>(log_n, latency != 0, v, tl);
+    else phast::heuristic_plan<float>(log_n, latency != 0, v, tl);
+    *tile_log = tl[0];
     for (size_t i = 0; i < v.size(); ++i) lrs[i] = v[i];
     return (int)v.size();
 }

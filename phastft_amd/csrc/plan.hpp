@@ -93,8 +93,9 @@ template <typename T> inline std::vector<cx_t<T>> host_small_tw(size_t n) {
 }
 
 // ---- tile shapes that exist as kernels: log2(rows), log2(cols) ----
-// 4096-point tiles (256 threads) and 8192-point tiles (512 threads)
-#define PHAST_TILE_SHAPES(X) X(6, 6) X(7, 5) X(8, 4) X(9, 3) X(8, 5) X(9, 4) X(10, 3)
+// 4096-point tiles (256 threads), 8192-point tiles (512 threads), 16384-point tiles (1024 threads)
+#define PHAST_TILE_SHAPES(X) \
+    X(6, 6) X(7, 5) X(8, 4) X(9, 3) X(10, 2) X(7, 6) X(8, 5) X(9, 4) X(10, 3) X(8, 6) X(9, 5) X(10, 4)
 
 inline bool shape_exists(unsigned lr, unsigned lc) {
 #define PHAST_CHK(LR_, LC_) \
@@ -113,41 +114,57 @@ struct PassGeom {
     unsigned log_mod() const { return lr + log_s_in; }  // the inter-pass twiddle is W_{2^log_mod}^{row*lo}
 };
 
-// Default factorisation of L = log2 N (L > kSmallMaxLog); tuned on MI355X.
-template <typename T> inline void heuristic_plan(unsigned L, std::vector<unsigned> &lrs, unsigned &tile_log) {
+// Default factorisations of L = log2 N (L > kSmallMaxLog), from the MI355X sweeps in profiles/ (DESIGN.md
+// section 5).  What the sweeps say: a pass runs at the copy rate of its access pattern, and that rate is set
+// by the contiguous segment a tile row covers (f64: 64 B ~3.0-3.7 TB/s, 128 B ~4.4, >= 256 B ~5.0-5.8), so
+//   * `throughput` (many transforms in flight): as few passes as possible while rows stay >= 128 B wide,
+//     8192-point tiles; N = 2^19, 2^20 take two 1024 x 8 passes (one fewer pass beats wider rows there);
+//   * `latency` (one small transform: launch- and latency-bound, not bandwidth-bound): fewest passes with
+//     4096-point tiles so that every CU gets a workgroup.
+template <typename T>
+inline void heuristic_plan(unsigned L, bool latency, std::vector<unsigned> &lrs, std::vector<unsigned> &tls) {
     lrs.clear();
-    tile_log = 12;
+    tls.assign(1, 12);
     if (L <= kSmallMaxLog) return;
-    const unsigned max12 = sizeof(T) == 8 ? 9 : 8;  // keep COLS*sizeof(T) >= 64-byte segments
-    unsigned np;
-    if (L <= 2 * max12) {
-        np = 2;
-    } else if (L <= 2 * (max12 + 1)) {
-        np = 2;
-        tile_log = 13;
-    } else if (L <= 3 * max12) {
-        np = 3;
-    } else {
-        np = 3;
-        tile_log = 13;
+    auto split = [&](unsigned np) {
+        lrs.clear();
+        for (unsigned i = 0; i < np; ++i) lrs.push_back(L / np + (i < L % np ? 1 : 0));  // balanced, larger first
+    };
+    if (latency) {
+        split(L <= 20 ? 2 : 3);
+        tls.assign(1, lrs[0] <= 10 ? 12 : 13);
+        return;
     }
-    for (unsigned i = 0; i < np; ++i) lrs.push_back(L / np + (i < L % np ? 1 : 0));  // balanced, larger first
+    const unsigned wide = sizeof(T) == 8 ? 9 : 8;  // largest LR whose 8192-point tile keeps >= 128-byte rows
+    if (L <= 14) {
+        split(2);
+        tls.assign(1, 12);
+    } else if (L <= 2 * wide || L <= 20) {
+        split(2);
+        tls.assign(1, 13);
+    } else {
+        split(3);
+        tls.assign(1, lrs[0] <= 7 ? 12 : 13);
+    }
 }
 
 // N = 2^L as 2 passes (a, b) or 3 passes (a, b, c):
 //   x[p][r][u] --A: FFT over p, runs out--> S[u][r][q] --B: FFT over r, in place--> S[u][kb][q]
 //              --C: FFT over u--> x[kc][kb][q]            (2 passes: S[r][q] --B--> x[kb][q])
-inline bool make_passes(unsigned L, const std::vector<unsigned> &lrs, unsigned tile_log, std::vector<PassGeom> &ps) {
+// `tile_logs` gives log2(points per tile) of every pass (one entry = the same for all passes).
+inline bool make_passes(unsigned L, const std::vector<unsigned> &lrs, const std::vector<unsigned> &tile_logs,
+                        std::vector<PassGeom> &ps) {
     unsigned sum = 0;
     for (unsigned lr : lrs) sum += lr;
     if (lrs.size() < 2 || lrs.size() > 3 || sum != L) return false;
-    for (unsigned lr : lrs)
-        if (lr > tile_log || !shape_exists(lr, tile_log - lr)) return false;
+    if (tile_logs.size() != 1 && tile_logs.size() != lrs.size()) return false;
     ps.assign(lrs.size(), PassGeom());
     const unsigned a = lrs[0], b = lrs[1], c = lrs.size() == 3 ? lrs[2] : 0;
     for (size_t i = 0; i < lrs.size(); ++i) {
+        const unsigned tl = tile_logs.size() == 1 ? tile_logs[0] : tile_logs[i];
+        if (lrs[i] > tl || !shape_exists(lrs[i], tl - lrs[i])) return false;
         ps[i].lr = lrs[i];
-        ps[i].lc = tile_log - lrs[i];
+        ps[i].lc = tl - lrs[i];
     }
     ps[0].transpose = true;  // FFT over the top `a` index bits; every column leaves as one contiguous run
     ps[0].log_s_in = L - a;
@@ -178,9 +195,11 @@ inline bool make_passes(unsigned L, const std::vector<unsigned> &lrs, unsigned t
         ps[2].out_row_stride = 1ull << (a + b);
         ps[2].tw_bits = tw3_bits_for(L);
     }
-    for (auto &p : ps)
-        if (p.lc > p.log_s_in) return false;  // a tile needs COLS adjacent columns sharing the row stride
-    return true;
+    for (auto &p : ps) {
+        if (p.lc > p.log_s_in) return false;    // a tile needs COLS adjacent columns sharing the row stride
+        if (p.lc > p.out_lo_bits) return false;  // ... and the output column map must be linear inside a tile
+    }
+    return L <= 30;  // per-lane offsets are 32-bit element indices
 }
 
 inline void geom_to_args(const PassGeom &p, unsigned log_n, size_t n_xforms, TileArgs &ta) {

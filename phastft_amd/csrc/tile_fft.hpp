@@ -11,7 +11,8 @@
 // Each thread holds 16 complex points in registers.  Inside the tile the ROWS-point FFT is a
 // decimation-in-frequency Cooley-Tukey split 16 x R2 (x R3); the radix-16/8/4/2 butterflies run in
 // registers with literal twiddles, and data moves between the radix steps through LDS:
-//     exchange 1 layout [n'][k1]  (row = n'*16 + k1, low bits XOR-swizzled by n' against bank conflicts)
+//     exchange 1 layout [n'][k1]  (row = n'*(16 + PADR) + k1; one pad row per n' when a 32-lane LDS access
+//                                  group spans G > 1 rows, so the G rows of a group fall on distinct banks)
 //     exchange 2 layout [n3][k2][k1]
 // Lanes are (column fastest, butterfly index); both exchanges are bank-conflict free for reads
 // (32-lane groups see G = 32/COLS consecutive rows) and writes.
@@ -93,9 +94,12 @@ template <typename T, int LR, int LC, bool PRE_TW, bool TRANSPOSE> struct TileBo
     static constexpr int R3 = THREE ? M / 16 : 1;
     static constexpr bool PLANE_SEQ = sizeof(T) == 8;  // exchange re and im one after the other (half the LDS)
     static constexpr int CS = ROWS + G;                // padded column stride of the transposing exchange
-    static constexpr int EXCH = TRANSPOSE ? COLS * CS : ROWS * COLS;
+    static constexpr int E1S = 16 + (G > 1 ? 1 : 0);   // rows per n' in exchange 1 (16 used + padding)
+    static constexpr int EXCH_E1 = M * E1S * COLS;
+    static constexpr int EXCH_E3 = TRANSPOSE ? COLS * CS : 0;
+    static constexpr int EXCH = EXCH_E1 > EXCH_E3 ? EXCH_E1 : EXCH_E3;
     static_assert(LR >= 6 && LR <= 10, "tile FFT length 64..1024");
-    static_assert(G <= 16, "swizzle must stay inside the k1 nibble");
+    static_assert(NT <= 1024, "at most 1024 threads per workgroup");
 
     static size_t lds_bytes(unsigned tw_bits) {
         size_t exch = (size_t)EXCH * sizeof(T) * (PLANE_SEQ ? 1 : 2);
@@ -130,33 +134,37 @@ template <typename T, int LR, int LC, bool PRE_TW, bool TRANSPOSE> struct TileBo
     }
 
     // ---------------- load rows n = n1*M + tau, apply the inter-pass twiddle ----------------
+    // Addresses are (wave-uniform 64-bit base) + (32-bit per-lane element offset): the tile's columns share
+    // the high part of in_col (tiles are COLS-aligned and COLS <= 2^log_s_in), the row n1*M is uniform, and
+    // only tau*2^log_s_in + col differs between lanes -- one VGPR for all 16 loads (saddr addressing).
     PHAST_HD static void load(const TileArgs &a, const Shared &sh, int tid, Regs &r) {
         const int col = col_of(tid), tau = tau_of(tid);
-        const unsigned g = r.g0 + col;
-        const unsigned lo = g & ((1u << a.log_s_in) - 1u);
-        const size_t in_col = ((size_t)(g >> a.log_s_in) << (a.log_s_in + LR)) | lo;
+        const unsigned lo0 = r.g0 & ((1u << a.log_s_in) - 1u);
+        const size_t ubase = (size_t)r.xform * a.in_dist + (((size_t)(r.g0 >> a.log_s_in) << (a.log_s_in + LR)) | lo0);
+        const unsigned voff = ((unsigned)tau << a.log_s_in) + (unsigned)col;
         if (!a.in_interleaved) {
-            const T *pr = reinterpret_cast<const T *>(a.in_re) + (size_t)r.xform * a.in_dist + in_col;
-            const T *pi = reinterpret_cast<const T *>(a.in_im) + (size_t)r.xform * a.in_dist + in_col;
+            const T *pr = reinterpret_cast<const T *>(a.in_re) + ubase;
+            const T *pi = reinterpret_cast<const T *>(a.in_im) + ubase;
             static_for<0, 16>([&](auto n1) {
-                const size_t off = (size_t)(decltype(n1)::value * M + tau) << a.log_s_in;
-                r.re[n1] = pr[off];
-                r.im[n1] = pi[off];
+                const size_t urow = (size_t)(decltype(n1)::value * M) << a.log_s_in;
+                r.re[n1] = (pr + urow)[voff];
+                r.im[n1] = (pi + urow)[voff];
             });
         } else {
-            const cx *pz = reinterpret_cast<const cx *>(a.in_re) + (size_t)r.xform * a.in_dist + in_col;
+            const cx *pz = reinterpret_cast<const cx *>(a.in_re) + ubase;
             static_for<0, 16>([&](auto n1) {
-                const size_t off = (size_t)(decltype(n1)::value * M + tau) << a.log_s_in;
-                cx v = pz[off];
+                const size_t urow = (size_t)(decltype(n1)::value * M) << a.log_s_in;
+                cx v = (pz + urow)[voff];
                 r.re[n1] = v.x;
                 r.im[n1] = v.y;
             });
         }
         if constexpr (PRE_TW) {
+            const unsigned lo = lo0 + (unsigned)col;
+            const unsigned e0 = (unsigned)tau * lo, de = (unsigned)M * lo;  // exponent of row n1*M + tau: e0 + n1*de
             static_for<0, 16>([&](auto n1) {
-                const unsigned row = decltype(n1)::value * M + tau;
                 T wr, wi;
-                tw3_lookup<T>(sh.tw3, a.tw_bits, row * lo, wr, wi);
+                tw3_lookup<T>(sh.tw3, a.tw_bits, e0 + decltype(n1)::value * de, wr, wi);
                 cmul(r.re[n1], r.im[n1], wr, wi);
             });
         }
@@ -205,45 +213,44 @@ template <typename T, int LR, int LC, bool PRE_TW, bool TRANSPOSE> struct TileBo
     }
 
     // frequency index (row of the tile FFT output) held by register P after the last step
-    template <int P> PHAST_HD static unsigned krow(int tid) {
-        const int tau = tau_of(tid);
+    //   = krow_lane(tid) + krow_const<P>()
+    PHAST_HD static unsigned krow_lane(int tid) { return (unsigned)tau_of(tid); }  // (tau&15) + 16*(tau>>4) = tau
+    template <int P> PHAST_HD static constexpr unsigned krow_const() {
         if constexpr (!THREE) {
             constexpr int I = P / R2, PP = P % R2;
-            return (unsigned)(tau + R2 * I) + 16u * bitrev_c(PP, ilog2_c(R2));
+            return (unsigned)(R2 * I) + 16u * bitrev_c(PP, ilog2_c(R2));
         } else {
             constexpr int I = P / R3, PP = P % R3;
-            return (unsigned)(tau & 15) + 16u * (unsigned)((tau >> 4) + R3 * I) + 256u * bitrev_c(PP, ilog2_c(R3));
+            return 16u * (unsigned)(R3 * I) + 256u * bitrev_c(PP, ilog2_c(R3));
         }
     }
+    template <int P> PHAST_HD static unsigned krow(int tid) { return krow_lane(tid) + krow_const<P>(); }
 
     // ---------------- LDS exchange addresses; E = 1, 2 (three-level only), 3 (transpose only) ----------------
     template <int E, int P> PHAST_HD static int waddr(int tid) {
         const int col = col_of(tid), tau = tau_of(tid);
-        if constexpr (E == 1) {  // logical row n'*16 + k1 with n' = tau, k1 = bitrev4(P)
+        if constexpr (E == 1) {  // row n'*E1S + k1 with n' = tau, k1 = bitrev4(P)
             constexpr int K1 = bitrev_c(P, 4);
-            return ((tau * 16 + (K1 ^ (tau & (G - 1)))) << LC) + col;
+            return ((tau * E1S) << LC) + col + (K1 << LC);
         } else if constexpr (E == 2) {  // [n3][k2][k1]
             constexpr int K2 = bitrev_c(P, 4);
-            return ((((tau >> 4) * 16 + K2) * 16 + (tau & 15)) << LC) + col;
+            return ((((tau >> 4) * 256) + (tau & 15)) << LC) + col + ((K2 * 16) << LC);
         } else {  // [col][k]
-            return col * CS + (int)krow<P>(tid);
+            return col * CS + (int)krow_lane(tid) + (int)krow_const<P>();
         }
     }
     template <int E, int P> PHAST_HD static int raddr(int tid) {
         const int col = col_of(tid), tau = tau_of(tid);
         if constexpr (E == 1) {
             if constexpr (!THREE) {
-                constexpr int I = P / R2, N2 = P % R2;  // n' = n2
-                const int k1 = tau + R2 * I;
-                return ((N2 * 16 + (k1 ^ (N2 & (G - 1)))) << LC) + col;
-            } else {
-                const int np = P * R3 + (tau >> 4);  // n' = n2*R3 + n3
-                return ((np * 16 + ((tau & 15) ^ (np & (G - 1)))) << LC) + col;
+                constexpr int I = P / R2, N2 = P % R2;  // n' = n2, k1 = tau + R2*I
+                return (tau << LC) + col + ((N2 * E1S + R2 * I) << LC);
+            } else {  // n' = n2*R3 + n3 with n2 = P, n3 = tau >> 4; k1 = tau & 15
+                return ((((tau >> 4) * E1S) + (tau & 15)) << LC) + col + ((P * R3 * E1S) << LC);
             }
         } else if constexpr (E == 2) {
-            constexpr int I = P / R3, N3 = P % R3;
-            const int k2 = (tau >> 4) + R3 * I;
-            return (((N3 * 16 + k2) * 16 + (tau & 15)) << LC) + col;
+            constexpr int I = P / R3, N3 = P % R3;  // k2 = (tau >> 4) + R3*I
+            return ((((tau >> 4) * 16) + (tau & 15)) << LC) + col + (((N3 * 16 + R3 * I) * 16) << LC);
         } else {
             const int f = P * NT + tid;
             return (f >> LR) * CS + (f & (ROWS - 1));
@@ -266,35 +273,46 @@ template <typename T, int LR, int LC, bool PRE_TW, bool TRANSPOSE> struct TileBo
     }
 
     // ---------------- store ----------------
-    PHAST_HD static size_t out_col(const TileArgs &a, unsigned g, unsigned xform) {
-        return (size_t)(g & ((1u << a.out_lo_bits) - 1u)) * a.out_s1 + (size_t)(g >> a.out_lo_bits) * a.out_s2 +
-               (size_t)xform * a.out_dist;
+    // out_col(g) for the tile's first column; tiles are COLS-aligned and COLS <= 2^out_lo_bits, so column
+    // g0 + c is out_col(g0) + c*out_s1 (checked by make_passes)
+    PHAST_HD static size_t out_base(const TileArgs &a, const Regs &r) {
+        return (size_t)(r.g0 & ((1u << a.out_lo_bits) - 1u)) * a.out_s1 + (size_t)(r.g0 >> a.out_lo_bits) * a.out_s2 +
+               (size_t)r.xform * a.out_dist;
     }
-    PHAST_HD static void put(const TileArgs &a, size_t off, T re, T im) {
+    PHAST_HD static void put(const TileArgs &a, size_t ubase, unsigned voff, T re, T im) {
         const T scale = (T)a.scale;
         if (!a.out_interleaved) {
-            reinterpret_cast<T *>(a.out_re)[off] = re * scale;
-            reinterpret_cast<T *>(a.out_im)[off] = im * scale;
+            (reinterpret_cast<T *>(a.out_re) + ubase)[voff] = re * scale;
+            (reinterpret_cast<T *>(a.out_im) + ubase)[voff] = im * scale;
         } else {
             cx v;
             v.x = (a.out_interleaved == 2 ? im : re) * scale;
             v.y = (a.out_interleaved == 2 ? re : im) * scale;
-            reinterpret_cast<cx *>(a.out_re)[off] = v;
+            (reinterpret_cast<cx *>(a.out_re) + ubase)[voff] = v;
         }
     }
     PHAST_HD static void store(const TileArgs &a, int tid, const Regs &r) {
-        if constexpr (!TRANSPOSE) {  // register P holds row krow<P> of column g0 + col
-            const size_t base = out_col(a, r.g0 + col_of(tid), r.xform);
+        const size_t base = out_base(a, r);
+        if constexpr (!TRANSPOSE) {  // register P holds row krow_lane + krow_const<P> of column g0 + col
+            const unsigned voff = (unsigned)col_of(tid) * (unsigned)a.out_s1 + krow_lane(tid) * (unsigned)a.out_row_stride;
             static_for<0, 16>([&](auto P) {
-                put(a, base + (size_t)krow<decltype(P)::value>(tid) * a.out_row_stride, r.re[P], r.im[P]);
+                put(a, base + (size_t)krow_const<decltype(P)::value>() * a.out_row_stride, voff, r.re[P], r.im[P]);
             });
         } else {  // after exchange 3: register P holds flat element f = P*NT + tid of the [col][k] tile
-            static_for<0, 16>([&](auto P) {
-                const int f = decltype(P)::value * NT + tid;
-                const size_t off = out_col(a, r.g0 + (unsigned)(f >> LR), r.xform) +
-                                   (size_t)(f & (ROWS - 1)) * a.out_row_stride;
-                put(a, off, r.re[P], r.im[P]);
-            });
+            if constexpr (NT >= ROWS) {  // f -> column (P*NT >> LR) + (tid >> LR), row tid & (ROWS-1)
+                const unsigned voff = (unsigned)(tid >> LR) * (unsigned)a.out_s1 +
+                                      (unsigned)(tid & (ROWS - 1)) * (unsigned)a.out_row_stride;
+                static_for<0, 16>([&](auto P) {
+                    constexpr int C0 = (decltype(P)::value * NT) >> LR;
+                    put(a, base + (size_t)C0 * a.out_s1, voff, r.re[P], r.im[P]);
+                });
+            } else {  // f -> column P*NT >> LR, row (P*NT & (ROWS-1)) + tid
+                const unsigned voff = (unsigned)tid * (unsigned)a.out_row_stride;
+                static_for<0, 16>([&](auto P) {
+                    constexpr int C0 = (decltype(P)::value * NT) >> LR, K0 = (decltype(P)::value * NT) & (ROWS - 1);
+                    put(a, base + (size_t)C0 * a.out_s1 + (size_t)K0 * a.out_row_stride, voff, r.re[P], r.im[P]);
+                });
+            }
         }
     }
 };
@@ -371,8 +389,23 @@ hipError_t launch_tile_inst(unsigned grid, hipStream_t stream, const TileArgs &a
         lds_limit = lds;
     }
     if (query_only) {
-        return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, reinterpret_cast<const void *>(kern),
-                                                            Body::NT, lds);
+        // residency from the kernel's real register count and LDS request (MI355X_MICROARCH.md: 512 VGPRs per
+        // lane per SIMD in granules of 8, 160 KiB LDS per CU, 32 waves per CU); the occupancy API is only a
+        // cross-check (it under-reports for large dynamic-LDS requests)
+        hipFuncAttributes fa;
+        hipError_t e = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern));
+        if (e != hipSuccess) return e;
+        const int alloc = ((fa.numRegs + 7) / 8) * 8;
+        int waves_per_simd = alloc > 0 ? 512 / alloc : 8;
+        if (waves_per_simd > 8) waves_per_simd = 8;
+        const int waves_per_wg = Body::NT / 64;
+        int by_regs = waves_per_simd * 4 / waves_per_wg;
+        int by_lds = (int)((160 * 1024) / lds);
+        int by_waves = 32 / waves_per_wg;
+        int b = by_regs < by_lds ? by_regs : by_lds;
+        if (by_waves < b) b = by_waves;
+        *blocks_per_cu = b < 1 ? 1 : b;
+        return hipSuccess;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(Body::NT), lds, stream, a);
     return hipGetLastError();

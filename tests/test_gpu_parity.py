@@ -228,7 +228,12 @@ def test_r2c_f64_vs_oracle_and_c2c(gpu, oracle, k):
     gpu.r2c_fft_f64(x, ore, oim)
     ref_re, ref_im = np.zeros(n // 2 + 1), np.zeros(n // 2 + 1)
     oracle.r2c_fft_f64(x, ref_re, ref_im)
-    assert rel_l2(ore, oim, ref_re, ref_im) <= 1e-12
+    # the oracle reproduces the reference's rotation-recurrence twiddles (planner.rs:128-138), which drift by
+    # ~1e-12 (N=2^16) .. 3e-10 (N=2^24); the GPU uses correctly rounded ones, so the bound vs the oracle is the
+    # drift, and the tight bound is against an independent real FFT
+    assert rel_l2(ore, oim, ref_re, ref_im) <= 1e-9
+    ind = np.fft.rfft(x)
+    assert rel_l2(ore, oim, ind.real, ind.imag) <= F64_REL
     out = np.zeros(n)
     gpu.c2r_fft_f64(ore, oim, out)
     assert np.max(np.abs(out - x)) < 1e-6  # r2c.rs:958-976
