@@ -1,0 +1,71 @@
+"""One-shard-per-GPU batching (BASELINE configs[4]).
+
+Independent transforms share nothing (the planner is read-only: planner.rs:38-39), so a batch is cut into
+contiguous shards, one per rank, and every rank transforms its shard with zero communication.  The only
+collective is the trivial gather of a 32-byte digest per transform (sum re, sum im, energy, one probe bin)
+-- gathering full outputs would be xGMI-bound by construction (112 GiB inbound for 8192 x 2^20 f64).
+`torch.distributed` supplies the process group: backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the
+CPU tests of the host logic.
+"""
+from __future__ import annotations
+
+from typing import Callable, Sequence
+
+
+def shard_bounds(total: int, world: int, rank: int) -> tuple[int, int]:
+    """(first transform id, count) of `rank`'s contiguous shard; the remainder goes to the first ranks."""
+    if world <= 0 or not (0 <= rank < world) or total < 0:
+        raise ValueError("bad shard request")
+    base, rem = divmod(total, world)
+    count = base + (1 if rank < rem else 0)
+    first = rank * base + min(rank, rem)
+    return first, count
+
+
+class ShardedBatch:
+    """`total` independent length-`n` transforms split over the ranks of a process group.
+
+    `transform(first_id, count)` runs the rank's shard in place and `digest(first_id, count)` returns a
+    (count, 4) float64 tensor; both are injected so that the GPU path (phastft_amd on device tensors) and the
+    CPU tests of this host logic share the code.
+    """
+
+    def __init__(self, total: int, n: int, rank: int, world: int, transform: Callable[[int, int], None],
+                 digest: Callable[[int, int], "object"]):
+        self.total, self.n, self.rank, self.world = total, n, rank, world
+        self.first, self.count = shard_bounds(total, world, rank)
+        self._transform, self._digest = transform, digest
+
+    def step(self) -> None:
+        if self.count:
+            self._transform(self.first, self.count)
+
+    def samples_per_step(self) -> int:
+        """whole-job samples per step (all ranks)"""
+        return self.total * self.n
+
+    def gather_digests(self, dist=None):
+        """All-gather of the per-transform digests; returns a (total, 4) tensor ordered by transform id."""
+        import torch
+
+        mine = self._digest(self.first, self.count)
+        if dist is None or self.world == 1:
+            return mine
+        counts = [shard_bounds(self.total, self.world, r)[1] for r in range(self.world)]
+        width = max(counts)
+        pad = torch.zeros((width, 4), dtype=mine.dtype, device=mine.device)
+        pad[: self.count] = mine
+        parts = [torch.empty_like(pad) for _ in range(self.world)]
+        dist.all_gather(parts, pad)
+        return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
+
+
+def max_over_ranks(seconds: float, dist=None, device=None) -> float:
+    """The bench contract: a step is as slow as its slowest rank."""
+    if dist is None:
+        return seconds
+    import torch
+
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

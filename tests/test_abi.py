@@ -1,0 +1,95 @@
+"""CPU-side checks of the drop-in boundary: libphastft_hip.so loads without a GPU, exports every symbol
+include/phastft_hip.h declares, keeps the reference's panic strings, and never computes on the CPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "phastft_hip.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(phast_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported_and_listed():
+    from phastft_amd import _lib
+
+    lib = _lib.lib()
+    syms = declared_symbols()
+    assert len(syms) >= 55
+    for s in syms:
+        getattr(lib, s)  # AttributeError = declared but not exported
+    assert sorted(_lib.SYMBOLS) == syms  # the Python loader's list is the header's list
+
+
+def test_header_cites_the_reference():
+    text = open(HEADER).read()
+    for cite in ("lib.rs:180", "lib.rs:143", "algorithms/dit.rs:263", "planner.rs:55", "planner.rs:194",
+                 "algorithms/r2c.rs:521", "algorithms/r2c.rs:695", "options.rs:38", "algorithms/bravo.rs:303"):
+        assert cite in text, cite
+
+
+def test_strerror_keeps_reference_panic_text():
+    from phastft_amd import _lib
+
+    lib = _lib.lib()
+    want = {4: "n must be a power of 2 >= 4", 5: "input length must match planner size",
+            6: "output_re must have length N/2 + 1", 7: "output_im must have length N/2 + 1",
+            8: "output length must match planner size", 9: "input_re must have length N/2 + 1",
+            10: "input_im must have length N/2 + 1", 11: "scratch_re must have length N/2",
+            12: "scratch_im must have length N/2"}
+    for code, msg in want.items():
+        assert lib.phast_strerror(code).decode() == msg
+
+
+def test_host_logic_without_a_device():
+    import phastft_amd as P
+
+    o = P.Options.guess_options(1 << 20)  # options.rs:38-43
+    assert o.multithreaded_bit_reversal and o.smallest_parallel_chunk_size == 16384
+    assert not P.Options.guess_options(1 << 15).multithreaded_bit_reversal
+    assert P.Options() == P.Options(False, 16384)  # options.rs:26-33
+    assert int(P.Direction.Forward) == 1 and int(P.Direction.Reverse) == -1  # planner.rs:13-15
+    with pytest.raises(P.PhastPanic):  # argument asserts fire before any device work
+        P.PlannerDit64(5)
+    with pytest.raises(P.PhastPanic) as ei:
+        P.PlannerR2c32(6)
+    assert str(ei.value) == "n must be a power of 2 >= 4"
+    with pytest.raises(P.PhastPanic):
+        P.bit_rev_bravo_f64(np.zeros(10), 3)
+    with pytest.raises(TypeError):
+        P.fft_64_dit(np.zeros(8, np.float32), np.zeros(8, np.float32), P.Direction.Forward)
+
+
+def test_no_cpu_fallback():
+    """Without a GPU every compute entry point must fail loudly, never compute on the host."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import phastft_amd as P
+
+    re, im = np.arange(16.0), np.zeros(16)
+    for call in (lambda: P.fft_64_dit(re, im, P.Direction.Forward), lambda: P.PlannerDit64(1024),
+                 lambda: P.bit_rev_bravo_f64(np.arange(8.0), 3),
+                 lambda: P.r2c_fft_f64(np.zeros(16), np.zeros(9), np.zeros(9))):
+        with pytest.raises(P.PhastHipError):
+            call()
+    assert np.array_equal(re, np.arange(16.0))  # untouched
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "phastft_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")) and f != "emu.hip":
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.replace("oracle/", "").replace("the oracle", "").replace("host oracle", "") \
+                    or "import oracle" not in text, f
+                assert "from oracle" not in text and "import oracle" not in text, f

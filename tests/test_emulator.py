@@ -1,0 +1,100 @@
+"""The tile-FFT kernels' index arithmetic, LDS layouts, twiddle tables and pass plans, executed on the
+CPU: libphastft_emu.so runs the SAME `TileBody` phase functions (csrc/tile_fft.hpp) and the SAME plan
+geometry (csrc/plan.hpp) as the GPU kernels, thread by thread, and is compared with the oracle.  This is
+what keeps kernel edits honest in the GPU-less build container; the `-m gpu` tests check the real thing."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def emu():
+    from phastft_amd import build
+
+    lib = C.CDLL(build.build_emulator())
+    lib.phast_emu_fft_f32_modes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint,
+                                            C.c_double, C.c_void_p, C.c_size_t, C.c_uint]
+    return lib
+
+
+def run(emu, re, im, direction=1, lrs=(), tile_log=12):
+    L = int(np.log2(re.size))
+    arr = (C.c_uint * max(1, len(lrs)))(*lrs)
+    fn = emu.phast_emu_fft_f64 if re.dtype == np.float64 else emu.phast_emu_fft_f32
+    return fn(re.ctypes.data_as(C.c_void_p), im.ctypes.data_as(C.c_void_p), C.c_uint(L), C.c_size_t(1),
+              C.c_int(direction), arr, C.c_size_t(len(lrs)), C.c_uint(tile_log))
+
+
+SHAPES = [(6, 6), (7, 5), (8, 4), (9, 3), (10, 2), (7, 6), (8, 5), (9, 4), (10, 3), (8, 6), (9, 5), (10, 4)]
+
+
+@pytest.mark.parametrize("is_f64", [1, 0])
+def test_lds_exchanges_in_bounds_permutations_and_conflict_free(emu, is_f64):
+    for lr, lc in SHAPES:
+        for transpose in (1, 0):
+            r, w = C.c_int(), C.c_int()
+            errors = emu.phast_emu_audit_lds(is_f64, lr, lc, transpose, C.byref(r), C.byref(w))
+            assert errors == 0, (lr, lc, transpose)
+            assert r.value == 1 and w.value == 1, (lr, lc, transpose, r.value, w.value)
+
+
+PLANS = [(12, (6, 6), 12), (13, (7, 6), 12), (15, (8, 7), 12), (16, (8, 8), 13), (17, (9, 8), 13), (18, (9, 9), 12),
+         (19, (10, 9), 13), (20, (10, 10), 12), (20, (10, 10), 13), (20, (10, 10), 14), (20, (7, 7, 6), 12),
+         (18, (6, 6, 6), 12), (21, (7, 7, 7), 13), (22, (8, 7, 7), 13)]
+
+
+@pytest.mark.parametrize("L,lrs,tl", PLANS)
+def test_forced_plans_vs_oracle_f64(emu, oracle, L, lrs, tl):
+    n = 1 << L
+    re, im = oracle.fill(n, np.float64, transform_id=L)
+    a, b = re.copy(), im.copy()
+    assert run(emu, a, b, 1, lrs, tl) == 0
+    oracle.fft_64_dit(re, im, oracle.FORWARD)
+    err = np.sqrt(np.sum((a - re) ** 2 + (b - im) ** 2) / np.sum(re ** 2 + im ** 2))
+    assert err <= 1e-13, err
+
+
+@pytest.mark.parametrize("L", list(range(12, 23)))
+def test_default_plans_both_types_and_inverse(emu, oracle, L):
+    n = 1 << L
+    for is_f64, dtype, tol, ofn in ((1, np.float64, 1e-13, oracle.fft_64_dit), (0, np.float32, 1e-5, oracle.fft_32_dit)):
+        for latency in (0, 1):
+            lrs = (C.c_uint * 3)()
+            tl = C.c_uint()
+            npass = emu.phast_emu_default_plan(is_f64, latency, L, lrs, C.byref(tl))
+            assert npass in (2, 3)
+            re, im = oracle.fill(n, dtype, transform_id=7 * L + latency)
+            a, b = re.copy(), im.copy()
+            direction = -1 if latency else 1
+            assert run(emu, a, b, direction, tuple(lrs)[:npass], tl.value) == 0
+            ofn(re, im, oracle.REVERSE if latency else oracle.FORWARD)
+            err = np.sqrt(np.sum((a.astype(np.float64) - re) ** 2 + (b.astype(np.float64) - im) ** 2) /
+                          np.sum(re.astype(np.float64) ** 2 + im.astype(np.float64) ** 2))
+            assert err <= tol, (L, is_f64, latency, err)
+
+
+def test_interleaved_load_and_swapped_interleaved_store(emu, oracle):
+    """The R2C deinterleave fused into the first pass's load and the C2R (im, re) interleave fused into the
+    last pass's store (r2c.rs:73-128, 446-489; algorithms/dit.rs:297-300)."""
+    L = 14
+    n = 1 << L
+    re, im = oracle.fill(n, np.float32, transform_id=3)
+    z = np.empty(2 * n, np.float32)
+    z[0::2], z[1::2] = re, im
+    out_re, out_im = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    lrs = (C.c_uint * 2)(7, 7)
+    p = lambda x: x.ctypes.data_as(C.c_void_p)
+    assert emu.phast_emu_fft_f32_modes(p(z), None, 1, p(out_re), p(out_im), 0, L, 1.0, lrs, 2, 12) == 0
+    r, m = re.copy(), im.copy()
+    oracle.fft_32_dit(r, m, oracle.FORWARD)
+    assert np.sqrt(np.sum((out_re - r) ** 2 + (out_im - m) ** 2) / np.sum(r ** 2 + m ** 2)) < 1e-5
+    # inverse by the swap trick, stored as (im, re) pairs == interleaved (re, im) of the true inverse
+    zz = np.zeros(2 * n, np.float32)
+    assert emu.phast_emu_fft_f32_modes(p(im), p(re), 0, p(zz), None, 2, L, 1.0 / n, lrs, 2, 12) == 0
+    r, m = re.copy(), im.copy()
+    oracle.fft_32_dit(r, m, oracle.REVERSE)
+    assert np.max(np.abs(zz[0::2] - r)) < 1e-6 and np.max(np.abs(zz[1::2] - m)) < 1e-6
