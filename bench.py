@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly from Python")
     ap.add_argument("--shard", type=int, default=SHARD, help="transforms per GPU when --gpus > 1")
     ap.add_argument("--extra", action="store_true", help="also measure N=2^26 and the batched shard at --gpus 1")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for dry runs)")
+    ap.add_argument("--same-gpu", action="store_true", help="dry run: every rank uses cuda:0 (needs --backend gloo)")
     return ap.parse_args()
 
 
@@ -79,8 +81,13 @@ def main():
     if multi:
         import torch.distributed as dist
 
+        if args.same_gpu:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
     else:
         torch.cuda.set_device(0)
     if args.gpus != world and rank == 0 and (args.gpus > 1 or world > 1):
@@ -153,42 +160,48 @@ def main():
     else:
         steps = args.steps if args.steps is not None else 10
         warmup = args.warmup if args.warmup is not None else 2
-        shard = args.shard
-        re = torch.empty(shard * N, dtype=torch.float64, device=dev)
-        im = torch.empty_like(re)
-        P.fill_uniform(re, im, N, seed=0xCAFE + rank, first_id=rank * shard)
-
-        def step(i):
-            P.fft_dit_batched(re, im, N, P.Direction.Forward, planner)
-
-        for i in range(warmup):
-            step(i)
-        # values grow by sqrt(N) per in-place step: refill so K timed steps stay far from overflow
-        P.fill_uniform(re, im, N, seed=0xCAFE + rank, first_id=rank * shard)
-        torch.cuda.synchronize()
         import torch.distributed as dist
 
+        from phastft_amd.sharding import ShardedBatch, max_over_ranks
+
+        total = args.shard * world
+        first, shard = rank * args.shard, args.shard
+        re = torch.empty(shard * N, dtype=torch.float64, device=dev)
+        im = torch.empty_like(re)
+
+        def refill():
+            P.fill_uniform(re, im, N, seed=0xCAFE, first_id=first)
+
+        def transform(first_id, count):  # the rank's contiguous shard, in place, no communication
+            P.fft_dit_batched(re, im, N, P.Direction.Forward, planner)
+
+        def digest_fn(first_id, count):
+            return P.digest(re, im, N, probe=1)
+
+        sb = ShardedBatch(total, N, rank, world, transform, digest_fn)
+        assert (sb.first, sb.count) == (first, shard)
+        refill()
+        for i in range(warmup):
+            sb.step()
+        refill()  # values grow by sqrt(N) per in-place step: K timed steps from fresh inputs stay far from overflow
+        torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
-            step(i)
+            sb.step()
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        # the trivial gather: one 32-byte digest per rank (first transform of the shard) over RCCL
-        dg = P.digest(re[:N], im[:N], N, probe=1).reshape(-1)
-        gathered = [torch.empty_like(dg) for _ in range(world)]
-        dist.all_gather(gathered, dg)
-        samples_per_step = N * shard * world
-        workload = (f"{shard * world} independent f64 forward FFTs N=2^{LOG_N}, {shard} per GPU, in place "
+        elapsed = max_over_ranks(time.perf_counter() - t0, dist, dev)
+        # the trivial gather (RCCL over xGMI): one 32-byte digest per transform -> (total, 4) on every rank
+        digests = sb.gather_digests(dist)
+        digest_ok = bool(torch.isfinite(digests).all()) and digests.shape[0] == total
+        samples_per_step = sb.samples_per_step()
+        workload = (f"{total} independent f64 forward FFTs N=2^{LOG_N}, {shard} per GPU, in place "
                     f"(BASELINE configs[4])")
         launch = "eager batched launches"
-        P.fill_uniform(re, im, N, seed=0xCAFE + rank, first_id=rank * shard)
+        refill()
         torch.cuda.synchronize()
         pass_ms = planner.time_passes(re, im, N, reps=2)
         units = shard
@@ -220,6 +233,12 @@ def main():
                        "plan": plan_text, "launch": launch},
             "roofline": roofline,
         }
+        if n_gpus > 1:
+            out["config"]["digest_gather"] = f"all_gather of {samples_per_step // N} x 32 B digests over RCCL"
+            out["config"]["digest_ok"] = digest_ok
+        traffic = load_profiled_traffic(n_gpus)
+        if traffic is not None:
+            roofline.update(traffic)
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         if n_gpus == 1 and args.extra:
@@ -230,6 +249,23 @@ def main():
 
         dist.barrier()
         dist.destroy_process_group()
+
+
+def load_profiled_traffic(n_gpus):
+    """HBM bytes per launch of the dominant pass kernel from the rocprofv3 PMC runs committed under
+    profiles/ (FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md's HBM
+    section prescribes for gfx950).  bench.py cannot collect PMC counters itself; the file records which
+    command produced the numbers.  None when no profile matches this workload."""
+    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+    except (OSError, ValueError):
+        return None
+    key = "single_2p20" if n_gpus == 1 else "batch_2p20"
+    if key not in t:
+        return None
+    return {"traffic": t[key]["hbm_bytes_per_launch"], "traffic_source": t[key]["source"]}
 
 
 def extra_measurements(P, torch, dev):

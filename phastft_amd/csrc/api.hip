@@ -85,19 +85,23 @@ struct PassDesc : PassGeom {
 
 template <typename T> struct Types;
 template <> struct Types<double> {
-    static hipError_t launch_a(int lr, int lc, unsigned g, hipStream_t s, const TileArgs &a, bool q, int *b, size_t *l) {
-        return launch_tile_f64_a(lr, lc, g, s, a, q, b, l);
+    static hipError_t launch_a(int lr, int lc, unsigned g, hipStream_t s, const TileArgs &a, bool q, int *b, size_t *l,
+                               hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
+        return launch_tile_f64_a(lr, lc, g, s, a, q, b, l, e0, e1);
     }
-    static hipError_t launch_bc(int lr, int lc, unsigned g, hipStream_t s, const TileArgs &a, bool q, int *b, size_t *l) {
-        return launch_tile_f64_bc(lr, lc, g, s, a, q, b, l);
+    static hipError_t launch_bc(int lr, int lc, unsigned g, hipStream_t s, const TileArgs &a, bool q, int *b, size_t *l,
+                               hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
+        return launch_tile_f64_bc(lr, lc, g, s, a, q, b, l, e0, e1);
     }
 };
 template <> struct Types<float> {
-    static hipError_t launch_a(int lr, int lc, unsigned g, hipStream_t s, const TileArgs &a, bool q, int *b, size_t *l) {
-        return launch_tile_f32_a(lr, lc, g, s, a, q, b, l);
+    static hipError_t launch_a(int lr, int lc, unsigned g, hipStream_t s, const TileArgs &a, bool q, int *b, size_t *l,
+                               hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
+        return launch_tile_f32_a(lr, lc, g, s, a, q, b, l, e0, e1);
     }
-    static hipError_t launch_bc(int lr, int lc, unsigned g, hipStream_t s, const TileArgs &a, bool q, int *b, size_t *l) {
-        return launch_tile_f32_bc(lr, lc, g, s, a, q, b, l);
+    static hipError_t launch_bc(int lr, int lc, unsigned g, hipStream_t s, const TileArgs &a, bool q, int *b, size_t *l,
+                               hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
+        return launch_tile_f32_bc(lr, lc, g, s, a, q, b, l, e0, e1);
     }
 };
 
@@ -117,12 +121,16 @@ struct PassTimer {
     ~PassTimer() {
         for (auto e : ev) hipEventDestroy(e);
     }
-    hipError_t mark(hipStream_t s) {
-        hipEvent_t e;
-        hipError_t rc = hipEventCreate(&e);
+    // a fresh (start, stop) pair; the launcher binds it to the dispatch (hipExtLaunchKernelGGL), so the
+    // interval is the kernel's own execution time -- what rocprofv3 --kernel-trace reports
+    hipError_t pair(int pass, hipEvent_t *e0, hipEvent_t *e1) {
+        hipError_t rc = hipEventCreate(e0);
+        if (rc == hipSuccess) rc = hipEventCreate(e1);
         if (rc != hipSuccess) return rc;
-        ev.push_back(e);
-        return hipEventRecord(e, s);
+        ev.push_back(*e0);
+        ev.push_back(*e1);
+        pass_of.push_back(pass);
+        return hipSuccess;
     }
 };
 
@@ -297,12 +305,9 @@ template <typename T> struct Planner {
                 sa.in_interleaved = in_mode;
                 sa.out_interleaved = out_mode;
                 sa.scale = scale;
-                if (timer) PHAST_HIP(timer->mark(stream));
-                PHAST_HIP(launch_small_fft<T>(sa, stream));
-                if (timer) {
-                    PHAST_HIP(timer->mark(stream));
-                    timer->pass_of.push_back(0);
-                }
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                if (timer) PHAST_HIP(timer->pair(0, &e0, &e1));
+                PHAST_HIP(launch_small_fft<T>(sa, stream, e0, e1));
             }
             return PHAST_OK;
         }
@@ -350,14 +355,11 @@ template <typename T> struct Planner {
                 unsigned grid = (unsigned)(g_wg_per_cu_override > 0 ? g_wg_per_cu_override : p.blocks_per_cu) * (unsigned)g_cus;
                 if (grid > ta.tiles_total) grid = ta.tiles_total;
                 if (grid >= 8) grid &= ~7u;  // keep tile%8 == workgroup%8 (XCD affinity of the tile order)
-                if (timer) PHAST_HIP(timer->mark(stream));
-                hipError_t e = p.transpose ? Types<T>::launch_a(p.lr, p.lc, grid, stream, ta, false, nullptr, nullptr)
-                                           : Types<T>::launch_bc(p.lr, p.lc, grid, stream, ta, false, nullptr, nullptr);
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                if (timer) PHAST_HIP(timer->pair((int)i, &e0, &e1));
+                hipError_t e = p.transpose ? Types<T>::launch_a(p.lr, p.lc, grid, stream, ta, false, nullptr, nullptr, e0, e1)
+                                           : Types<T>::launch_bc(p.lr, p.lc, grid, stream, ta, false, nullptr, nullptr, e0, e1);
                 if (e != hipSuccess) return hip_fail(e, "tile_fft launch");
-                if (timer) {
-                    PHAST_HIP(timer->mark(stream));
-                    timer->pass_of.push_back((int)i);
-                }
             }
         }
         return PHAST_OK;

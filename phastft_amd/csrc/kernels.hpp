@@ -21,7 +21,9 @@ struct SmallArgs {
     double scale;
 };
 constexpr unsigned kSmallMaxLog = 11;
-template <typename T> hipError_t launch_small_fft(const SmallArgs &a, hipStream_t stream);
+template <typename T>
+hipError_t launch_small_fft(const SmallArgs &a, hipStream_t stream, hipEvent_t ev_start = nullptr,
+                            hipEvent_t ev_stop = nullptr);
 
 // ---- bitrev.hip: in-place bit-reversal permutation of `batch` arrays of 2^log_n elements ----
 template <typename T> hipError_t launch_bitrev(T *data, unsigned log_n, size_t batch, size_t dist, hipStream_t stream);

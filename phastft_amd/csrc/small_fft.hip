@@ -5,6 +5,8 @@
 // workgroup per transform; the bit reversal is the LDS store index of the load, each stage is one
 // sweep over LDS with W_{2^(s+1)}^j read from a W_N table.  Small N is launch-bound, not a
 // bandwidth problem, so this kernel favours being obviously correct.
+#include <hip/hip_ext.h>
+
 #include "kernels.hpp"
 
 namespace phast {
@@ -65,14 +67,18 @@ template <typename T> __global__ void __launch_bounds__(256) small_fft_kernel(co
     }
 }
 
-template <typename T> hipError_t launch_small_fft(const SmallArgs &a, hipStream_t stream) {
+template <typename T>
+hipError_t launch_small_fft(const SmallArgs &a, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     const size_t lds = (size_t)2 * sizeof(T) << a.log_n;
     const unsigned grid = a.batch < 65536u ? a.batch : 65536u;
-    hipLaunchKernelGGL(small_fft_kernel<T>, dim3(grid), dim3(256), lds, stream, a);
+    if (ev_start && ev_stop)
+        hipExtLaunchKernelGGL(small_fft_kernel<T>, dim3(grid), dim3(256), (uint32_t)lds, stream, ev_start, ev_stop, 0, a);
+    else
+        hipLaunchKernelGGL(small_fft_kernel<T>, dim3(grid), dim3(256), lds, stream, a);
     return hipGetLastError();
 }
 
-template hipError_t launch_small_fft<float>(const SmallArgs &, hipStream_t);
-template hipError_t launch_small_fft<double>(const SmallArgs &, hipStream_t);
+template hipError_t launch_small_fft<float>(const SmallArgs &, hipStream_t, hipEvent_t, hipEvent_t);
+template hipError_t launch_small_fft<double>(const SmallArgs &, hipStream_t, hipEvent_t, hipEvent_t);
 
 }  // namespace phast

@@ -26,6 +26,8 @@
 // -- the build container has no GPU.
 #pragma once
 
+#include <hip/hip_ext.h>
+
 #include "common.hpp"
 
 namespace phast {
@@ -374,7 +376,7 @@ __global__ void __launch_bounds__(1 << (LR + LC - 4)) tile_fft_kernel(const Tile
 // host-side launcher for one (T, LR, LC, mode) instantiation
 template <typename T, int LR, int LC, bool PRE_TW, bool TRANSPOSE>
 hipError_t launch_tile_inst(unsigned grid, hipStream_t stream, const TileArgs &a, bool query_only, int *blocks_per_cu,
-                            size_t *lds_out) {
+                            size_t *lds_out, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
     using Body = TileBody<T, LR, LC, PRE_TW, TRANSPOSE>;
     auto kern = tile_fft_kernel<T, LR, LC, PRE_TW, TRANSPOSE>;
     const size_t lds = Body::lds_bytes(a.tw_bits);
@@ -407,7 +409,10 @@ hipError_t launch_tile_inst(unsigned grid, hipStream_t stream, const TileArgs &a
         *blocks_per_cu = b < 1 ? 1 : b;
         return hipSuccess;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(Body::NT), lds, stream, a);
+    if (ev_start && ev_stop)  // events bound to the dispatch itself: their interval is the kernel's execution time
+        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(Body::NT), (uint32_t)lds, stream, ev_start, ev_stop, 0, a);
+    else
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(Body::NT), lds, stream, a);
     return hipGetLastError();
 }
 

@@ -51,6 +51,8 @@ class ShardedBatch:
         mine = self._digest(self.first, self.count)
         if dist is None or self.world == 1:
             return mine
+        if dist.get_backend() == "gloo":  # CPU collectives (tests, dry runs)
+            mine = mine.cpu()
         counts = [shard_bounds(self.total, self.world, r)[1] for r in range(self.world)]
         width = max(counts)
         pad = torch.zeros((width, 4), dtype=mine.dtype, device=mine.device)
@@ -66,6 +68,8 @@ def max_over_ranks(seconds: float, dist=None, device=None) -> float:
         return seconds
     import torch
 
+    if dist.get_backend() == "gloo":
+        device = "cpu"
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
