@@ -38,18 +38,18 @@ extern "C" {
 
 /* ---- status codes: one per reference assert ---- */
 #define PHAST_OK 0
-#define PHAST_ERR_NOT_POW2 1        /* planner.rs:66, algorithms/dit.rs:285,357 */
-#define PHAST_ERR_LEN_MISMATCH 2    /* algorithms/dit.rs:284,356 */
-#define PHAST_ERR_PLANNER_SIZE 3    /* algorithms/dit.rs:289,361 */
+#define PHAST_ERR_NOT_POW2 1        /* planner.rs:66, algorithms/dit.rs:285,359 */
+#define PHAST_ERR_LEN_MISMATCH 2    /* algorithms/dit.rs:284,358 */
+#define PHAST_ERR_PLANNER_SIZE 3    /* algorithms/dit.rs:289,363 */
 #define PHAST_ERR_R2C_N 4           /* planner.rs:195 */
-#define PHAST_ERR_R2C_INPUT_LEN 5   /* algorithms/r2c.rs:535,615 */
-#define PHAST_ERR_R2C_OUT_RE_LEN 6  /* algorithms/r2c.rs:536-540,616-620 */
-#define PHAST_ERR_R2C_OUT_IM_LEN 7  /* algorithms/r2c.rs:541-545,621-625 */
-#define PHAST_ERR_C2R_OUTPUT_LEN 8  /* algorithms/r2c.rs:737,842 */
-#define PHAST_ERR_C2R_IN_RE_LEN 9   /* algorithms/r2c.rs:738-742,843-847 */
-#define PHAST_ERR_C2R_IN_IM_LEN 10  /* algorithms/r2c.rs:743-747,848-852 */
-#define PHAST_ERR_C2R_SCRATCH_RE 11 /* algorithms/r2c.rs:748,853 */
-#define PHAST_ERR_C2R_SCRATCH_IM 12 /* algorithms/r2c.rs:749,854 */
+#define PHAST_ERR_R2C_INPUT_LEN 5   /* algorithms/r2c.rs:543,615 */
+#define PHAST_ERR_R2C_OUT_RE_LEN 6  /* algorithms/r2c.rs:544-548,616-620 */
+#define PHAST_ERR_R2C_OUT_IM_LEN 7  /* algorithms/r2c.rs:549-553,621-625 */
+#define PHAST_ERR_C2R_OUTPUT_LEN 8  /* algorithms/r2c.rs:750,846 */
+#define PHAST_ERR_C2R_IN_RE_LEN 9   /* algorithms/r2c.rs:751-755,847-851 */
+#define PHAST_ERR_C2R_IN_IM_LEN 10  /* algorithms/r2c.rs:756-760,852-856 */
+#define PHAST_ERR_C2R_SCRATCH_RE 11 /* algorithms/r2c.rs:761,857 */
+#define PHAST_ERR_C2R_SCRATCH_IM 12 /* algorithms/r2c.rs:762,858 */
 #define PHAST_ERR_ALLOC 13          /* host allocation failed */
 #define PHAST_ERR_HIP 14            /* a HIP runtime call failed; see phast_last_hip_error() */
 #define PHAST_ERR_NO_DEVICE 15      /* no gfx950 device visible: the library never falls back to CPU */
@@ -130,7 +130,7 @@ int phast_r2c_fft_f32(const float *input_re, size_t input_len, float *output_re,
                       float *output_im, size_t output_im_len); /* r2c.rs:598 */
 int phast_r2c_fft_f64_with_planner(const double *input_re, size_t input_len, double *output_re,
                                    size_t output_re_len, double *output_im, size_t output_im_len,
-                                   const phast_planner_r2c64 *planner); /* r2c.rs:527 */
+                                   const phast_planner_r2c64 *planner); /* r2c.rs:535 */
 int phast_r2c_fft_f32_with_planner(const float *input_re, size_t input_len, float *output_re, size_t output_re_len,
                                    float *output_im, size_t output_im_len,
                                    const phast_planner_r2c32 *planner); /* r2c.rs:607 */
@@ -144,15 +144,15 @@ int phast_r2c_fft_f32_dev(const float *d_input, float *d_output_re, float *d_out
 int phast_c2r_fft_f64(const double *input_re, size_t input_re_len, const double *input_im, size_t input_im_len,
                       double *output, size_t output_len); /* r2c.rs:695 */
 int phast_c2r_fft_f32(const float *input_re, size_t input_re_len, const float *input_im, size_t input_im_len,
-                      float *output, size_t output_len); /* r2c.rs:800 */
+                      float *output, size_t output_len); /* r2c.rs:804 */
 int phast_c2r_fft_f64_with_planner(const double *input_re, size_t input_re_len, const double *input_im,
                                    size_t input_im_len, double *output, size_t output_len,
-                                   const phast_planner_r2c64 *planner); /* r2c.rs:704 */
+                                   const phast_planner_r2c64 *planner); /* r2c.rs:710 */
 int phast_c2r_fft_f32_with_planner(const float *input_re, size_t input_re_len, const float *input_im,
                                    size_t input_im_len, float *output, size_t output_len,
-                                   const phast_planner_r2c32 *planner); /* r2c.rs:809 */
+                                   const phast_planner_r2c32 *planner); /* r2c.rs:813 */
 /* the scratch slices are validated for length exactly as the reference does and otherwise unused:
- * the device path keeps its workspace in the planner (r2c.rs:727,832) */
+ * the device path keeps its workspace in the planner (r2c.rs:740,836) */
 int phast_c2r_fft_f64_with_planner_and_scratch(const double *input_re, size_t input_re_len, const double *input_im,
                                                size_t input_im_len, double *output, size_t output_len,
                                                const phast_planner_r2c64 *planner, double *scratch_re,

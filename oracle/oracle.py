@@ -220,7 +220,7 @@ def _c2r(sfx, dtype, input_re, input_im, output, planner=None, scratch_re=None, 
     if planner is None:
         _check(getattr(lib(), "pho_c2r_fft_" + sfx)(*args))
         return
-    if scratch_re is None:  # r2c.rs:704-725: the allocating form
+    if scratch_re is None:  # r2c.rs:710-725: the allocating form
         half = planner.n // 2
         scratch_re, scratch_im = np.zeros(half, dtype), np.zeros(half, dtype)
     _req(scratch_re, dtype), _req(scratch_im, dtype)

@@ -39,11 +39,11 @@ extern "C" {
 #define PHO_ERR_R2C_INPUT_LEN 5  /* r2c.rs:543     "input length must match planner size" */
 #define PHO_ERR_R2C_OUT_RE_LEN 6 /* r2c.rs:544-548 "output_re must have length N/2 + 1" */
 #define PHO_ERR_R2C_OUT_IM_LEN 7 /* r2c.rs:549-553 "output_im must have length N/2 + 1" */
-#define PHO_ERR_C2R_OUTPUT_LEN 8 /* r2c.rs:735     "output length must match planner size" */
-#define PHO_ERR_C2R_IN_RE_LEN 9  /* r2c.rs:736-740 "input_re must have length N/2 + 1" */
-#define PHO_ERR_C2R_IN_IM_LEN 10 /* r2c.rs:741-745 "input_im must have length N/2 + 1" */
-#define PHO_ERR_C2R_SCRATCH_RE 11 /* r2c.rs:746    "scratch_re must have length N/2" */
-#define PHO_ERR_C2R_SCRATCH_IM 12 /* r2c.rs:747    "scratch_im must have length N/2" */
+#define PHO_ERR_C2R_OUTPUT_LEN 8 /* r2c.rs:750     "output length must match planner size" */
+#define PHO_ERR_C2R_IN_RE_LEN 9  /* r2c.rs:751-755 "input_re must have length N/2 + 1" */
+#define PHO_ERR_C2R_IN_IM_LEN 10 /* r2c.rs:756-760 "input_im must have length N/2 + 1" */
+#define PHO_ERR_C2R_SCRATCH_RE 11 /* r2c.rs:761    "scratch_re must have length N/2" */
+#define PHO_ERR_C2R_SCRATCH_IM 12 /* r2c.rs:762    "scratch_im must have length N/2" */
 #define PHO_ERR_ALLOC 13
 
 /* options.rs:10-24 */

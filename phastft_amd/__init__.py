@@ -401,7 +401,7 @@ def r2c_fft_f32(input_re, output_re, output_im) -> None:
 
 
 def r2c_fft_f64_with_planner(input_re, output_re, output_im, planner: PlannerR2c64) -> None:
-    """r2c.rs:527"""
+    """r2c.rs:535"""
     _r2c("f64", np.float64, input_re, output_re, output_im, planner)
 
 
@@ -455,27 +455,27 @@ def c2r_fft_f64(input_re, input_im, output) -> None:
 
 
 def c2r_fft_f32(input_re, input_im, output) -> None:
-    """r2c.rs:800"""
+    """r2c.rs:804"""
     _c2r("f32", np.float32, input_re, input_im, output)
 
 
 def c2r_fft_f64_with_planner(input_re, input_im, output, planner: PlannerR2c64) -> None:
-    """r2c.rs:704"""
+    """r2c.rs:710"""
     _c2r("f64", np.float64, input_re, input_im, output, planner)
 
 
 def c2r_fft_f32_with_planner(input_re, input_im, output, planner: PlannerR2c32) -> None:
-    """r2c.rs:809"""
+    """r2c.rs:813"""
     _c2r("f32", np.float32, input_re, input_im, output, planner)
 
 
 def c2r_fft_f64_with_planner_and_scratch(input_re, input_im, output, planner, scratch_re, scratch_im) -> None:
-    """r2c.rs:727"""
+    """r2c.rs:740"""
     _c2r("f64", np.float64, input_re, input_im, output, planner, (scratch_re, scratch_im))
 
 
 def c2r_fft_f32_with_planner_and_scratch(input_re, input_im, output, planner, scratch_re, scratch_im) -> None:
-    """r2c.rs:832"""
+    """r2c.rs:836"""
     _c2r("f32", np.float32, input_re, input_im, output, planner, (scratch_re, scratch_im))
 
 

@@ -410,7 +410,7 @@ template <typename T> struct PlannerR2c {
         return PHAST_OK;
     }
 
-    // r2c.rs:527-593 / 607-662 on device pointers
+    // r2c.rs:535-593 / 607-662 on device pointers
     int r2c(const T *d_in, T *d_ore, T *d_oim, size_t batch, size_t in_dist, size_t out_dist, hipStream_t s) const {
         const size_t half = n / 2;
         if (in_dist & 1) return PHAST_ERR_INVALID_ARG;  // the input is read as (even, odd) pairs
@@ -430,7 +430,7 @@ template <typename T> struct PlannerR2c {
         return PHAST_OK;
     }
 
-    // r2c.rs:727-790 / 832-895 on device pointers
+    // r2c.rs:740-790 / 836-895 on device pointers
     int c2r(const T *d_ire, const T *d_iim, T *d_out, size_t batch, size_t in_dist, size_t out_dist,
             hipStream_t s) const {
         const size_t half = n / 2;

@@ -193,7 +193,7 @@ impl_fft!(f32, PlannerDit32, fft_32_dit_with_planner_and_opts, fft_32_dit_with_p
 
 macro_rules! impl_r2c {
     ($t:ty, $planner:ident, $r2c:ident, $r2c_p:ident, $c2r:ident, $c2r_p:ident, $c2r_ps:ident, $c_r2c:ident, $c_c2r:ident) => {
-        /// r2c.rs:527 / 607
+        /// r2c.rs:535 / 607
         pub fn $r2c_p(input_re: &[$t], output_re: &mut [$t], output_im: &mut [$t], planner: &$planner) {
             check(unsafe {
                 $c_r2c(input_re.as_ptr(), input_re.len(), output_re.as_mut_ptr(), output_re.len(),
@@ -205,7 +205,7 @@ macro_rules! impl_r2c {
             let planner = <$planner>::new(input_re.len());
             $r2c_p(input_re, output_re, output_im, &planner);
         }
-        /// r2c.rs:727 / 832
+        /// r2c.rs:740 / 836
         pub fn $c2r_ps(input_re: &[$t], input_im: &[$t], output: &mut [$t], planner: &$planner,
                        scratch_re: &mut [$t], scratch_im: &mut [$t]) {
             check(unsafe {
@@ -214,13 +214,13 @@ macro_rules! impl_r2c {
                        scratch_im.len())
             });
         }
-        /// r2c.rs:704 / 809
+        /// r2c.rs:710 / 813
         pub fn $c2r_p(input_re: &[$t], input_im: &[$t], output: &mut [$t], planner: &$planner) {
             let half = planner.n / 2;
             let (mut sre, mut sim) = (vec![0.0 as $t; half], vec![0.0 as $t; half]);
             $c2r_ps(input_re, input_im, output, planner, &mut sre, &mut sim);
         }
-        /// r2c.rs:695 / 800
+        /// r2c.rs:695 / 804
         pub fn $c2r(input_re: &[$t], input_im: &[$t], output: &mut [$t]) {
             let planner = <$planner>::new(output.len());
             $c2r_p(input_re, input_im, output, &planner);
