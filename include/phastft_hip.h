@@ -191,6 +191,9 @@ int phast_planner_dit32_set_plan(phast_planner_dit32 *p, const unsigned *log_row
 /* tuning hook: force the number of resident workgroups per CU the tile passes are launched with (0 = planner's own
  * residency estimate).  Process-wide; for sweeps in tools/ only. */
 void phast_debug_set_wg_per_cu(int wg_per_cu);
+/* debug hook: device buffer of [3 passes][4096 workgroups][16] s_memtime stamps written by the tile kernels while
+ * set (NULL = off; adds drains, so never leave it on while measuring).  tools/trace_tile.py decodes it. */
+void phast_debug_set_trace(unsigned long long *d_trace);
 
 /* ---- measurement hook (bench.py "roofline"): runs `reps` batched forward transforms in place on the given
  * buffers with hipEvents recorded on `stream` around every pass kernel; pass_ms[i] = average duration of pass i

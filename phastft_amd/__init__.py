@@ -178,8 +178,8 @@ class _PlannerDit:
         return cls(num_points, mode)
 
     def __del__(self):
-        if getattr(self, "_h", None) is not None and self._h.value:
-            getattr(_lib.lib(), f"phast_planner_dit{self._sfx}_free")(self._h)
+        if getattr(self, "_h", None) is not None and self._h.value and _lib is not None and _lib._lib is not None:
+            getattr(_lib._lib, f"phast_planner_dit{self._sfx}_free")(self._h)
             self._h = C.c_void_p()
 
     # ---- MI355X-side extras (no reference counterpart) ----
@@ -242,8 +242,8 @@ class _PlannerR2c:
         return cls(n)
 
     def __del__(self):
-        if getattr(self, "_h", None) is not None and self._h.value:
-            getattr(_lib.lib(), f"phast_planner_r2c{self._sfx}_free")(self._h)
+        if getattr(self, "_h", None) is not None and self._h.value and _lib is not None and _lib._lib is not None:
+            getattr(_lib._lib, f"phast_planner_r2c{self._sfx}_free")(self._h)
             self._h = C.c_void_p()
 
 

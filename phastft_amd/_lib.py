@@ -31,7 +31,7 @@ phast_c2r_fft_f64_with_planner_and_scratch phast_c2r_fft_f32_with_planner_and_sc
 phast_c2r_fft_f64_dev phast_c2r_fft_f32_dev
 phast_fill_f64_dev phast_fill_f32_dev phast_digest_f64_dev phast_digest_f32_dev
 phast_planner_dit64_set_plan phast_planner_dit32_set_plan
-phast_planner_dit64_time_passes phast_planner_dit32_time_passes phast_debug_set_wg_per_cu
+phast_planner_dit64_time_passes phast_planner_dit32_time_passes phast_debug_set_wg_per_cu phast_debug_set_trace
 """.split()
 
 
@@ -66,11 +66,10 @@ def lib() -> C.CDLL:
     l.phast_planner_dit64_device_bytes.restype = C.c_size_t
     l.phast_planner_dit32_device_bytes.restype = C.c_size_t
     for name in SYMBOLS:
-        fn = getattr(l, name)  # AttributeError here = header/library mismatch
-        if fn.restype is C.c_int and name not in ("phast_options_default",):
-            pass
+        getattr(l, name)  # AttributeError here = header/library mismatch
     l.phast_options_default.restype = None
     l.phast_debug_set_wg_per_cu.restype = None
+    l.phast_debug_set_trace.restype = None
     for sfx in ("64", "32"):
         getattr(l, f"phast_planner_dit{sfx}_free").restype = None
         getattr(l, f"phast_planner_r2c{sfx}_free").restype = None

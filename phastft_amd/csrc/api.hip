@@ -37,7 +37,8 @@ static int hip_fail(hipError_t e, const char *what) {
     } while (0)
 
 static int g_cus = 0;
-static int g_wg_per_cu_override = 0;  // tuning hook (phast_debug_set_wg_per_cu)
+static int g_wg_per_cu_override = 0;
+static unsigned long long *g_trace = nullptr;  // tuning hook (phast_debug_set_trace)  // tuning hook (phast_debug_set_wg_per_cu)
 static int ensure_device() {
     static std::once_flag once;
     static int status = PHAST_OK;
@@ -85,23 +86,23 @@ struct PassDesc : PassGeom {
 
 template <typename T> struct Types;
 template <> struct Types<double> {
-    static hipError_t launch_a(int lr, int lc, unsigned g, hipStream_t s, const TileArgs &a, bool q, int *b, size_t *l,
-                               hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
-        return launch_tile_f64_a(lr, lc, g, s, a, q, b, l, e0, e1);
+    static hipError_t launch_a(int lr, int lc, bool seq, unsigned g, hipStream_t s, const TileArgs &a, bool q, int *b,
+                               size_t *l, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
+        return launch_tile_f64_a(lr, lc, seq, g, s, a, q, b, l, e0, e1);
     }
-    static hipError_t launch_bc(int lr, int lc, unsigned g, hipStream_t s, const TileArgs &a, bool q, int *b, size_t *l,
-                               hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
-        return launch_tile_f64_bc(lr, lc, g, s, a, q, b, l, e0, e1);
+    static hipError_t launch_bc(int lr, int lc, bool seq, unsigned g, hipStream_t s, const TileArgs &a, bool q, int *b,
+                               size_t *l, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
+        return launch_tile_f64_bc(lr, lc, seq, g, s, a, q, b, l, e0, e1);
     }
 };
 template <> struct Types<float> {
-    static hipError_t launch_a(int lr, int lc, unsigned g, hipStream_t s, const TileArgs &a, bool q, int *b, size_t *l,
-                               hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
-        return launch_tile_f32_a(lr, lc, g, s, a, q, b, l, e0, e1);
+    static hipError_t launch_a(int lr, int lc, bool seq, unsigned g, hipStream_t s, const TileArgs &a, bool q, int *b,
+                               size_t *l, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
+        return launch_tile_f32_a(lr, lc, seq, g, s, a, q, b, l, e0, e1);
     }
-    static hipError_t launch_bc(int lr, int lc, unsigned g, hipStream_t s, const TileArgs &a, bool q, int *b, size_t *l,
-                               hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
-        return launch_tile_f32_bc(lr, lc, g, s, a, q, b, l, e0, e1);
+    static hipError_t launch_bc(int lr, int lc, bool seq, unsigned g, hipStream_t s, const TileArgs &a, bool q, int *b,
+                               size_t *l, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
+        return launch_tile_f32_bc(lr, lc, seq, g, s, a, q, b, l, e0, e1);
     }
 };
 
@@ -173,7 +174,10 @@ template <typename T> struct Planner {
         std::vector<PassGeom> geo;
         if (!make_passes(log_n, lrs, tls, geo)) return PHAST_ERR_INVALID_ARG;
         std::vector<PassDesc> ps(geo.size());
-        for (size_t i = 0; i < geo.size(); ++i) static_cast<PassGeom &>(ps[i]) = geo[i];
+        for (size_t i = 0; i < geo.size(); ++i) {
+            static_cast<PassGeom &>(ps[i]) = geo[i];
+            ps[i].plane_seq = which != 2;  // latency plan: one workgroup per CU, LDS is free -> half the barriers
+        }
         size_t tb = 0;
         for (size_t i = 0; i < ps.size(); ++i) {
             int rc = upload<T>(host_twr<T>(1u << ps[i].lr), &ps[i].d_twr);
@@ -186,8 +190,8 @@ template <typename T> struct Planner {
                 TileArgs ta{};
                 ta.tw_bits = ps[i].tw_bits;
                 hipError_t e = ps[i].transpose
-                                   ? Types<T>::launch_a(ps[i].lr, ps[i].lc, 0, nullptr, ta, true, &ps[i].blocks_per_cu, &ps[i].lds)
-                                   : Types<T>::launch_bc(ps[i].lr, ps[i].lc, 0, nullptr, ta, true, &ps[i].blocks_per_cu, &ps[i].lds);
+                                   ? Types<T>::launch_a(ps[i].lr, ps[i].lc, ps[i].plane_seq, 0, nullptr, ta, true, &ps[i].blocks_per_cu, &ps[i].lds)
+                                   : Types<T>::launch_bc(ps[i].lr, ps[i].lc, ps[i].plane_seq, 0, nullptr, ta, true, &ps[i].blocks_per_cu, &ps[i].lds);
                 if (e != hipSuccess) rc = hip_fail(e, "occupancy query");
                 if (ps[i].blocks_per_cu < 1) ps[i].blocks_per_cu = 1;
                 if (rc == PHAST_OK && ps[i].lds > 160 * 1024) rc = PHAST_ERR_INVALID_ARG;  // tile does not fit one CU's LDS
@@ -350,6 +354,7 @@ template <typename T> struct Planner {
                 }
                 ta.tw3 = p.d_tw3;
                 ta.twr = p.d_twr;
+                ta.trace = g_trace ? g_trace + (size_t)i * 16 * 4096 : nullptr;
                 if (((unsigned long long)nb << (log_n - p.lr - p.lc)) > 0xffffffffull) return PHAST_ERR_INVALID_ARG;
                 geom_to_args(p, log_n, nb, ta);
                 unsigned grid = (unsigned)(g_wg_per_cu_override > 0 ? g_wg_per_cu_override : p.blocks_per_cu) * (unsigned)g_cus;
@@ -357,8 +362,8 @@ template <typename T> struct Planner {
                 if (grid >= 8) grid &= ~7u;  // keep tile%8 == workgroup%8 (XCD affinity of the tile order)
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (timer) PHAST_HIP(timer->pair((int)i, &e0, &e1));
-                hipError_t e = p.transpose ? Types<T>::launch_a(p.lr, p.lc, grid, stream, ta, false, nullptr, nullptr, e0, e1)
-                                           : Types<T>::launch_bc(p.lr, p.lc, grid, stream, ta, false, nullptr, nullptr, e0, e1);
+                hipError_t e = p.transpose ? Types<T>::launch_a(p.lr, p.lc, p.plane_seq, grid, stream, ta, false, nullptr, nullptr, e0, e1)
+                                           : Types<T>::launch_bc(p.lr, p.lc, p.plane_seq, grid, stream, ta, false, nullptr, nullptr, e0, e1);
                 if (e != hipSuccess) return hip_fail(e, "tile_fft launch");
             }
         }
@@ -706,6 +711,7 @@ const char *phast_strerror(int code) {
 const char *phast_last_hip_error(void) { return g_hip_err; }
 
 void phast_debug_set_wg_per_cu(int wg_per_cu) { g_wg_per_cu_override = wg_per_cu; }
+void phast_debug_set_trace(unsigned long long *d_trace) { g_trace = d_trace; }
 
 int phast_device_info(char *name, size_t name_len, int *compute_units, size_t *lds_per_block,
                       size_t *global_mem_bytes) {

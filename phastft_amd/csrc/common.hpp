@@ -93,6 +93,7 @@ struct TileArgs {
     unsigned out_interleaved;  // 1: output is one array of (re, im) pairs (C2R interleave fused into the store);
                                // 2: pairs stored as (im, re) -- the swap-trick inverse (algorithms/dit.rs:297-300)
     double scale;              // 1/N on the last pass of an inverse transform, else 1
+    unsigned long long *trace; // tools/trace_tile.py only: [workgroup][16] s_memtime stamps of the first tile's phases
 };
 
 }  // namespace phast

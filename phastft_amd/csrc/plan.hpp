@@ -109,6 +109,7 @@ inline bool shape_exists(unsigned lr, unsigned lc) {
 struct PassGeom {
     unsigned lr = 0, lc = 0;
     bool pre_tw = false, transpose = false;
+    bool plane_seq = true;  // f64: exchange re/im planes sequentially (false only for 4096-point latency tiles)
     unsigned log_s_in = 0, out_lo_bits = 0, tw_bits = 1;
     unsigned long long out_s1 = 0, out_s2 = 0, out_row_stride = 0;
     unsigned log_mod() const { return lr + log_s_in; }  // the inter-pass twiddle is W_{2^log_mod}^{row*lo}
@@ -130,21 +131,22 @@ inline void heuristic_plan(unsigned L, bool latency, std::vector<unsigned> &lrs,
         lrs.clear();
         for (unsigned i = 0; i < np; ++i) lrs.push_back(L / np + (i < L % np ? 1 : 0));  // balanced, larger first
     };
-    if (latency) {
+    const bool f64 = sizeof(T) == 8;
+    if (latency && (f64 || L <= 16)) {
         split(L <= 20 ? 2 : 3);
         tls.assign(1, lrs[0] <= 10 ? 12 : 13);
         return;
     }
-    const unsigned wide = sizeof(T) == 8 ? 9 : 8;  // largest LR whose 8192-point tile keeps >= 128-byte rows
-    if (L <= 14) {
+    if (L <= 14) {  // 128 x 32 tiles and smaller: rows >= 128 B in both types
         split(2);
         tls.assign(1, 12);
-    } else if (L <= 2 * wide || L <= 20) {
+    } else if (L <= 17 || (f64 && L <= 20)) {  // (three passes need L >= 18: tile FFTs are at least 64 long)
         split(2);
         tls.assign(1, 13);
     } else {
         split(3);
-        tls.assign(1, lrs[0] <= 7 ? 12 : 13);
+        // measured (profiles/r01_sweep_*): f64 wants 8192-point tiles from LR = 8 up, f32 only from LR = 9 up
+        tls.assign(1, lrs[0] <= (f64 ? 7u : 8u) ? 12 : 13);
     }
 }
 

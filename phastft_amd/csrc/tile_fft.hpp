@@ -84,7 +84,7 @@ template <typename T, int R, int OFF> PHAST_HD void fft_reg_dif(T (&re)[16], T (
     });
 }
 
-template <typename T, int LR, int LC, bool PRE_TW, bool TRANSPOSE> struct TileBody {
+template <typename T, int LR, int LC, bool PRE_TW, bool TRANSPOSE, bool SEQ> struct TileBody {
     using cx = cx_t<T>;
     static constexpr int ROWS = 1 << LR;
     static constexpr int COLS = 1 << LC;
@@ -94,7 +94,7 @@ template <typename T, int LR, int LC, bool PRE_TW, bool TRANSPOSE> struct TileBo
     static constexpr bool THREE = LR > 8;        // 16 x 16 x R3, else 16 x R2
     static constexpr int R2 = THREE ? 16 : M;
     static constexpr int R3 = THREE ? M / 16 : 1;
-    static constexpr bool PLANE_SEQ = sizeof(T) == 8;  // exchange re and im one after the other (half the LDS)
+    static constexpr bool PLANE_SEQ = SEQ;  // exchange re and im one after the other (half the LDS, twice the barriers)
     static constexpr int CS = ROWS + G;                // padded column stride of the transposing exchange
     static constexpr int E1S = 16 + (G > 1 ? 1 : 0);   // rows per n' in exchange 1 (16 used + padding)
     static constexpr int EXCH_E1 = M * E1S * COLS;
@@ -139,7 +139,7 @@ template <typename T, int LR, int LC, bool PRE_TW, bool TRANSPOSE> struct TileBo
     // Addresses are (wave-uniform 64-bit base) + (32-bit per-lane element offset): the tile's columns share
     // the high part of in_col (tiles are COLS-aligned and COLS <= 2^log_s_in), the row n1*M is uniform, and
     // only tau*2^log_s_in + col differs between lanes -- one VGPR for all 16 loads (saddr addressing).
-    PHAST_HD static void load(const TileArgs &a, const Shared &sh, int tid, Regs &r) {
+    PHAST_HD static void load_raw(const TileArgs &a, int tid, Regs &r) {
         const int col = col_of(tid), tau = tau_of(tid);
         const unsigned lo0 = r.g0 & ((1u << a.log_s_in) - 1u);
         const size_t ubase = (size_t)r.xform * a.in_dist + (((size_t)(r.g0 >> a.log_s_in) << (a.log_s_in + LR)) | lo0);
@@ -161,7 +161,12 @@ template <typename T, int LR, int LC, bool PRE_TW, bool TRANSPOSE> struct TileBo
                 r.im[n1] = v.y;
             });
         }
+    }
+    // inter-pass twiddle W_{ROWS*S}^{row*lo} on the freshly loaded rows (needs the LDS tables)
+    PHAST_HD static void pre_twiddle(const TileArgs &a, const Shared &sh, int tid, Regs &r) {
         if constexpr (PRE_TW) {
+            const int col = col_of(tid), tau = tau_of(tid);
+            const unsigned lo0 = r.g0 & ((1u << a.log_s_in) - 1u);
             const unsigned lo = lo0 + (unsigned)col;
             const unsigned e0 = (unsigned)tau * lo, de = (unsigned)M * lo;  // exponent of row n1*M + tau: e0 + n1*de
             static_for<0, 16>([&](auto n1) {
@@ -319,9 +324,9 @@ template <typename T, int LR, int LC, bool PRE_TW, bool TRANSPOSE> struct TileBo
     }
 };
 
-template <typename T, int LR, int LC, bool PRE_TW, bool TRANSPOSE>
+template <typename T, int LR, int LC, bool PRE_TW, bool TRANSPOSE, bool SEQ>
 __global__ void __launch_bounds__(1 << (LR + LC - 4)) tile_fft_kernel(const TileArgs a) {
-    using Body = TileBody<T, LR, LC, PRE_TW, TRANSPOSE>;
+    using Body = TileBody<T, LR, LC, PRE_TW, TRANSPOSE, SEQ>;
     using cx = cx_t<T>;
     constexpr int NT = Body::NT;
 
@@ -332,10 +337,29 @@ __global__ void __launch_bounds__(1 << (LR + LC - 4)) tile_fft_kernel(const Tile
     const typename Body::Shared sh{ex_re, Body::PLANE_SEQ ? ex_re : ex_re + Body::EXCH, l_tw3, l_twr};
 
     const int tid = threadIdx.x;
+    // phase stamps (debug): drains outstanding memory ops first so that a stamp means "everything before is done"
+    int stamp_i = 0;
+    auto stamp = [&]() {
+        if (a.trace != nullptr) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            if (tid == 0 && stamp_i < 16) a.trace[(size_t)blockIdx.x * 16 + stamp_i] = now;
+            ++stamp_i;
+        }
+    };
+    stamp();  // 0: kernel entry
+    // the first tile's global loads are issued before the table loads so the two latencies overlap
+    typename Body::Regs r;
+    unsigned t = blockIdx.x;
+    if (t < a.tiles_total) {
+        Body::locate(a, t, r);
+        Body::load_raw(a, tid, r);
+    }
     for (int i = tid; i < 64; i += NT) l_twr[i] = reinterpret_cast<const cx *>(a.twr)[i];
     if constexpr (PRE_TW)
         for (unsigned i = tid; i < (3u << a.tw_bits); i += NT) l_tw3[i] = reinterpret_cast<const cx *>(a.tw3)[i];
     __syncthreads();
+    stamp();  // 1: twiddle tables in LDS
 
     // one exchange: barrier (previous readers done), write, barrier, read -- per plane when PLANE_SEQ
     auto exchange = [&](auto e, typename Body::Regs &r) {
@@ -357,28 +381,41 @@ __global__ void __launch_bounds__(1 << (LR + LC - 4)) tile_fft_kernel(const Tile
         }
     };
 
-    for (unsigned t = blockIdx.x; t < a.tiles_total; t += gridDim.x) {
-        typename Body::Regs r;
-        Body::locate(a, t, r);
-        Body::load(a, sh, tid, r);
+    while (t < a.tiles_total) {
+        Body::pre_twiddle(a, sh, tid, r);
+        stamp();  // 2: tile loaded (+ pre-twiddle)
         Body::step1(sh, tid, r);
+        stamp();  // 3
         exchange(std::integral_constant<int, 1>{}, r);
+        stamp();  // 4
         Body::step2(sh, tid, r);
+        stamp();  // 5
         if constexpr (Body::THREE) {
             exchange(std::integral_constant<int, 2>{}, r);
+            stamp();  // 6
             Body::step3(r);
+            stamp();  // 7
         }
-        if constexpr (TRANSPOSE) exchange(std::integral_constant<int, 3>{}, r);
+        if constexpr (TRANSPOSE) {
+            exchange(std::integral_constant<int, 3>{}, r);
+            stamp();  // 6 or 8
+        }
         Body::store(a, tid, r);
+        stamp();  // last: stores retired
+        t += gridDim.x;
+        if (t < a.tiles_total) {  // next tile's loads go out right behind the stores
+            Body::locate(a, t, r);
+            Body::load_raw(a, tid, r);
+        }
     }
 }
 
 // host-side launcher for one (T, LR, LC, mode) instantiation
-template <typename T, int LR, int LC, bool PRE_TW, bool TRANSPOSE>
+template <typename T, int LR, int LC, bool PRE_TW, bool TRANSPOSE, bool SEQ>
 hipError_t launch_tile_inst(unsigned grid, hipStream_t stream, const TileArgs &a, bool query_only, int *blocks_per_cu,
                             size_t *lds_out, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
-    using Body = TileBody<T, LR, LC, PRE_TW, TRANSPOSE>;
-    auto kern = tile_fft_kernel<T, LR, LC, PRE_TW, TRANSPOSE>;
+    using Body = TileBody<T, LR, LC, PRE_TW, TRANSPOSE, SEQ>;
+    auto kern = tile_fft_kernel<T, LR, LC, PRE_TW, TRANSPOSE, SEQ>;
     const size_t lds = Body::lds_bytes(a.tw_bits);
     if (lds_out) *lds_out = lds;
     // raise the dynamic-LDS limit only when it grows: the steady state issues no runtime call besides the
@@ -418,8 +455,8 @@ hipError_t launch_tile_inst(unsigned grid, hipStream_t stream, const TileArgs &a
 
 // Thread-by-thread host execution of one pass: the same TileBody phases, barriers replaced by
 // "every thread finishes the phase".  Test infrastructure for the GPU-less build container.
-template <typename T, int LR, int LC, bool PRE_TW, bool TRANSPOSE> void emulate_tile_pass(const TileArgs &a) {
-    using Body = TileBody<T, LR, LC, PRE_TW, TRANSPOSE>;
+template <typename T, int LR, int LC, bool PRE_TW, bool TRANSPOSE, bool SEQ> void emulate_tile_pass(const TileArgs &a) {
+    using Body = TileBody<T, LR, LC, PRE_TW, TRANSPOSE, SEQ>;
     using Regs = typename Body::Regs;
     constexpr int NT = Body::NT;
     T *ex = new T[(size_t)Body::EXCH * 2];
@@ -447,7 +484,8 @@ template <typename T, int LR, int LC, bool PRE_TW, bool TRANSPOSE> void emulate_
     for (unsigned tile = 0; tile < a.tiles_total; ++tile) {
         for (int t = 0; t < NT; ++t) {
             Body::locate(a, tile, regs[t]);
-            Body::load(a, sh, t, regs[t]);
+            Body::load_raw(a, t, regs[t]);
+            Body::pre_twiddle(a, sh, t, regs[t]);
             Body::step1(sh, t, regs[t]);
         }
         exchange(std::integral_constant<int, 1>{});
