@@ -117,6 +117,25 @@ int phast_fft_64_dit_dev(double *d_reals, double *d_imags, size_t n, size_t batc
 int phast_fft_32_dit_dev(float *d_reals, float *d_imags, size_t n, size_t batch, size_t dist, int direction,
                          const phast_planner_dit32 *planner, void *stream);
 
+/* ---- C2C on interleaved Complex<T> signals: lib.rs:41-140 (feature `complex-nums`) ----
+ * `signal` holds n complex numbers as (re, im) pairs, transformed in place.  The reference copies into two planar
+ * Vecs, runs the planar path and copies back (lib.rs:56-58); here the (de)interleave is fused into the first
+ * pass's load and the last pass's store.  `dist` of the _dev form counts complex elements. */
+int phast_fft_64_interleaved(double *signal, size_t n, int direction);                               /* lib.rs:120 */
+int phast_fft_32_interleaved(float *signal, size_t n, int direction);
+int phast_fft_64_interleaved_with_planner(double *signal, size_t n, int direction,
+                                          const phast_planner_dit64 *planner);                       /* lib.rs:87 */
+int phast_fft_32_interleaved_with_planner(float *signal, size_t n, int direction, const phast_planner_dit32 *planner);
+int phast_fft_64_interleaved_with_planner_and_opts(double *signal, size_t n, int direction,
+                                                   const phast_planner_dit64 *planner,
+                                                   const phast_options *opts);                        /* lib.rs:50 */
+int phast_fft_32_interleaved_with_planner_and_opts(float *signal, size_t n, int direction,
+                                                   const phast_planner_dit32 *planner, const phast_options *opts);
+int phast_fft_64_interleaved_dev(double *d_signal, size_t n, size_t batch, size_t dist, int direction,
+                                 const phast_planner_dit64 *planner, void *stream);
+int phast_fft_32_interleaved_dev(float *d_signal, size_t n, size_t batch, size_t dist, int direction,
+                                 const phast_planner_dit32 *planner, void *stream);
+
 /* ---- bit reversal: algorithms/bravo.rs:303,317 (public with feature bench-internals, lib.rs:20-23) ---- */
 int phast_bit_rev_f64(double *data, size_t len, unsigned log_n); /* host slice */
 int phast_bit_rev_f32(float *data, size_t len, unsigned log_n);

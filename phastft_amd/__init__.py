@@ -44,6 +44,8 @@ __all__ = [
     "r2c_fft_f64", "r2c_fft_f32", "r2c_fft_f64_with_planner", "r2c_fft_f32_with_planner",
     "c2r_fft_f64", "c2r_fft_f32", "c2r_fft_f64_with_planner", "c2r_fft_f32_with_planner",
     "c2r_fft_f64_with_planner_and_scratch", "c2r_fft_f32_with_planner_and_scratch",
+    "fft_64_interleaved", "fft_32_interleaved", "fft_64_interleaved_with_planner", "fft_32_interleaved_with_planner",
+    "fft_64_interleaved_with_planner_and_opts", "fft_32_interleaved_with_planner_and_opts",
     "bit_rev_bravo_f64", "bit_rev_bravo_f32", "fft_dit_batched", "fill_uniform", "digest", "device_info",
 ]
 
@@ -316,6 +318,70 @@ def fft_64_dit_with_planner_and_opts(reals, imags, direction: Direction, planner
 def fft_32_dit_with_planner_and_opts(reals, imags, direction: Direction, planner: PlannerDit32, opts: Options) -> None:
     """algorithms/dit.rs:338"""
     _fft("32", np.float32, reals, imags, direction, planner, opts, True)
+
+
+# ---------------------------------------------------------------------------------------------
+# interleaved Complex<T> signals  (lib.rs:41-140, feature `complex-nums`)
+# ---------------------------------------------------------------------------------------------
+def _fft_interleaved(sfx, cdtype, signal, direction, planner=None, opts=None, need_opts=False):
+    l = _lib.lib()
+    fdtype = np.float64 if sfx == "64" else np.float32
+    if _is_torch(signal):
+        import torch
+
+        want = torch.complex128 if sfx == "64" else torch.complex64
+        if signal.dtype != want or signal.dim() != 1 or not signal.is_contiguous() or signal.device.type != "cuda":
+            raise TypeError(f"signal: need a contiguous 1-D {want} cuda tensor")
+        n = signal.numel()
+        own = planner is None
+        if own:
+            planner = (PlannerDit64 if sfx == "64" else PlannerDit32)(n)
+        _check(getattr(l, f"phast_fft_{sfx}_interleaved_dev")(C.c_void_p(signal.data_ptr()), C.c_size_t(n), C.c_size_t(1),
+                                                              C.c_size_t(n), C.c_int(int(direction)), planner._h,
+                                                              _stream()))
+        if own:
+            torch.cuda.current_stream().synchronize()
+        return
+    if not (isinstance(signal, np.ndarray) and signal.dtype == cdtype and signal.ndim == 1 and signal.flags.c_contiguous):
+        raise TypeError(f"signal: need a contiguous 1-D {np.dtype(cdtype).name} ndarray or a cuda tensor")
+    flat = signal.view(fdtype)
+    args = [flat.ctypes.data_as(C.c_void_p), C.c_size_t(signal.size), C.c_int(int(direction))]
+    if planner is None:
+        _check(getattr(l, f"phast_fft_{sfx}_interleaved")(*args))
+    elif need_opts:
+        _check(getattr(l, f"phast_fft_{sfx}_interleaved_with_planner_and_opts")(*args, planner._h, C.byref(opts._c())))
+    else:
+        _check(getattr(l, f"phast_fft_{sfx}_interleaved_with_planner")(*args, planner._h))
+
+
+def fft_64_interleaved(signal, direction: Direction) -> None:
+    """lib.rs:120 (macro impl_fft_interleaved)"""
+    _fft_interleaved("64", np.complex128, signal, direction)
+
+
+def fft_32_interleaved(signal, direction: Direction) -> None:
+    """lib.rs:120"""
+    _fft_interleaved("32", np.complex64, signal, direction)
+
+
+def fft_64_interleaved_with_planner(signal, direction: Direction, planner: PlannerDit64) -> None:
+    """lib.rs:87"""
+    _fft_interleaved("64", np.complex128, signal, direction, planner)
+
+
+def fft_32_interleaved_with_planner(signal, direction: Direction, planner: PlannerDit32) -> None:
+    """lib.rs:87"""
+    _fft_interleaved("32", np.complex64, signal, direction, planner)
+
+
+def fft_64_interleaved_with_planner_and_opts(signal, direction: Direction, planner: PlannerDit64, opts: Options) -> None:
+    """lib.rs:50"""
+    _fft_interleaved("64", np.complex128, signal, direction, planner, opts, True)
+
+
+def fft_32_interleaved_with_planner_and_opts(signal, direction: Direction, planner: PlannerDit32, opts: Options) -> None:
+    """lib.rs:50"""
+    _fft_interleaved("32", np.complex64, signal, direction, planner, opts, True)
 
 
 def fft_dit_batched(reals, imags, n: int, direction: Direction, planner) -> None:

@@ -23,6 +23,9 @@ phast_planner_r2c64_new phast_planner_r2c64_free phast_planner_r2c32_new phast_p
 phast_fft_64_dit phast_fft_32_dit phast_fft_64_dit_with_planner phast_fft_32_dit_with_planner
 phast_fft_64_dit_with_planner_and_opts phast_fft_32_dit_with_planner_and_opts
 phast_fft_64_dit_dev phast_fft_32_dit_dev
+phast_fft_64_interleaved phast_fft_32_interleaved phast_fft_64_interleaved_with_planner
+phast_fft_32_interleaved_with_planner phast_fft_64_interleaved_with_planner_and_opts
+phast_fft_32_interleaved_with_planner_and_opts phast_fft_64_interleaved_dev phast_fft_32_interleaved_dev
 phast_bit_rev_f64 phast_bit_rev_f32 phast_bit_rev_f64_dev phast_bit_rev_f32_dev
 phast_r2c_fft_f64 phast_r2c_fft_f32 phast_r2c_fft_f64_with_planner phast_r2c_fft_f32_with_planner
 phast_r2c_fft_f64_dev phast_r2c_fft_f32_dev

@@ -538,6 +538,21 @@ static int time_passes(const Planner<T> *pl, T *d_re, T *d_im, size_t batch, siz
     return PHAST_OK;
 }
 
+// lib.rs:41-140 (feature complex-nums): interleaved Complex<T> signal, in place.  The reference copies into two
+// planar Vecs and back; here the (de)interleave is the first pass's load and the last pass's store.
+template <typename T>
+static int fft_interleaved_dev(T *d_signal, size_t n, size_t batch, size_t dist, int direction, const Planner<T> *pl,
+                               hipStream_t s) {
+    if (!pl || !d_signal) return PHAST_ERR_INVALID_ARG;
+    if (direction != PHAST_FORWARD && direction != PHAST_REVERSE) return PHAST_ERR_INVALID_ARG;
+    if (!is_pow2(n)) return PHAST_ERR_NOT_POW2;
+    if (ilog2(n) != pl->log_n) return PHAST_ERR_PLANNER_SIZE;
+    if (batch > 1 && dist < n) return PHAST_ERR_INVALID_ARG;
+    if (direction == PHAST_REVERSE)  // swap trick: read (im, re), transform, store (im, re) scaled by 1/N
+        return pl->exec(d_signal, nullptr, dist, 2, d_signal, nullptr, dist, 2, batch, 1.0 / (double)n, s);
+    return pl->exec(d_signal, nullptr, dist, 1, d_signal, nullptr, dist, 1, batch, 1.0, s);
+}
+
 struct DevBuf {
     void *p = nullptr;
     ~DevBuf() {
@@ -569,6 +584,21 @@ static int fft_host(T *re, size_t re_len, T *im, size_t im_len, int direction, c
     PHAST_HIP(hipStreamSynchronize(nullptr));
     PHAST_HIP(hipMemcpy(re, d_re, bytes, hipMemcpyDeviceToHost));
     PHAST_HIP(hipMemcpy(im, d_im, bytes, hipMemcpyDeviceToHost));
+    return PHAST_OK;
+}
+
+template <typename T> static int fft_interleaved_host(T *signal, size_t n, int direction, const Planner<T> *pl) {
+    if (!pl || (!signal && n)) return PHAST_ERR_INVALID_ARG;
+    if (!is_pow2(n)) return PHAST_ERR_NOT_POW2;
+    if (ilog2(n) != pl->log_n) return PHAST_ERR_PLANNER_SIZE;
+    DevBuf buf;
+    int rc = buf.alloc(2 * n * sizeof(T));
+    if (rc) return rc;
+    PHAST_HIP(hipMemcpy(buf.p, signal, 2 * n * sizeof(T), hipMemcpyHostToDevice));
+    rc = fft_interleaved_dev<T>(reinterpret_cast<T *>(buf.p), n, 1, n, direction, pl, nullptr);
+    if (rc) return rc;
+    PHAST_HIP(hipStreamSynchronize(nullptr));
+    PHAST_HIP(hipMemcpy(signal, buf.p, 2 * n * sizeof(T), hipMemcpyDeviceToHost));
     return PHAST_OK;
 }
 
@@ -796,6 +826,28 @@ PHAST_PLANNER_API(32, float)
     int phast_fft_##SFX##_dit_dev(T *d_re, T *d_im, size_t n, size_t batch, size_t dist, int direction,             \
                                   const phast_planner_dit##SFX *pl, void *stream) {                                 \
         return fft_dev<T>(d_re, d_im, n, batch, dist, direction, pl, static_cast<hipStream_t>(stream));             \
+    }                                                                                                               \
+    int phast_fft_##SFX##_interleaved(T *signal, size_t n, int direction) {                                         \
+        Planner<T> *pl = nullptr;                                                                                   \
+        int rc = planner_new(n, &pl); /* lib.rs:121 */                                                              \
+        if (rc) return rc;                                                                                          \
+        rc = fft_interleaved_host<T>(signal, n, direction, pl);                                                     \
+        delete pl;                                                                                                  \
+        return rc;                                                                                                  \
+    }                                                                                                               \
+    int phast_fft_##SFX##_interleaved_with_planner(T *signal, size_t n, int direction,                              \
+                                                   const phast_planner_dit##SFX *pl) {                              \
+        return fft_interleaved_host<T>(signal, n, direction, pl);                                                   \
+    }                                                                                                               \
+    int phast_fft_##SFX##_interleaved_with_planner_and_opts(T *signal, size_t n, int direction,                     \
+                                                            const phast_planner_dit##SFX *pl,                       \
+                                                            const phast_options *opts) {                            \
+        if (!opts) return PHAST_ERR_INVALID_ARG;                                                                    \
+        return fft_interleaved_host<T>(signal, n, direction, pl);                                                   \
+    }                                                                                                               \
+    int phast_fft_##SFX##_interleaved_dev(T *d_signal, size_t n, size_t batch, size_t dist, int direction,          \
+                                          const phast_planner_dit##SFX *pl, void *stream) {                         \
+        return fft_interleaved_dev<T>(d_signal, n, batch, dist, direction, pl, static_cast<hipStream_t>(stream));   \
     }                                                                                                               \
     int phast_bit_rev_##FS(T *data, size_t len, unsigned log_n) { return bitrev_host<T>(data, len, log_n); }        \
     int phast_bit_rev_##FS##_dev(T *d, unsigned log_n, size_t batch, size_t dist, void *stream) {                   \

@@ -89,7 +89,7 @@ struct TileArgs {
     unsigned log_s_in;
     unsigned out_lo_bits;
     unsigned tw_bits;
-    unsigned in_interleaved;   // input is one array of (re, im) pairs (R2C deinterleave fused into the load)
+    unsigned in_interleaved;   // 1: input is one array of (re, im) pairs (R2C deinterleave fused into the load); 2: read as (im, re)
     unsigned out_interleaved;  // 1: output is one array of (re, im) pairs (C2R interleave fused into the store);
                                // 2: pairs stored as (im, re) -- the swap-trick inverse (algorithms/dit.rs:297-300)
     double scale;              // 1/N on the last pass of an inverse transform, else 1

@@ -25,8 +25,8 @@ template <typename T> __global__ void __launch_bounds__(256) small_fft_kernel(co
             const unsigned j = a.log_n ? (__brev(i) >> (32u - a.log_n)) : 0u;
             if (a.in_interleaved) {
                 cx v = reinterpret_cast<const cx *>(a.in_re)[(size_t)xf * a.in_dist + i];
-                s_re[j] = v.x;
-                s_im[j] = v.y;
+                s_re[j] = a.in_interleaved == 2 ? v.y : v.x;
+                s_im[j] = a.in_interleaved == 2 ? v.x : v.y;
             } else {
                 s_re[j] = reinterpret_cast<const T *>(a.in_re)[(size_t)xf * a.in_dist + i];
                 s_im[j] = reinterpret_cast<const T *>(a.in_im)[(size_t)xf * a.in_dist + i];

@@ -157,8 +157,8 @@ template <typename T, int LR, int LC, bool PRE_TW, bool TRANSPOSE, bool SEQ> str
             static_for<0, 16>([&](auto n1) {
                 const size_t urow = (size_t)(decltype(n1)::value * M) << a.log_s_in;
                 cx v = (pz + urow)[voff];
-                r.re[n1] = v.x;
-                r.im[n1] = v.y;
+                r.re[n1] = a.in_interleaved == 2 ? v.y : v.x;
+                r.im[n1] = a.in_interleaved == 2 ? v.x : v.y;
             });
         }
     }

@@ -342,3 +342,28 @@ def test_determinism_across_entry_points(gpu):
     d1, d2 = dev(x.copy()), dev(x.copy())
     gpu.fft_64_dit(d1, d2, gpu.Direction.Forward)  # device path == host path
     assert np.array_equal(d1.cpu().numpy(), re1) and np.array_equal(d2.cpu().numpy(), im1)
+
+
+# ---------------------------------------------------------------- interleaved Complex<T> API (lib.rs:41-140, 340-378)
+def test_interleaved_matches_planar(gpu):
+    """fft_interleaved_correctness (lib.rs:340-378): interleaved == planar at 1e-10, plus inverse and device tensors."""
+    import torch
+
+    rng = np.random.default_rng(12)
+    for k, cdt, fdt, fwd, planar, tol in ((10, np.complex128, np.float64, gpu.fft_64_interleaved, gpu.fft_64_dit, 1e-10),
+                                          (10, np.complex64, np.float32, gpu.fft_32_interleaved, gpu.fft_32_dit, 1e-4),
+                                          (16, np.complex128, np.float64, gpu.fft_64_interleaved, gpu.fft_64_dit, 1e-9),
+                                          (21, np.complex128, np.float64, gpu.fft_64_interleaved, gpu.fft_64_dit, 1e-8)):
+        n = 1 << k
+        sig = (np.arange(1, n + 1) + 0j).astype(cdt) if k == 10 else (rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n)).astype(cdt)
+        re, im = sig.real.astype(fdt).copy(), sig.imag.astype(fdt).copy()
+        orig = sig.copy()
+        fwd(sig, gpu.Direction.Forward)
+        planar(re, im, gpu.Direction.Forward)
+        scale = max(1.0, float(np.max(np.abs(re))))
+        assert np.max(np.abs(sig.real - re)) < tol * scale and np.max(np.abs(sig.imag - im)) < tol * scale, k
+        d = torch.from_numpy(orig.copy()).cuda()
+        fwd(d, gpu.Direction.Forward)
+        assert np.array_equal(d.cpu().numpy(), sig)  # device path == host path, bit for bit
+        fwd(sig, gpu.Direction.Reverse)
+        assert np.max(np.abs(sig - orig)) < (1e-9 if fdt == np.float64 else 1e-3) * max(1.0, float(np.max(np.abs(orig)))), k
