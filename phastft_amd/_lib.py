@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libphastft_hip.so")
+LIB_PATH = os.environ.get("PHASTFT_HIP_LIB") or os.path.join(_HERE, "lib", "libphastft_hip.so")
 
 # every symbol include/phastft_hip.h declares (tests/test_abi.py checks this list against the header)
 SYMBOLS = """

@@ -45,11 +45,11 @@ def _stale(target: str, sources: list[str]) -> bool:
     return any(os.path.getmtime(s) > t for s in sources)
 
 
-def _compile(unit: str, force: bool) -> str:
+def _compile(unit: str, force: bool, trace: bool = False, extra: tuple = (), tag: str = "") -> str:
     src = os.path.join(SRC, unit + ".hip")
-    obj = os.path.join(OBJ, unit + ".o")
+    obj = os.path.join(OBJ, unit + ("_trace" if trace else "") + tag + ".o")
     if force or _stale(obj, [src] + _deps()):
-        cmd = [hipcc(), *FLAGS, "-I", INCLUDE, "-c", src, "-o", obj]
+        cmd = [hipcc(), *FLAGS, *(["-DPHAST_TRACE"] if trace else []), *extra, "-I", INCLUDE, "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {unit}:\n{r.stdout}\n{r.stderr}")
@@ -72,26 +72,31 @@ def build_emulator(force: bool = False) -> str:
     return EMU_LIB
 
 
-def build(force: bool = False, jobs: int | None = None, verbose: bool = False) -> str:
+def build(force: bool = False, jobs: int | None = None, verbose: bool = False, trace: bool = False,
+          extra: tuple = (), tag: str = "") -> str:
+    """trace=True builds lib/libphastft_hip_trace.so with per-phase s_memtime stamps (tools/trace_tile.py;
+    load it with PHASTFT_HIP_LIB=...); the product library never carries them."""
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIB_DIR, exist_ok=True)
     jobs = jobs or min(len(UNITS), os.cpu_count() or 4)
+    lib = LIB.replace(".so", ("_trace" if trace else "") + tag + ".so")  # tag/extra: experimental variants (tools/)
     with cf.ThreadPoolExecutor(jobs) as ex:
-        objs = list(ex.map(lambda u: _compile(u, force), UNITS))
-    if force or _stale(LIB, objs):
-        cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+        objs = list(ex.map(lambda u: _compile(u, force, trace, extra, tag), UNITS))
+    if force or _stale(lib, objs):
+        cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
     if verbose:
-        print(LIB)
-    return LIB
+        print(lib)
+    return lib
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--jobs", type=int, default=None)
+    ap.add_argument("--trace", action="store_true")
     a = ap.parse_args()
-    build(a.force, a.jobs, verbose=True)
+    build(a.force, a.jobs, verbose=True, trace=a.trace)
     sys.exit(0)

@@ -100,6 +100,10 @@ template <typename T, int LR, int LC, bool PRE_TW, bool TRANSPOSE, bool SEQ> str
     static constexpr int EXCH_E1 = M * E1S * COLS;
     static constexpr int EXCH_E3 = TRANSPOSE ? COLS * CS : 0;
     static constexpr int EXCH = EXCH_E1 > EXCH_E3 ? EXCH_E1 : EXCH_E3;
+    // Non-temporal global accesses when a tile row is a whole 128-byte line or more: every byte is touched once
+    // per pass, and the strided-copy microbenchmark gains 5-10 % (profiles/r01_strided_copy_nt.log).  Narrower
+    // rows share their line with the neighbouring tile and NEED the L2 (nt loads cost 25 % there).
+    static constexpr bool NT_HINT = COLS * sizeof(T) >= 128;
     static_assert(LR >= 6 && LR <= 10, "tile FFT length 64..1024");
     static_assert(NT <= 1024, "at most 1024 threads per workgroup");
 
@@ -149,8 +153,13 @@ template <typename T, int LR, int LC, bool PRE_TW, bool TRANSPOSE, bool SEQ> str
             const T *pi = reinterpret_cast<const T *>(a.in_im) + ubase;
             static_for<0, 16>([&](auto n1) {
                 const size_t urow = (size_t)(decltype(n1)::value * M) << a.log_s_in;
-                r.re[n1] = (pr + urow)[voff];
-                r.im[n1] = (pi + urow)[voff];
+                if constexpr (NT_HINT) {
+                    r.re[n1] = __builtin_nontemporal_load(pr + urow + voff);
+                    r.im[n1] = __builtin_nontemporal_load(pi + urow + voff);
+                } else {
+                    r.re[n1] = (pr + urow)[voff];
+                    r.im[n1] = (pi + urow)[voff];
+                }
             });
         } else {
             const cx *pz = reinterpret_cast<const cx *>(a.in_re) + ubase;
@@ -289,8 +298,13 @@ template <typename T, int LR, int LC, bool PRE_TW, bool TRANSPOSE, bool SEQ> str
     PHAST_HD static void put(const TileArgs &a, size_t ubase, unsigned voff, T re, T im) {
         const T scale = (T)a.scale;
         if (!a.out_interleaved) {
-            (reinterpret_cast<T *>(a.out_re) + ubase)[voff] = re * scale;
-            (reinterpret_cast<T *>(a.out_im) + ubase)[voff] = im * scale;
+            if constexpr (NT_HINT) {
+                __builtin_nontemporal_store(re * scale, reinterpret_cast<T *>(a.out_re) + ubase + voff);
+                __builtin_nontemporal_store(im * scale, reinterpret_cast<T *>(a.out_im) + ubase + voff);
+            } else {
+                (reinterpret_cast<T *>(a.out_re) + ubase)[voff] = re * scale;
+                (reinterpret_cast<T *>(a.out_im) + ubase)[voff] = im * scale;
+            }
         } else {
             cx v;
             v.x = (a.out_interleaved == 2 ? im : re) * scale;
@@ -324,8 +338,11 @@ template <typename T, int LR, int LC, bool PRE_TW, bool TRANSPOSE, bool SEQ> str
     }
 };
 
+#ifndef PHAST_MIN_WAVES
+#define PHAST_MIN_WAVES(LR, LC) 1
+#endif
 template <typename T, int LR, int LC, bool PRE_TW, bool TRANSPOSE, bool SEQ>
-__global__ void __launch_bounds__(1 << (LR + LC - 4)) tile_fft_kernel(const TileArgs a) {
+__global__ void __launch_bounds__(1 << (LR + LC - 4), PHAST_MIN_WAVES(LR, LC)) tile_fft_kernel(const TileArgs a) {
     using Body = TileBody<T, LR, LC, PRE_TW, TRANSPOSE, SEQ>;
     using cx = cx_t<T>;
     constexpr int NT = Body::NT;
@@ -337,7 +354,9 @@ __global__ void __launch_bounds__(1 << (LR + LC - 4)) tile_fft_kernel(const Tile
     const typename Body::Shared sh{ex_re, Body::PLANE_SEQ ? ex_re : ex_re + Body::EXCH, l_tw3, l_twr};
 
     const int tid = threadIdx.x;
-    // phase stamps (debug): drains outstanding memory ops first so that a stamp means "everything before is done"
+    // Phase stamps exist only in the -DPHAST_TRACE build (tools/trace_tile.py): even behind a uniform branch the
+    // drains below wreck register allocation (256 VGPRs + 300 spills), so the product kernels carry none.
+#ifdef PHAST_TRACE
     int stamp_i = 0;
     auto stamp = [&]() {
         if (a.trace != nullptr) {
@@ -347,6 +366,9 @@ __global__ void __launch_bounds__(1 << (LR + LC - 4)) tile_fft_kernel(const Tile
             ++stamp_i;
         }
     };
+#else
+    auto stamp = []() {};
+#endif
     stamp();  // 0: kernel entry
     // the first tile's global loads are issued before the table loads so the two latencies overlap
     typename Body::Regs r;

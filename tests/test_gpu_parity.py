@@ -367,3 +367,38 @@ def test_interleaved_matches_planar(gpu):
         assert np.array_equal(d.cpu().numpy(), sig)  # device path == host path, bit for bit
         fwd(sig, gpu.Direction.Reverse)
         assert np.max(np.abs(sig - orig)) < (1e-9 if fdt == np.float64 else 1e-3) * max(1.0, float(np.max(np.abs(orig)))), k
+
+
+@pytest.mark.parametrize("k,dt", [(24, "f64"), (27, "f64"), (28, "f64"), (25, "f32"), (27, "f32")])
+def test_large_sizes_properties(gpu, k, dt):
+    """Sizes past what the oracle finishes in seconds: size-independent properties instead --
+    Parseval, sampled bins against a direct O(N) DFT (exact integer phase reduction), and the round trip."""
+    import torch
+
+    n = 1 << k
+    tdt = torch.float64 if dt == "f64" else torch.float32
+    Planner = gpu.PlannerDit64 if dt == "f64" else gpu.PlannerDit32
+    fwd = gpu.fft_64_dit_with_planner if dt == "f64" else gpu.fft_32_dit_with_planner
+    re = torch.empty(n, dtype=tdt, device="cuda")
+    im = torch.empty_like(re)
+    gpu.fill_uniform(re, im, n, seed=0xCAFE, first_id=k)
+    re0, im0 = re.clone(), im.clone()
+    planner = Planner(n)
+    fwd(re, im, gpu.Direction.Forward, planner)
+    e_in = float((re0.double() ** 2 + im0.double() ** 2).sum())
+    e_out = float((re.double() ** 2 + im.double() ** 2).sum())
+    assert abs(e_out / (n * e_in) - 1.0) < (1e-12 if dt == "f64" else 1e-5), planner.describe()
+    j = torch.arange(n, dtype=torch.int64, device="cuda")
+    norm = np.sqrt(n * e_in)
+    for kk in (0, 1, 777, n // 2 + 3, n - 1):
+        ang = ((j * kk) % n).to(torch.float64) * (-2.0 * np.pi / n)
+        c, s = torch.cos(ang), torch.sin(ang)
+        xr = float((re0.double() * c - im0.double() * s).sum())
+        xi = float((re0.double() * s + im0.double() * c).sum())
+        tol = (1e-11 if dt == "f64" else 2e-4) * norm
+        assert abs(float(re[kk]) - xr) < tol and abs(float(im[kk]) - xi) < tol, (kk, planner.describe())
+        del ang, c, s
+    del j
+    fwd(re, im, gpu.Direction.Reverse, planner)
+    lim = 1e-10 if dt == "f64" else 2e-5
+    assert float((re - re0).abs().max()) < lim and float((im - im0).abs().max()) < lim

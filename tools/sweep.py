@@ -50,14 +50,11 @@ def run(log_n, batch, plans, wgs, reps):
 
 
 if a.what in ("batch20", "all"):
-    print("batch of 64 x 2^20")
-    run(20, 64, [((10, 10), 14), ((10, 10), (14, 13)), ((10, 10), 13), ((7, 7, 6), 12), ((7, 7, 6), (13, 13, 12)),
-                 ((7, 7, 6), (13, 12, 12)), ((8, 6, 6), (13, 12, 12)), ((8, 6, 6), (14, 12, 12)), ((7, 6, 7), (13, 12, 13))],
-        [0], 3)
+    print("batch of 256 x 2^20")
+    run(20, 256, [((), 12), ((10, 10), 13), ((7, 7, 6), 12), ((8, 6, 6), (13, 12, 12))], [0], 3)
 if a.what in ("single20", "all"):
     print("single 2^20")
-    run(20, 1, [((10, 10), 14), ((10, 10), 13), ((10, 10), 12), ((7, 7, 6), 12)], [0], 20)
+    run(20, 1, [((), 12), ((10, 10), 13), ((7, 7, 6), 12)], [0], 20)
 if a.what in ("big26", "all"):
     print("single 2^26")
-    run(26, 1, [((9, 9, 8), 14), ((9, 9, 8), 13), ((10, 8, 8), (14, 14, 14)), ((10, 8, 8), 13), ((8, 9, 9), 14),
-                ((8, 9, 9), 13), ((8, 8, 10), 14), ((9, 8, 9), 14)], [0], 3)
+    run(26, 1, [((), 12), ((9, 9, 8), 13), ((10, 8, 8), 13), ((8, 9, 9), 13), ((9, 9, 8), 12)], [0], 3)

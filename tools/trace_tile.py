@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Phase timeline of the tile kernels for one transform (s_memtime stamps, 100 MHz constant clock)."""
+"""Phase timeline of the tile kernels for one transform (s_memtime stamps).
+
+    python -m phastft_amd.build --trace && PHASTFT_HIP_LIB=phastft_amd/lib/libphastft_hip_trace.so python tools/trace_tile.py 20
+"""
 import ctypes as C
 import os
 import sys
