@@ -9,6 +9,8 @@
 // happens in LDS with a +1 padded row so neither side has bank conflicts.  B = 32 for 8-byte and 64 for
 // 4-byte elements -- the reference's TILE_SIDE_F64 / TILE_SIDE_F32 (bravo.rs:19-20).  Pure data
 // movement: elements travel as integers, so NaN payloads and signed zeros survive.
+#include <cstdlib>
+
 #include "kernels.hpp"
 
 namespace phast {
@@ -26,8 +28,8 @@ template <typename U> __global__ void __launch_bounds__(256) bitrev_simple_kerne
     }
 }
 
-template <typename U, int BETA>
-__global__ void __launch_bounds__(256) bitrev_tiled_kernel(U *data, unsigned log_n, size_t dist, unsigned tiles) {
+template <typename U, int BETA, int NTH>
+__global__ void __launch_bounds__(NTH) bitrev_tiled_kernel(U *data, unsigned log_n, size_t dist, unsigned tiles) {
     constexpr int B = 1 << BETA;
     __shared__ U sa[B][B + 1];
     __shared__ U sb[B][B + 1];
@@ -39,13 +41,13 @@ __global__ void __launch_bounds__(256) bitrev_tiled_kernel(U *data, unsigned log
     U *x = data + (size_t)xf * dist;
     const unsigned ustride_log = log_n - BETA;
 
-    for (int idx = threadIdx.x; idx < B * B; idx += 256) {
+    for (int idx = threadIdx.x; idx < B * B; idx += NTH) {
         const unsigned u = idx >> BETA, v = idx & (B - 1);
         sa[u][v] = x[((size_t)u << ustride_log) + ((size_t)t << BETA) + v];
         if (t != tr) sb[u][v] = x[((size_t)u << ustride_log) + ((size_t)tr << BETA) + v];
     }
     __syncthreads();
-    for (int idx = threadIdx.x; idx < B * B; idx += 256) {
+    for (int idx = threadIdx.x; idx < B * B; idx += NTH) {
         const unsigned u = idx >> BETA, v = idx & (B - 1);
         const unsigned ru = __brev(u) >> (32 - BETA), rv = __brev(v) >> (32 - BETA);
         if (t != tr) {
@@ -57,7 +59,12 @@ __global__ void __launch_bounds__(256) bitrev_tiled_kernel(U *data, unsigned log
     }
 }
 
-template <typename U, int BETA>
+static int bitrev_variant() {  // tuning hook: PHAST_BITREV_VARIANT=0 (default) | 1 | 2 | 3 (tools/sweep_bitrev.py)
+    const char *e = getenv("PHAST_BITREV_VARIANT");
+    return e ? atoi(e) : 0;
+}
+
+template <typename U, int BETA, int NTH>
 static hipError_t launch_bitrev_u(U *data, unsigned log_n, size_t batch, size_t dist, hipStream_t stream) {
     if (log_n == 0 || batch == 0) return hipSuccess;
     if (log_n < 2 * BETA) {
@@ -75,17 +82,27 @@ static hipError_t launch_bitrev_u(U *data, unsigned log_n, size_t batch, size_t 
     const size_t per_launch = (size_t)0x40000000u / tiles ? (size_t)0x40000000u / tiles : 1;
     for (size_t b0 = 0; b0 < batch; b0 += per_launch) {
         const size_t nb = (batch - b0) < per_launch ? (batch - b0) : per_launch;
-        hipLaunchKernelGGL((bitrev_tiled_kernel<U, BETA>), dim3((unsigned)(nb * tiles)), dim3(256), 0, stream,
+        hipLaunchKernelGGL((bitrev_tiled_kernel<U, BETA, NTH>), dim3((unsigned)(nb * tiles)), dim3(NTH), 0, stream,
                            data + b0 * dist, log_n, dist, tiles);
     }
     return hipGetLastError();
 }
 
 template <> hipError_t launch_bitrev<double>(double *data, unsigned log_n, size_t batch, size_t dist, hipStream_t s) {
-    return launch_bitrev_u<unsigned long long, 5>(reinterpret_cast<unsigned long long *>(data), log_n, batch, dist, s);
+    auto *p = reinterpret_cast<unsigned long long *>(data);
+    const int v = bitrev_variant();
+    if (v == 1 && log_n >= 12) return launch_bitrev_u<unsigned long long, 6, 512>(p, log_n, batch, dist, s);
+    if (v == 2 && log_n >= 12) return launch_bitrev_u<unsigned long long, 6, 1024>(p, log_n, batch, dist, s);
+    if (v == 3) return launch_bitrev_u<unsigned long long, 5, 512>(p, log_n, batch, dist, s);
+    return launch_bitrev_u<unsigned long long, 5, 256>(p, log_n, batch, dist, s);
 }
 template <> hipError_t launch_bitrev<float>(float *data, unsigned log_n, size_t batch, size_t dist, hipStream_t s) {
-    return launch_bitrev_u<unsigned, 6>(reinterpret_cast<unsigned *>(data), log_n, batch, dist, s);
+    auto *p = reinterpret_cast<unsigned *>(data);
+    const int v = bitrev_variant();
+    if (v == 1) return launch_bitrev_u<unsigned, 6, 256>(p, log_n, batch, dist, s);
+    if (v == 2) return launch_bitrev_u<unsigned, 6, 1024>(p, log_n, batch, dist, s);
+    if (v == 3 && log_n >= 14) return launch_bitrev_u<unsigned, 7, 1024>(p, log_n, batch, dist, s);
+    return launch_bitrev_u<unsigned, 6, 512>(p, log_n, batch, dist, s);  // measured best (profiles/r01_sweep_bitrev.log)
 }
 
 }  // namespace phast
