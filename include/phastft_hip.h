@@ -200,12 +200,13 @@ int phast_digest_f32_dev(const float *d_reals, const float *d_imags, size_t n, s
 
 /* ---- tuning hook used by tools/ and tests to force a pass plan (n_passes = 0 restores the heuristic) ----
  * log_rows[i] = log2 of pass i's tile FFT length, tile_logs[i] = log2 of the points per tile of pass i
- * (12, 13 or 14: 256, 512 or 1024 threads per workgroup).  Returns PHAST_ERR_INVALID_ARG when the
+ * (12, 13 or 14), points_log = log2 of the complex points each thread holds (4, or 3 for the 4096-point
+ * latency tiles).  The forced plan serves every batch size.  Returns PHAST_ERR_INVALID_ARG when the
  * factorisation is not realisable with the compiled tile shapes. */
 int phast_planner_dit64_set_plan(phast_planner_dit64 *p, const unsigned *log_rows, const unsigned *tile_logs,
-                                 size_t n_passes);
+                                 size_t n_passes, unsigned points_log);
 int phast_planner_dit32_set_plan(phast_planner_dit32 *p, const unsigned *log_rows, const unsigned *tile_logs,
-                                 size_t n_passes);
+                                 size_t n_passes, unsigned points_log);
 
 /* tuning hook: force the number of resident workgroups per CU the tile passes are launched with (0 = planner's own
  * residency estimate).  Process-wide; for sweeps in tools/ only. */

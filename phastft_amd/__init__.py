@@ -196,14 +196,14 @@ class _PlannerDit:
     def reserve_batch(self, max_batch: int) -> None:
         _check(getattr(_lib.lib(), f"phast_planner_dit{self._sfx}_reserve_batch")(self._h, C.c_size_t(max_batch)))
 
-    def set_plan(self, log_rows=(), tile_log=12) -> None:
+    def set_plan(self, log_rows=(), tile_log=12, points_log=4) -> None:
         """Force the pass factorisation (tuning hook); ``()`` restores the heuristic.  ``tile_log`` is
-        log2(points per tile): one int for all passes or one per pass."""
+        log2(points per tile): one int for all passes or one per pass; ``points_log`` = log2(points per thread)."""
         n = len(log_rows)
         tls = [tile_log] * n if isinstance(tile_log, int) else list(tile_log)
         arr = (C.c_uint * max(1, n))(*log_rows)
         tarr = (C.c_uint * max(1, n))(*tls)
-        _check(getattr(_lib.lib(), f"phast_planner_dit{self._sfx}_set_plan")(self._h, arr, tarr, C.c_size_t(n)))
+        _check(getattr(_lib.lib(), f"phast_planner_dit{self._sfx}_set_plan")(self._h, arr, tarr, C.c_size_t(n), C.c_uint(points_log)))
 
 
     def time_passes(self, reals, imags, n: int, reps: int = 10):

@@ -86,23 +86,23 @@ struct PassDesc : PassGeom {
 
 template <typename T> struct Types;
 template <> struct Types<double> {
-    static hipError_t launch_a(int lr, int lc, bool seq, unsigned g, hipStream_t s, const TileArgs &a, bool q, int *b,
+    static hipError_t launch_a(int lr, int lc, int lp, unsigned g, hipStream_t s, const TileArgs &a, bool q, int *b,
                                size_t *l, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
-        return launch_tile_f64_a(lr, lc, seq, g, s, a, q, b, l, e0, e1);
+        return launch_tile_f64_a(lr, lc, lp, g, s, a, q, b, l, e0, e1);
     }
-    static hipError_t launch_bc(int lr, int lc, bool seq, unsigned g, hipStream_t s, const TileArgs &a, bool q, int *b,
+    static hipError_t launch_bc(int lr, int lc, int lp, unsigned g, hipStream_t s, const TileArgs &a, bool q, int *b,
                                size_t *l, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
-        return launch_tile_f64_bc(lr, lc, seq, g, s, a, q, b, l, e0, e1);
+        return launch_tile_f64_bc(lr, lc, lp, g, s, a, q, b, l, e0, e1);
     }
 };
 template <> struct Types<float> {
-    static hipError_t launch_a(int lr, int lc, bool seq, unsigned g, hipStream_t s, const TileArgs &a, bool q, int *b,
+    static hipError_t launch_a(int lr, int lc, int lp, unsigned g, hipStream_t s, const TileArgs &a, bool q, int *b,
                                size_t *l, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
-        return launch_tile_f32_a(lr, lc, seq, g, s, a, q, b, l, e0, e1);
+        return launch_tile_f32_a(lr, lc, lp, g, s, a, q, b, l, e0, e1);
     }
-    static hipError_t launch_bc(int lr, int lc, bool seq, unsigned g, hipStream_t s, const TileArgs &a, bool q, int *b,
+    static hipError_t launch_bc(int lr, int lc, int lp, unsigned g, hipStream_t s, const TileArgs &a, bool q, int *b,
                                size_t *l, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
-        return launch_tile_f32_bc(lr, lc, seq, g, s, a, q, b, l, e0, e1);
+        return launch_tile_f32_bc(lr, lc, lp, g, s, a, q, b, l, e0, e1);
     }
 };
 
@@ -171,15 +171,12 @@ template <typename T> struct Planner {
         scratch_cap = 0;
     }
 
-    // which: 0 = both plans, 1 = throughput plan only, 2 = latency plan only
-    int set_plan(const std::vector<unsigned> &lrs, const std::vector<unsigned> &tls, int which = 0) {
+    // which: 0 = both plans, 1 = throughput plan only, 2 = latency plan only; lp = log2(points per thread)
+    int set_plan(const std::vector<unsigned> &lrs, const std::vector<unsigned> &tls, int which = 0, unsigned lp = 4) {
         std::vector<PassGeom> geo;
-        if (!make_passes(log_n, lrs, tls, geo)) return PHAST_ERR_INVALID_ARG;
+        if (!make_passes(log_n, lrs, tls, geo, lp)) return PHAST_ERR_INVALID_ARG;
         std::vector<PassDesc> ps(geo.size());
-        for (size_t i = 0; i < geo.size(); ++i) {
-            static_cast<PassGeom &>(ps[i]) = geo[i];
-            ps[i].plane_seq = which != 2;  // latency plan: one workgroup per CU, LDS is free -> half the barriers
-        }
+        for (size_t i = 0; i < geo.size(); ++i) static_cast<PassGeom &>(ps[i]) = geo[i];
         size_t tb = 0;
         for (size_t i = 0; i < ps.size(); ++i) {
             int rc = upload<T>(host_twr<T>(1u << ps[i].lr), &ps[i].d_twr);
@@ -192,8 +189,8 @@ template <typename T> struct Planner {
                 TileArgs ta{};
                 ta.tw_bits = ps[i].tw_bits;
                 hipError_t e = ps[i].transpose
-                                   ? Types<T>::launch_a(ps[i].lr, ps[i].lc, ps[i].plane_seq, 0, nullptr, ta, true, &ps[i].blocks_per_cu, &ps[i].lds)
-                                   : Types<T>::launch_bc(ps[i].lr, ps[i].lc, ps[i].plane_seq, 0, nullptr, ta, true, &ps[i].blocks_per_cu, &ps[i].lds);
+                                   ? Types<T>::launch_a(ps[i].lr, ps[i].lc, (int)ps[i].lp, 0, nullptr, ta, true, &ps[i].blocks_per_cu, &ps[i].lds)
+                                   : Types<T>::launch_bc(ps[i].lr, ps[i].lc, (int)ps[i].lp, 0, nullptr, ta, true, &ps[i].blocks_per_cu, &ps[i].lds);
                 if (e != hipSuccess) rc = hip_fail(e, "occupancy query");
                 if (ps[i].blocks_per_cu < 1) ps[i].blocks_per_cu = 1;
                 if (rc == PHAST_OK && ps[i].lds > 160 * 1024) rc = PHAST_ERR_INVALID_ARG;  // tile does not fit one CU's LDS
@@ -234,7 +231,8 @@ template <typename T> struct Planner {
         rc = set_plan(lrs, tls, 1);
         if (rc) return rc;
         heuristic_plan<T>(log_n, true, lrs_l, tls_l);
-        if (lrs_l != lrs || tls_l != tls) rc = set_plan(lrs_l, tls_l, 2);
+        // latency plan: 8 points per thread (twice the waves) when those tiles exist, else 16
+        if (set_plan(lrs_l, tls_l, 2, 3) != PHAST_OK && (lrs_l != lrs || tls_l != tls)) rc = set_plan(lrs_l, tls_l, 2, 4);
         return rc;
     }
 
@@ -278,8 +276,8 @@ template <typename T> struct Planner {
         auto add = [&](const char *tag, const std::vector<PassDesc> &v) {
             s += std::string(" ") + tag + "=" + std::to_string(v.size()) + "p";
             for (auto &p : v) {
-                std::snprintf(buf, sizeof buf, "[%ux%u%s lds=%zu wg/cu=%d]", 1u << p.lr, 1u << p.lc,
-                              p.transpose ? "A" : "", p.lds, p.blocks_per_cu);
+                std::snprintf(buf, sizeof buf, "[%ux%u%s p%u lds=%zu wg/cu=%d]", 1u << p.lr, 1u << p.lc,
+                              p.transpose ? "A" : "", 1u << p.lp, p.lds, p.blocks_per_cu);
                 s += buf;
             }
         };
@@ -364,8 +362,8 @@ template <typename T> struct Planner {
                 if (grid >= 8) grid &= ~7u;  // keep tile%8 == workgroup%8 (XCD affinity of the tile order)
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (timer) PHAST_HIP(timer->pair((int)i, &e0, &e1));
-                hipError_t e = p.transpose ? Types<T>::launch_a(p.lr, p.lc, p.plane_seq, grid, stream, ta, false, nullptr, nullptr, e0, e1)
-                                           : Types<T>::launch_bc(p.lr, p.lc, p.plane_seq, grid, stream, ta, false, nullptr, nullptr, e0, e1);
+                hipError_t e = p.transpose ? Types<T>::launch_a(p.lr, p.lc, (int)p.lp, grid, stream, ta, false, nullptr, nullptr, e0, e1)
+                                           : Types<T>::launch_bc(p.lr, p.lc, (int)p.lp, grid, stream, ta, false, nullptr, nullptr, e0, e1);
                 if (e != hipSuccess) return hip_fail(e, "tile_fft launch");
             }
         }
@@ -684,7 +682,8 @@ template <typename T> static int describe_to(const Planner<T> *p, char *buf, siz
 }
 
 template <typename T>
-static int set_plan_c(Planner<T> *p, const unsigned *log_rows, const unsigned *tile_logs, size_t n_passes) {
+static int set_plan_c(Planner<T> *p, const unsigned *log_rows, const unsigned *tile_logs, size_t n_passes,
+                      unsigned points_log) {
     if (!p) return PHAST_ERR_INVALID_ARG;
     if (p->log_n <= kSmallMaxLog) return n_passes == 0 ? PHAST_OK : PHAST_ERR_INVALID_ARG;
     std::vector<unsigned> lrs, tls;
@@ -694,13 +693,15 @@ static int set_plan_c(Planner<T> *p, const unsigned *log_rows, const unsigned *t
         if (rc) return rc;
         std::vector<unsigned> lrs_l, tls_l;
         heuristic_plan<T>(p->log_n, true, lrs_l, tls_l);
-        return (lrs_l != lrs || tls_l != tls) ? p->set_plan(lrs_l, tls_l, 2) : PHAST_OK;
+        if (p->set_plan(lrs_l, tls_l, 2, 3) == PHAST_OK) return PHAST_OK;
+        return (lrs_l != lrs || tls_l != tls) ? p->set_plan(lrs_l, tls_l, 2, 4) : PHAST_OK;
     } else {
         if (!log_rows || !tile_logs) return PHAST_ERR_INVALID_ARG;
         lrs.assign(log_rows, log_rows + n_passes);
         tls.assign(tile_logs, tile_logs + n_passes);
     }
-    return p->set_plan(lrs, tls);
+    if (points_log != 3 && points_log != 4) return PHAST_ERR_INVALID_ARG;
+    return p->set_plan(lrs, tls, 0, points_log);
 }
 
 }  // namespace phast
@@ -796,8 +797,8 @@ int phast_options_guess(size_t input_size, phast_options *out) {
         return p->ensure_scratch(max_batch, &cap);                                                                 \
     }                                                                                                              \
     int phast_planner_dit##SFX##_set_plan(phast_planner_dit##SFX *p, const unsigned *lr, const unsigned *tl,       \
-                                          size_t np) {                                                             \
-        return set_plan_c<T>(p, lr, tl, np);                                                                       \
+                                          size_t np, unsigned points_log) {                                        \
+        return set_plan_c<T>(p, lr, tl, np, points_log);                                                           \
     }                                                                                                              \
     int phast_planner_dit##SFX##_time_passes(const phast_planner_dit##SFX *p, T *d_re, T *d_im, size_t batch,       \
                                              size_t dist, int reps, float *pass_ms, int *n_passes, void *stream) { \

@@ -93,13 +93,15 @@ template <typename T> inline std::vector<cx_t<T>> host_small_tw(size_t n) {
 }
 
 // ---- tile shapes that exist as kernels: log2(rows), log2(cols) ----
-// 4096-point tiles (256 threads), 8192-point tiles (512 threads), 16384-point tiles (1024 threads)
-#define PHAST_TILE_SHAPES(X) \
-    X(6, 6) X(7, 5) X(8, 4) X(9, 3) X(10, 2) X(7, 6) X(8, 5) X(9, 4) X(10, 3) X(8, 6) X(9, 5) X(10, 4)
+// log2(rows), log2(cols), log2(points per thread).  16 points per thread: 4096-, 8192- and 16384-point tiles
+// (256 / 512 / 1024 threads); 8 points per thread: 4096-point tiles with 512 threads (latency plans).
+#define PHAST_TILE_SHAPES(X)                                                                                  \
+    X(6, 6, 4) X(7, 5, 4) X(8, 4, 4) X(9, 3, 4) X(10, 2, 4) X(7, 6, 4) X(8, 5, 4) X(9, 4, 4) X(10, 3, 4)      \
+    X(8, 6, 4) X(9, 5, 4) X(10, 4, 4) X(6, 6, 3) X(7, 5, 3) X(8, 4, 3) X(9, 3, 3) X(10, 2, 3)
 
-inline bool shape_exists(unsigned lr, unsigned lc) {
-#define PHAST_CHK(LR_, LC_) \
-    if (lr == LR_ && lc == LC_) return true;
+inline bool shape_exists(unsigned lr, unsigned lc, unsigned lp = 4) {
+#define PHAST_CHK(LR_, LC_, LP_) \
+    if (lr == LR_ && lc == LC_ && lp == LP_) return true;
     PHAST_TILE_SHAPES(PHAST_CHK)
 #undef PHAST_CHK
     return false;
@@ -108,8 +110,8 @@ inline bool shape_exists(unsigned lr, unsigned lc) {
 // ---- geometry of one pass (see TileArgs in common.hpp) ----
 struct PassGeom {
     unsigned lr = 0, lc = 0;
+    unsigned lp = 4;  // log2(points per thread): 4 = throughput tiles, 3 = latency tiles (twice the waves)
     bool pre_tw = false, transpose = false;
-    bool plane_seq = true;  // f64: exchange re/im planes sequentially (false only for 4096-point latency tiles)
     unsigned log_s_in = 0, out_lo_bits = 0, tw_bits = 1;
     unsigned long long out_s1 = 0, out_s2 = 0, out_row_stride = 0;
     unsigned log_mod() const { return lr + log_s_in; }  // the inter-pass twiddle is W_{2^log_mod}^{row*lo}
@@ -155,7 +157,7 @@ inline void heuristic_plan(unsigned L, bool latency, std::vector<unsigned> &lrs,
 //              --C: FFT over u--> x[kc][kb][q]            (2 passes: S[r][q] --B--> x[kb][q])
 // `tile_logs` gives log2(points per tile) of every pass (one entry = the same for all passes).
 inline bool make_passes(unsigned L, const std::vector<unsigned> &lrs, const std::vector<unsigned> &tile_logs,
-                        std::vector<PassGeom> &ps) {
+                        std::vector<PassGeom> &ps, unsigned lp = 4) {
     unsigned sum = 0;
     for (unsigned lr : lrs) sum += lr;
     if (lrs.size() < 2 || lrs.size() > 3 || sum != L) return false;
@@ -164,9 +166,10 @@ inline bool make_passes(unsigned L, const std::vector<unsigned> &lrs, const std:
     const unsigned a = lrs[0], b = lrs[1], c = lrs.size() == 3 ? lrs[2] : 0;
     for (size_t i = 0; i < lrs.size(); ++i) {
         const unsigned tl = tile_logs.size() == 1 ? tile_logs[0] : tile_logs[i];
-        if (lrs[i] > tl || !shape_exists(lrs[i], tl - lrs[i])) return false;
+        if (lrs[i] > tl || !shape_exists(lrs[i], tl - lrs[i], lp)) return false;
         ps[i].lr = lrs[i];
         ps[i].lc = tl - lrs[i];
+        ps[i].lp = lp;
     }
     ps[0].transpose = true;  // FFT over the top `a` index bits; every column leaves as one contiguous run
     ps[0].log_s_in = L - a;

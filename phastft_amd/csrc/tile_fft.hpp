@@ -8,18 +8,14 @@
 // Design.  N = 2^L is factored into 2 or 3 passes N = R_A * R_B (* R_C).  A pass
 // runs ROWS-point FFTs along a strided axis; a workgroup owns a tile of ROWS x COLS points (COLS
 // adjacent columns => every global access of a wave covers COLS*sizeof(T)-byte contiguous segments).
-// Each thread holds 16 complex points in registers.  Inside the tile the ROWS-point FFT is a
-// decimation-in-frequency Cooley-Tukey split 16 x R2 (x R3); the radix-16/8/4/2 butterflies run in
-// registers with literal twiddles, and data moves between the radix steps through LDS:
-//     exchange 1 layout [n'][k1]  (row = n'*(16 + PADR) + k1; one pad row per n' when a 32-lane LDS access
-//                                  group spans G > 1 rows, so the G rows of a group fall on distinct banks)
-//     exchange 2 layout [n3][k2][k1]
-// Lanes are (column fastest, butterfly index); both exchanges are bank-conflict free for reads
-// (32-lane groups see G = 32/COLS consecutive rows) and writes.
-// Pass A (TRANSPOSE) additionally transposes through LDS (exchange 3, [col][k], padded) so that each
-// column's ROWS outputs leave as one contiguous run: this is where the digit reversal happens.  Later
-// passes (PRE_TW) multiply by the inter-pass twiddle W_{ROWS*S}^{row*lo} on load, looked up as a product
-// of three small LDS tables.  No MFMA: 6 FMA-class ops per 64 B moved per radix-2 stage -- HBM-bound.
+// Each thread holds P = 16 (or 8) complex points in registers.  Inside the tile the ROWS-point FFT is a
+// decimation-in-frequency digit chain ROWS = R_1 * ... * R_S (R_i <= P); the radix-16/8/4/2 butterflies run
+// in registers with literal twiddles, and data moves between the radix steps through LDS (layouts and the
+// bank-conflict argument are with TileBody below; tests/test_emulator.py audits every shape).
+// Pass A (TRANSPOSE) additionally transposes through LDS ([col][k], padded) so that each column's ROWS
+// outputs leave as one contiguous run: this is where the digit reversal happens.  Later passes (PRE_TW)
+// multiply by the inter-pass twiddle W_{ROWS*S}^{row*lo} on load, looked up as a product of three small LDS
+// tables.  No MFMA: 6 FMA-class ops per 64 B moved per radix-2 stage -- HBM-bound.
 //
 // The per-thread work is written as __host__ __device__ phase functions (TileBody) so that the very
 // same index arithmetic is executed thread-by-thread on the CPU by csrc/emu.hip (tests/test_emulator.py)
@@ -63,9 +59,9 @@ template <typename T, int N, int J> PHAST_HD void mul_w(T &re, T &im) {
     }
 }
 
-// In-register radix-R decimation-in-frequency FFT on regs [OFF, OFF+R).
+// In-register radix-R decimation-in-frequency FFT on regs [OFF, OFF+R) of a P-register thread.
 // Afterwards position OFF+p holds X[bitrev(p)].
-template <typename T, int R, int OFF> PHAST_HD void fft_reg_dif(T (&re)[16], T (&im)[16]) {
+template <typename T, int R, int OFF, int P> PHAST_HD void fft_reg_dif(T (&re)[P], T (&im)[P]) {
     static_for<0, ilog2_c(R)>([&](auto st) {
         constexpr int SPAN = R >> (decltype(st)::value + 1);
         static_for<0, R / 2>([&](auto bi) {
@@ -84,28 +80,49 @@ template <typename T, int R, int OFF> PHAST_HD void fft_reg_dif(T (&re)[16], T (
     });
 }
 
-template <typename T, int LR, int LC, bool PRE_TW, bool TRANSPOSE, bool SEQ> struct TileBody {
+// One tile pass, generic in the points per thread P = 2^LP (16: throughput plans; 8: latency plans, twice the
+// waves per tile -- a one-tile-per-CU launch is issue-stall bound with one wave per SIMD).
+//
+// The ROWS-point FFT is a DIF digit chain ROWS = R_1 * R_2 * ... * R_S with R_i <= P (R_1 = ... = P, the last
+// takes the remainder).  K_i = R_1...R_i.  Step i consumes input digit n_i (most significant first) and
+// produces output digit k_i (least significant first):
+//   * butterfly id b in [0, ROWS/R_i): b = k_low + K_{i-1} * n_rest  (k_low: digits already produced,
+//     n_rest: input digits still to go);  thread tau owns b = tau + M*I, I < P/R_i  (M = ROWS/P threads per column)
+//   * register I*R_i + j holds digit value n_i = j before the butterfly and k_i = bitrev(j) after it
+//   * then the twiddle W_{ROWS/K_{i-1}}^{n_rest * k_i} = W_ROWS^{n_rest * k_i * K_{i-1}}
+//   * exchange i (LDS) stores row n_rest*K_i + k_i*K_{i-1} + k_low; step i+1 reads row (j*L + n_rest')*K_i + k_low'
+//     with L = ROWS/(K_i R_{i+1}).  Lanes are (column fastest, tau): from exchange 2 on, a 32-lane access group
+//     sees consecutive rows by construction; exchange 1 (whose writers stride by K_1 rows) gets one pad row per
+//     n' = n_rest when the group spans G > 1 rows.
+// After the last step register I*R_S + j of thread tau holds frequency row bitrev(j)*K_{S-1} + tau + M*I.
+template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool SEQ> struct TileBody {
     using cx = cx_t<T>;
     static constexpr int ROWS = 1 << LR;
     static constexpr int COLS = 1 << LC;
-    static constexpr int NT = ROWS * COLS / 16;  // threads per workgroup, 16 points each
-    static constexpr int M = ROWS / 16;          // threads per column
+    static constexpr int P = 1 << LP;             // complex points per thread
+    static constexpr int NT = ROWS * COLS / P;    // threads per workgroup
+    static constexpr int M = ROWS / P;            // threads per column
+    static constexpr int LM = LR - LP;
     static constexpr int G = COLS >= 32 ? 1 : 32 / COLS;  // rows seen by one 32-lane LDS access group
-    static constexpr bool THREE = LR > 8;        // 16 x 16 x R3, else 16 x R2
-    static constexpr int R2 = THREE ? 16 : M;
-    static constexpr int R3 = THREE ? M / 16 : 1;
+    static constexpr int S = (LR + LP - 1) / LP;  // number of radix steps
     static constexpr bool PLANE_SEQ = SEQ;  // exchange re and im one after the other (half the LDS, twice the barriers)
-    static constexpr int CS = ROWS + G;                // padded column stride of the transposing exchange
-    static constexpr int E1S = 16 + (G > 1 ? 1 : 0);   // rows per n' in exchange 1 (16 used + padding)
+    static constexpr int CS = ROWS + G;     // padded column stride of the transposing exchange
+    static constexpr int E1S = P + (G > 1 ? 1 : 0);  // rows per n' in exchange 1 (P used + padding)
     static constexpr int EXCH_E1 = M * E1S * COLS;
-    static constexpr int EXCH_E3 = TRANSPOSE ? COLS * CS : 0;
-    static constexpr int EXCH = EXCH_E1 > EXCH_E3 ? EXCH_E1 : EXCH_E3;
+    static constexpr int EXCH_ET = TRANSPOSE ? COLS * CS : 0;
+    static constexpr int EXCH = EXCH_E1 > EXCH_ET ? EXCH_E1 : EXCH_ET;
     // Non-temporal global accesses when a tile row is a whole 128-byte line or more: every byte is touched once
     // per pass, and the strided-copy microbenchmark gains 5-10 % (profiles/r01_strided_copy_nt.log).  Narrower
     // rows share their line with the neighbouring tile and NEED the L2 (nt loads cost 25 % there).
     static constexpr bool NT_HINT = COLS * sizeof(T) >= 128;
     static_assert(LR >= 6 && LR <= 10, "tile FFT length 64..1024");
-    static_assert(NT <= 1024, "at most 1024 threads per workgroup");
+    static_assert(LP == 3 || LP == 4, "8 or 16 points per thread");
+    static_assert(NT <= 1024 && NT >= 64, "64..1024 threads per workgroup");
+    static_assert(S >= 2, "at least two radix steps (ROWS > P)");
+
+    // log2 of radix R_i (1-based) and of K_i = R_1...R_i
+    static constexpr int rbits(int i) { return i < S ? LP : LR - LP * (S - 1); }
+    static constexpr int kbits(int i) { return i <= 0 ? 0 : (i < S ? LP * i : LR); }
 
     static size_t lds_bytes(unsigned tw_bits) {
         size_t exch = (size_t)EXCH * sizeof(T) * (PLANE_SEQ ? 1 : 2);
@@ -123,7 +140,7 @@ template <typename T, int LR, int LC, bool PRE_TW, bool TRANSPOSE, bool SEQ> str
     };
     // what a thread keeps in registers across barriers
     struct Regs {
-        T re[16], im[16];
+        T re[P], im[P];
         unsigned xform, g0;
     };
 
@@ -139,10 +156,10 @@ template <typename T, int LR, int LC, bool PRE_TW, bool TRANSPOSE, bool SEQ> str
         r.g0 = (tile - r.xform * a.tiles_per_xform) << LC;
     }
 
-    // ---------------- load rows n = n1*M + tau, apply the inter-pass twiddle ----------------
+    // ---------------- load rows n = j*M + tau, j = 0..P-1 ----------------
     // Addresses are (wave-uniform 64-bit base) + (32-bit per-lane element offset): the tile's columns share
-    // the high part of in_col (tiles are COLS-aligned and COLS <= 2^log_s_in), the row n1*M is uniform, and
-    // only tau*2^log_s_in + col differs between lanes -- one VGPR for all 16 loads (saddr addressing).
+    // the high part of in_col (tiles are COLS-aligned and COLS <= 2^log_s_in), the row j*M is uniform, and
+    // only tau*2^log_s_in + col differs between lanes -- one VGPR for all P loads (saddr addressing).
     PHAST_HD static void load_raw(const TileArgs &a, int tid, Regs &r) {
         const int col = col_of(tid), tau = tau_of(tid);
         const unsigned lo0 = r.g0 & ((1u << a.log_s_in) - 1u);
@@ -151,37 +168,37 @@ template <typename T, int LR, int LC, bool PRE_TW, bool TRANSPOSE, bool SEQ> str
         if (!a.in_interleaved) {
             const T *pr = reinterpret_cast<const T *>(a.in_re) + ubase;
             const T *pi = reinterpret_cast<const T *>(a.in_im) + ubase;
-            static_for<0, 16>([&](auto n1) {
-                const size_t urow = (size_t)(decltype(n1)::value * M) << a.log_s_in;
+            static_for<0, P>([&](auto j) {
+                const size_t urow = (size_t)(decltype(j)::value * M) << a.log_s_in;
                 if constexpr (NT_HINT) {
-                    r.re[n1] = __builtin_nontemporal_load(pr + urow + voff);
-                    r.im[n1] = __builtin_nontemporal_load(pi + urow + voff);
+                    r.re[j] = __builtin_nontemporal_load(pr + urow + voff);
+                    r.im[j] = __builtin_nontemporal_load(pi + urow + voff);
                 } else {
-                    r.re[n1] = (pr + urow)[voff];
-                    r.im[n1] = (pi + urow)[voff];
+                    r.re[j] = (pr + urow)[voff];
+                    r.im[j] = (pi + urow)[voff];
                 }
             });
         } else {
             const cx *pz = reinterpret_cast<const cx *>(a.in_re) + ubase;
-            static_for<0, 16>([&](auto n1) {
-                const size_t urow = (size_t)(decltype(n1)::value * M) << a.log_s_in;
+            static_for<0, P>([&](auto j) {
+                const size_t urow = (size_t)(decltype(j)::value * M) << a.log_s_in;
                 cx v = (pz + urow)[voff];
-                r.re[n1] = a.in_interleaved == 2 ? v.y : v.x;
-                r.im[n1] = a.in_interleaved == 2 ? v.x : v.y;
+                r.re[j] = a.in_interleaved == 2 ? v.y : v.x;
+                r.im[j] = a.in_interleaved == 2 ? v.x : v.y;
             });
         }
     }
-    // inter-pass twiddle W_{ROWS*S}^{row*lo} on the freshly loaded rows (needs the LDS tables)
+    // inter-pass twiddle W_{ROWS*S_in}^{row*lo} on the freshly loaded rows (needs the LDS tables)
     PHAST_HD static void pre_twiddle(const TileArgs &a, const Shared &sh, int tid, Regs &r) {
         if constexpr (PRE_TW) {
             const int col = col_of(tid), tau = tau_of(tid);
             const unsigned lo0 = r.g0 & ((1u << a.log_s_in) - 1u);
             const unsigned lo = lo0 + (unsigned)col;
-            const unsigned e0 = (unsigned)tau * lo, de = (unsigned)M * lo;  // exponent of row n1*M + tau: e0 + n1*de
-            static_for<0, 16>([&](auto n1) {
+            const unsigned e0 = (unsigned)tau * lo, de = (unsigned)M * lo;  // exponent of row j*M + tau: e0 + j*de
+            static_for<0, P>([&](auto j) {
                 T wr, wi;
-                tw3_lookup<T>(sh.tw3, a.tw_bits, e0 + decltype(n1)::value * de, wr, wi);
-                cmul(r.re[n1], r.im[n1], wr, wi);
+                tw3_lookup<T>(sh.tw3, a.tw_bits, e0 + decltype(j)::value * de, wr, wi);
+                cmul(r.re[j], r.im[j], wr, wi);
             });
         }
     }
@@ -192,99 +209,76 @@ template <typename T, int LR, int LC, bool PRE_TW, bool TRANSPOSE, bool SEQ> str
         wi = w0.x * w1.y + w0.y * w1.x;
     }
 
-    // ---------------- step 1: radix-16 over n1; register p then holds k1 = bitrev4(p) ----------------
-    PHAST_HD static void step1(const Shared &sh, int tid, Regs &r) {
-        const int tau = tau_of(tid);
-        fft_reg_dif<T, 16, 0>(r.re, r.im);
-        static_for<1, 16>([&](auto p) {
-            constexpr int K1 = bitrev_c(decltype(p)::value, 4);
-            T wr, wi;
-            twr_lookup(sh, (unsigned)tau * K1, wr, wi);  // W_ROWS^(n' * k1), n' = tau
-            cmul(r.re[p], r.im[p], wr, wi);
-        });
-    }
-
-    // ---------------- step 2 ----------------
-    // two-level tiles: 16/R2 radix-R2 butterflies per thread, butterfly i has k1 = tau + R2*i (final step)
-    // three-level tiles: one radix-16 over n2 for (k1, n3) = (tau & 15, tau >> 4), then W_{16*R3}^{n3*k2}
-    PHAST_HD static void step2(const Shared &sh, int tid, Regs &r) {
-        if constexpr (!THREE) {
-            static_for<0, 16 / R2>([&](auto i) { fft_reg_dif<T, R2, decltype(i)::value * R2>(r.re, r.im); });
-        } else {
-            const int n3 = tau_of(tid) >> 4;
-            fft_reg_dif<T, 16, 0>(r.re, r.im);
-            static_for<1, 16>([&](auto p) {
-                constexpr int K2 = bitrev_c(decltype(p)::value, 4);
-                T wr, wi;
-                twr_lookup(sh, 16u * (unsigned)n3 * K2, wr, wi);
-                cmul(r.re[p], r.im[p], wr, wi);
+    // ---------------- step I (1-based): P/R_I radix-R_I butterflies + the inter-digit twiddle ----------------
+    template <int I> PHAST_HD static void step(const Shared &sh, int tid, Regs &r) {
+        constexpr int RB = rbits(I), R = 1 << RB, NB = P / R, KB = kbits(I - 1);
+        static_for<0, NB>([&](auto i) { fft_reg_dif<T, R, decltype(i)::value * R, P>(r.re, r.im); });
+        if constexpr (I < S) {  // n_rest = (tau + M*i) >> KB; twiddle W_ROWS^(n_rest * k_I * K_{I-1})
+            const int tau = tau_of(tid);
+            static_for<0, NB>([&](auto i) {
+                const unsigned n_rest = (unsigned)(tau + M * decltype(i)::value) >> KB;
+                static_for<1, R>([&](auto p) {
+                    constexpr int KI = bitrev_c(decltype(p)::value, RB);
+                    T wr, wi;
+                    twr_lookup(sh, (n_rest * KI) << KB, wr, wi);
+                    cmul(r.re[decltype(i)::value * R + decltype(p)::value], r.im[decltype(i)::value * R + decltype(p)::value],
+                         wr, wi);
+                });
             });
         }
     }
 
-    // ---------------- step 3 (three-level only): 16/R3 radix-R3 butterflies, k2 = (tau >> 4) + R3*i ----------------
-    PHAST_HD static void step3(Regs &r) {
-        if constexpr (THREE)
-            static_for<0, 16 / R3>([&](auto i) { fft_reg_dif<T, R3, decltype(i)::value * R3>(r.re, r.im); });
+    // frequency index (row of the tile FFT output) held by register Q after the last step
+    //   = krow_lane(tid) + krow_const<Q>()
+    PHAST_HD static unsigned krow_lane(int tid) { return (unsigned)tau_of(tid); }
+    template <int Q> PHAST_HD static constexpr unsigned krow_const() {
+        constexpr int RB = rbits(S), R = 1 << RB;
+        return (unsigned)(bitrev_c(Q % R, RB) << kbits(S - 1)) + (unsigned)(M * (Q / R));
     }
 
-    // frequency index (row of the tile FFT output) held by register P after the last step
-    //   = krow_lane(tid) + krow_const<P>()
-    PHAST_HD static unsigned krow_lane(int tid) { return (unsigned)tau_of(tid); }  // (tau&15) + 16*(tau>>4) = tau
-    template <int P> PHAST_HD static constexpr unsigned krow_const() {
-        if constexpr (!THREE) {
-            constexpr int I = P / R2, PP = P % R2;
-            return (unsigned)(R2 * I) + 16u * bitrev_c(PP, ilog2_c(R2));
-        } else {
-            constexpr int I = P / R3, PP = P % R3;
-            return 16u * (unsigned)(R3 * I) + 256u * bitrev_c(PP, ilog2_c(R3));
-        }
+    // ---------------- LDS exchange addresses (in elements); E = 1..S-1, E = S is the transposing exchange ----
+    // physical row of logical (n_rest, kk) with kk < K_E: exchange 1 pads one row per n_rest
+    template <int E> PHAST_HD static int phys_row(int n_rest, int kk) {
+        if constexpr (E == 1) return n_rest * E1S + kk;
+        else return (n_rest << kbits(E)) + kk;
     }
-    template <int P> PHAST_HD static unsigned krow(int tid) { return krow_lane(tid) + krow_const<P>(); }
-
-    // ---------------- LDS exchange addresses; E = 1, 2 (three-level only), 3 (transpose only) ----------------
-    template <int E, int P> PHAST_HD static int waddr(int tid) {
+    template <int E, int Q> PHAST_HD static int waddr(int tid) {
         const int col = col_of(tid), tau = tau_of(tid);
-        if constexpr (E == 1) {  // row n'*E1S + k1 with n' = tau, k1 = bitrev4(P)
-            constexpr int K1 = bitrev_c(P, 4);
-            return ((tau * E1S) << LC) + col + (K1 << LC);
-        } else if constexpr (E == 2) {  // [n3][k2][k1]
-            constexpr int K2 = bitrev_c(P, 4);
-            return ((((tau >> 4) * 256) + (tau & 15)) << LC) + col + ((K2 * 16) << LC);
+        if constexpr (E < S) {  // written by step E: register Q = I*R + j, k_E = bitrev(j)
+            constexpr int RB = rbits(E), R = 1 << RB, KB = kbits(E - 1);
+            constexpr int I = Q / R, KE = bitrev_c(Q % R, RB);
+            const int b = tau + M * I, k_low = b & ((1 << KB) - 1), n_rest = b >> KB;
+            return (phys_row<E>(n_rest, (KE << KB) + k_low) << LC) + col;
         } else {  // [col][k]
-            return col * CS + (int)krow_lane(tid) + (int)krow_const<P>();
+            return col * CS + (int)krow_lane(tid) + (int)krow_const<Q>();
         }
     }
-    template <int E, int P> PHAST_HD static int raddr(int tid) {
+    template <int E, int Q> PHAST_HD static int raddr(int tid) {
         const int col = col_of(tid), tau = tau_of(tid);
-        if constexpr (E == 1) {
-            if constexpr (!THREE) {
-                constexpr int I = P / R2, N2 = P % R2;  // n' = n2, k1 = tau + R2*I
-                return (tau << LC) + col + ((N2 * E1S + R2 * I) << LC);
-            } else {  // n' = n2*R3 + n3 with n2 = P, n3 = tau >> 4; k1 = tau & 15
-                return ((((tau >> 4) * E1S) + (tau & 15)) << LC) + col + ((P * R3 * E1S) << LC);
-            }
-        } else if constexpr (E == 2) {
-            constexpr int I = P / R3, N3 = P % R3;  // k2 = (tau >> 4) + R3*I
-            return ((((tau >> 4) * 16) + (tau & 15)) << LC) + col + (((N3 * 16 + R3 * I) * 16) << LC);
+        if constexpr (E < S) {  // read by step E+1: register Q = I*R + j holds input digit n_{E+1} = j
+            constexpr int RB = rbits(E + 1), R = 1 << RB, KB = kbits(E);
+            constexpr int I = Q / R, J = Q % R;
+            constexpr int L = ROWS >> (KB + RB);  // values of the digits after n_{E+1}
+            const int b = tau + M * I, k_low = b & ((1 << KB) - 1), n_rest = b >> KB;
+            return (phys_row<E>(J * L + n_rest, k_low) << LC) + col;
         } else {
-            const int f = P * NT + tid;
+            const int f = Q * NT + tid;
             return (f >> LR) * CS + (f & (ROWS - 1));
         }
     }
     // plane 0 = real parts through ex_re, plane 1 = imaginary parts through ex_im
     template <int E> PHAST_HD static void ex_write(const Shared &sh, int tid, const Regs &r, int plane) {
         T *dst = plane ? sh.ex_im : sh.ex_re;
-        static_for<0, 16>([&](auto P) { dst[waddr<E, decltype(P)::value>(tid)] = plane ? r.im[P] : r.re[P]; });
+        static_for<0, P>([&](auto Q) { dst[waddr<E, decltype(Q)::value>(tid)] = plane ? r.im[Q] : r.re[Q]; });
     }
     template <int E> PHAST_HD static void ex_read(const Shared &sh, int tid, Regs &r, int plane) {
         const T *src = plane ? sh.ex_im : sh.ex_re;
-        static_for<0, 16>([&](auto P) {
-            const T v = src[raddr<E, decltype(P)::value>(tid)];
+        static_for<0, P>([&](auto Q) {
+            const T v = src[raddr<E, decltype(Q)::value>(tid)];
             if (plane)
-                r.im[P] = v;
+                r.im[Q] = v;
             else
-                r.re[P] = v;
+                r.re[Q] = v;
         });
     }
 
@@ -314,36 +308,46 @@ template <typename T, int LR, int LC, bool PRE_TW, bool TRANSPOSE, bool SEQ> str
     }
     PHAST_HD static void store(const TileArgs &a, int tid, const Regs &r) {
         const size_t base = out_base(a, r);
-        if constexpr (!TRANSPOSE) {  // register P holds row krow_lane + krow_const<P> of column g0 + col
+        if constexpr (!TRANSPOSE) {  // register Q holds row krow_lane + krow_const<Q> of column g0 + col
             const unsigned voff = (unsigned)col_of(tid) * (unsigned)a.out_s1 + krow_lane(tid) * (unsigned)a.out_row_stride;
-            static_for<0, 16>([&](auto P) {
-                put(a, base + (size_t)krow_const<decltype(P)::value>() * a.out_row_stride, voff, r.re[P], r.im[P]);
+            static_for<0, P>([&](auto Q) {
+                put(a, base + (size_t)krow_const<decltype(Q)::value>() * a.out_row_stride, voff, r.re[Q], r.im[Q]);
             });
-        } else {  // after exchange 3: register P holds flat element f = P*NT + tid of the [col][k] tile
-            if constexpr (NT >= ROWS) {  // f -> column (P*NT >> LR) + (tid >> LR), row tid & (ROWS-1)
+        } else {  // after the transposing exchange: register Q holds flat element f = Q*NT + tid of the [col][k] tile
+            if constexpr (NT >= ROWS) {  // f -> column (Q*NT >> LR) + (tid >> LR), row tid & (ROWS-1)
                 const unsigned voff = (unsigned)(tid >> LR) * (unsigned)a.out_s1 +
                                       (unsigned)(tid & (ROWS - 1)) * (unsigned)a.out_row_stride;
-                static_for<0, 16>([&](auto P) {
-                    constexpr int C0 = (decltype(P)::value * NT) >> LR;
-                    put(a, base + (size_t)C0 * a.out_s1, voff, r.re[P], r.im[P]);
+                static_for<0, P>([&](auto Q) {
+                    constexpr int C0 = (decltype(Q)::value * NT) >> LR;
+                    put(a, base + (size_t)C0 * a.out_s1, voff, r.re[Q], r.im[Q]);
                 });
-            } else {  // f -> column P*NT >> LR, row (P*NT & (ROWS-1)) + tid
+            } else {  // f -> column Q*NT >> LR, row (Q*NT & (ROWS-1)) + tid
                 const unsigned voff = (unsigned)tid * (unsigned)a.out_row_stride;
-                static_for<0, 16>([&](auto P) {
-                    constexpr int C0 = (decltype(P)::value * NT) >> LR, K0 = (decltype(P)::value * NT) & (ROWS - 1);
-                    put(a, base + (size_t)C0 * a.out_s1 + (size_t)K0 * a.out_row_stride, voff, r.re[P], r.im[P]);
+                static_for<0, P>([&](auto Q) {
+                    constexpr int C0 = (decltype(Q)::value * NT) >> LR, K0 = (decltype(Q)::value * NT) & (ROWS - 1);
+                    put(a, base + (size_t)C0 * a.out_s1 + (size_t)K0 * a.out_row_stride, voff, r.re[Q], r.im[Q]);
                 });
             }
         }
+    }
+
+    // the whole per-tile chain between the load and the store, parameterised by how an exchange is performed
+    // (barriers on the GPU, "every thread finishes the phase" in the emulator)
+    template <typename StepFn, typename ExchFn> PHAST_HD static void chain(StepFn &&do_step, ExchFn &&do_exchange) {
+        static_for<1, S + 1>([&](auto i) {
+            do_step(i);
+            if constexpr (decltype(i)::value < S) do_exchange(i);
+        });
+        if constexpr (TRANSPOSE) do_exchange(std::integral_constant<int, S>{});
     }
 };
 
 #ifndef PHAST_MIN_WAVES
 #define PHAST_MIN_WAVES(LR, LC) 1
 #endif
-template <typename T, int LR, int LC, bool PRE_TW, bool TRANSPOSE, bool SEQ>
-__global__ void __launch_bounds__(1 << (LR + LC - 4), PHAST_MIN_WAVES(LR, LC)) tile_fft_kernel(const TileArgs a) {
-    using Body = TileBody<T, LR, LC, PRE_TW, TRANSPOSE, SEQ>;
+template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool SEQ>
+__global__ void __launch_bounds__(1 << (LR + LC - LP), PHAST_MIN_WAVES(LR, LC)) tile_fft_kernel(const TileArgs a) {
+    using Body = TileBody<T, LR, LC, LP, PRE_TW, TRANSPOSE, SEQ>;
     using cx = cx_t<T>;
     constexpr int NT = Body::NT;
 
@@ -384,7 +388,7 @@ __global__ void __launch_bounds__(1 << (LR + LC - 4), PHAST_MIN_WAVES(LR, LC)) t
     stamp();  // 1: twiddle tables in LDS
 
     // one exchange: barrier (previous readers done), write, barrier, read -- per plane when PLANE_SEQ
-    auto exchange = [&](auto e, typename Body::Regs &r) {
+    auto exchange = [&](auto e) {
         constexpr int E = decltype(e)::value;
         if constexpr (!Body::PLANE_SEQ) {
             __syncthreads();
@@ -401,27 +405,17 @@ __global__ void __launch_bounds__(1 << (LR + LC - 4), PHAST_MIN_WAVES(LR, LC)) t
                 Body::template ex_read<E>(sh, tid, r, plane);
             }
         }
+        stamp();
+    };
+    auto do_step = [&](auto i) {
+        Body::template step<decltype(i)::value>(sh, tid, r);
+        stamp();
     };
 
     while (t < a.tiles_total) {
         Body::pre_twiddle(a, sh, tid, r);
         stamp();  // 2: tile loaded (+ pre-twiddle)
-        Body::step1(sh, tid, r);
-        stamp();  // 3
-        exchange(std::integral_constant<int, 1>{}, r);
-        stamp();  // 4
-        Body::step2(sh, tid, r);
-        stamp();  // 5
-        if constexpr (Body::THREE) {
-            exchange(std::integral_constant<int, 2>{}, r);
-            stamp();  // 6
-            Body::step3(r);
-            stamp();  // 7
-        }
-        if constexpr (TRANSPOSE) {
-            exchange(std::integral_constant<int, 3>{}, r);
-            stamp();  // 6 or 8
-        }
+        Body::chain(do_step, exchange);
         Body::store(a, tid, r);
         stamp();  // last: stores retired
         t += gridDim.x;
@@ -433,11 +427,11 @@ __global__ void __launch_bounds__(1 << (LR + LC - 4), PHAST_MIN_WAVES(LR, LC)) t
 }
 
 // host-side launcher for one (T, LR, LC, mode) instantiation
-template <typename T, int LR, int LC, bool PRE_TW, bool TRANSPOSE, bool SEQ>
+template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool SEQ>
 hipError_t launch_tile_inst(unsigned grid, hipStream_t stream, const TileArgs &a, bool query_only, int *blocks_per_cu,
                             size_t *lds_out, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
-    using Body = TileBody<T, LR, LC, PRE_TW, TRANSPOSE, SEQ>;
-    auto kern = tile_fft_kernel<T, LR, LC, PRE_TW, TRANSPOSE, SEQ>;
+    using Body = TileBody<T, LR, LC, LP, PRE_TW, TRANSPOSE, SEQ>;
+    auto kern = tile_fft_kernel<T, LR, LC, LP, PRE_TW, TRANSPOSE, SEQ>;
     const size_t lds = Body::lds_bytes(a.tw_bits);
     if (lds_out) *lds_out = lds;
     // raise the dynamic-LDS limit only when it grows: the steady state issues no runtime call besides the
@@ -477,8 +471,8 @@ hipError_t launch_tile_inst(unsigned grid, hipStream_t stream, const TileArgs &a
 
 // Thread-by-thread host execution of one pass: the same TileBody phases, barriers replaced by
 // "every thread finishes the phase".  Test infrastructure for the GPU-less build container.
-template <typename T, int LR, int LC, bool PRE_TW, bool TRANSPOSE, bool SEQ> void emulate_tile_pass(const TileArgs &a) {
-    using Body = TileBody<T, LR, LC, PRE_TW, TRANSPOSE, SEQ>;
+template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool SEQ> void emulate_tile_pass(const TileArgs &a) {
+    using Body = TileBody<T, LR, LC, LP, PRE_TW, TRANSPOSE, SEQ>;
     using Regs = typename Body::Regs;
     constexpr int NT = Body::NT;
     T *ex = new T[(size_t)Body::EXCH * 2];
@@ -503,20 +497,16 @@ template <typename T, int LR, int LC, bool PRE_TW, bool TRANSPOSE, bool SEQ> voi
             }
         }
     };
+    auto do_step = [&](auto i) {
+        for (int t = 0; t < NT; ++t) Body::template step<decltype(i)::value>(sh, t, regs[t]);
+    };
     for (unsigned tile = 0; tile < a.tiles_total; ++tile) {
         for (int t = 0; t < NT; ++t) {
             Body::locate(a, tile, regs[t]);
             Body::load_raw(a, t, regs[t]);
             Body::pre_twiddle(a, sh, t, regs[t]);
-            Body::step1(sh, t, regs[t]);
         }
-        exchange(std::integral_constant<int, 1>{});
-        for (int t = 0; t < NT; ++t) Body::step2(sh, t, regs[t]);
-        if constexpr (Body::THREE) {
-            exchange(std::integral_constant<int, 2>{});
-            for (int t = 0; t < NT; ++t) Body::step3(regs[t]);
-        }
-        if constexpr (TRANSPOSE) exchange(std::integral_constant<int, 3>{});
+        Body::chain(do_step, exchange);
         for (int t = 0; t < NT; ++t) Body::store(a, t, regs[t]);
     }
     delete[] regs;

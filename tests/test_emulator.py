@@ -21,38 +21,43 @@ def emu():
     return lib
 
 
-def run(emu, re, im, direction=1, lrs=(), tile_log=12):
+def run(emu, re, im, direction=1, lrs=(), tile_log=12, points_log=4):
     L = int(np.log2(re.size))
     arr = (C.c_uint * max(1, len(lrs)))(*lrs)
     fn = emu.phast_emu_fft_f64 if re.dtype == np.float64 else emu.phast_emu_fft_f32
     return fn(re.ctypes.data_as(C.c_void_p), im.ctypes.data_as(C.c_void_p), C.c_uint(L), C.c_size_t(1),
-              C.c_int(direction), arr, C.c_size_t(len(lrs)), C.c_uint(tile_log))
+              C.c_int(direction), arr, C.c_size_t(len(lrs)), C.c_uint(tile_log | (points_log << 8)))
 
 
-SHAPES = [(6, 6), (7, 5), (8, 4), (9, 3), (10, 2), (7, 6), (8, 5), (9, 4), (10, 3), (8, 6), (9, 5), (10, 4)]
+# (log2 rows, log2 cols, log2 points per thread) -- PHAST_TILE_SHAPES of csrc/plan.hpp
+SHAPES = [(6, 6, 4), (7, 5, 4), (8, 4, 4), (9, 3, 4), (10, 2, 4), (7, 6, 4), (8, 5, 4), (9, 4, 4), (10, 3, 4), (8, 6, 4),
+          (9, 5, 4), (10, 4, 4), (6, 6, 3), (7, 5, 3), (8, 4, 3), (9, 3, 3), (10, 2, 3)]
 
 
 @pytest.mark.parametrize("is_f64", [1, 0])
 def test_lds_exchanges_in_bounds_permutations_and_conflict_free(emu, is_f64):
-    for lr, lc in SHAPES:
+    for lr, lc, lp in SHAPES:
         for transpose in (1, 0):
             r, w = C.c_int(), C.c_int()
-            errors = emu.phast_emu_audit_lds(is_f64, lr, lc, transpose, C.byref(r), C.byref(w))
-            assert errors == 0, (lr, lc, transpose)
-            assert r.value == 1 and w.value == 1, (lr, lc, transpose, r.value, w.value)
+            errors = emu.phast_emu_audit_lds(is_f64, lr, lc, lp, transpose, C.byref(r), C.byref(w))
+            assert errors == 0, (lr, lc, lp, transpose)
+            assert r.value == 1 and w.value == 1, (lr, lc, lp, transpose, r.value, w.value)
 
 
-PLANS = [(12, (6, 6), 12), (13, (7, 6), 12), (15, (8, 7), 12), (16, (8, 8), 13), (17, (9, 8), 13), (18, (9, 9), 12),
-         (19, (10, 9), 13), (20, (10, 10), 12), (20, (10, 10), 13), (20, (10, 10), 14), (20, (7, 7, 6), 12),
-         (18, (6, 6, 6), 12), (21, (7, 7, 7), 13), (22, (8, 7, 7), 13)]
+PLANS = [(12, (6, 6), 12, 4), (13, (7, 6), 12, 4), (15, (8, 7), 12, 4), (16, (8, 8), 13, 4), (17, (9, 8), 13, 4),
+         (18, (9, 9), 12, 4), (19, (10, 9), 13, 4), (20, (10, 10), 12, 4), (20, (10, 10), 13, 4), (20, (10, 10), 14, 4),
+         (20, (7, 7, 6), 12, 4), (18, (6, 6, 6), 12, 4), (21, (7, 7, 7), 13, 4), (22, (8, 7, 7), 13, 4),
+         # 8 points per thread (latency tiles): every 4096-point shape, 2..4 radix steps
+         (12, (6, 6), 12, 3), (13, (7, 6), 12, 3), (15, (8, 7), 12, 3), (17, (9, 8), 12, 3), (19, (10, 9), 12, 3),
+         (20, (10, 10), 12, 3), (21, (7, 7, 7), 12, 3)]
 
 
-@pytest.mark.parametrize("L,lrs,tl", PLANS)
-def test_forced_plans_vs_oracle_f64(emu, oracle, L, lrs, tl):
+@pytest.mark.parametrize("L,lrs,tl,lp", PLANS)
+def test_forced_plans_vs_oracle_f64(emu, oracle, L, lrs, tl, lp):
     n = 1 << L
     re, im = oracle.fill(n, np.float64, transform_id=L)
     a, b = re.copy(), im.copy()
-    assert run(emu, a, b, 1, lrs, tl) == 0
+    assert run(emu, a, b, 1, lrs, tl, lp) == 0
     oracle.fft_64_dit(re, im, oracle.FORWARD)
     err = np.sqrt(np.sum((a - re) ** 2 + (b - im) ** 2) / np.sum(re ** 2 + im ** 2))
     assert err <= 1e-13, err
@@ -70,7 +75,7 @@ def test_default_plans_both_types_and_inverse(emu, oracle, L):
             re, im = oracle.fill(n, dtype, transform_id=7 * L + latency)
             a, b = re.copy(), im.copy()
             direction = -1 if latency else 1
-            assert run(emu, a, b, direction, tuple(lrs)[:npass], tl.value) == 0
+            assert run(emu, a, b, direction, tuple(lrs)[:npass], tl.value, 3 if (latency and tl.value == 12) else 4) == 0
             ofn(re, im, oracle.REVERSE if latency else oracle.FORWARD)
             err = np.sqrt(np.sum((a.astype(np.float64) - re) ** 2 + (b.astype(np.float64) - im) ** 2) /
                           np.sum(re.astype(np.float64) ** 2 + im.astype(np.float64) ** 2))

@@ -27,10 +27,13 @@ def run(log_n, batch, plans, wgs, reps):
     n = 1 << log_n
     re = torch.empty(n * batch, dtype=dt, device="cuda")
     im = torch.empty_like(re)
-    for lrs, tl in plans:
+    for plan in plans:
+        lrs, tl = plan[0], plan[1]
+        lp = plan[2] if len(plan) > 2 else 4
         pl = Planner(n)
         try:
-            pl.set_plan(lrs, tl)
+            if lrs:
+                pl.set_plan(lrs, tl, lp)
         except P.PhastPanic:
             print(f"  plan {lrs}@{tl}: not available")
             continue
@@ -42,7 +45,7 @@ def run(log_n, batch, plans, wgs, reps):
             ms = pl.time_passes(re, im, n, reps=reps)
             tot = sum(ms)
             gbs = [bps * n * batch / (m * 1e-3) / 1e9 for m in ms]
-            print(f"  2^{log_n} x{batch} plan={lrs}@{tl} wg/cu={wg or 'auto'}: pass_ms={[round(m, 4) for m in ms]} "
+            print(f"  2^{log_n} x{batch} plan={lrs}@{tl}p{1 << lp} wg/cu={wg or 'auto'}: pass_ms={[round(m, 4) for m in ms]} "
                   f"pass_GB/s={[int(g) for g in gbs]} total={tot:.4f} ms {n * batch / tot / 1e6:.1f} GS/s "
                   f"| {pl.describe() if wg == wgs[0] else ''}", flush=True)
     lib.phast_debug_set_wg_per_cu(0)
@@ -54,7 +57,7 @@ if a.what in ("batch20", "all"):
     run(20, 256, [((), 12), ((10, 10), 13), ((7, 7, 6), 12), ((8, 6, 6), (13, 12, 12))], [0], 3)
 if a.what in ("single20", "all"):
     print("single 2^20")
-    run(20, 1, [((), 12), ((10, 10), 13), ((7, 7, 6), 12)], [0], 20)
+    run(20, 1, [((), 12), ((10, 10), 12, 3), ((10, 10), 12, 4), ((10, 10), 13, 4), ((7, 7, 6), 12, 3), ((7, 7, 6), 12, 4)], [0], 20)
 if a.what in ("big26", "all"):
     print("single 2^26")
     run(26, 1, [((), 12), ((9, 9, 8), 13), ((10, 8, 8), 13), ((8, 9, 9), 13), ((9, 9, 8), 12)], [0], 3)
