@@ -46,7 +46,7 @@ __all__ = [
     "c2r_fft_f64_with_planner_and_scratch", "c2r_fft_f32_with_planner_and_scratch",
     "fft_64_interleaved", "fft_32_interleaved", "fft_64_interleaved_with_planner", "fft_32_interleaved_with_planner",
     "fft_64_interleaved_with_planner_and_opts", "fft_32_interleaved_with_planner_and_opts",
-    "bit_rev_bravo_f64", "bit_rev_bravo_f32", "fft_dit_batched", "fill_uniform", "digest", "device_info",
+    "bit_rev_bravo_f64", "bit_rev_bravo_f32", "fft_dit_batched", "r2c_fft_batched", "c2r_fft_batched", "fill_uniform", "digest", "device_info",
 ]
 
 
@@ -384,20 +384,46 @@ def fft_32_interleaved_with_planner_and_opts(signal, direction: Direction, plann
     _fft_interleaved("32", np.complex64, signal, direction, planner, opts, True)
 
 
-def fft_dit_batched(reals, imags, n: int, direction: Direction, planner) -> None:
-    """Device-resident batch: ``reals``/``imags`` hold ``len/n`` transforms back to back (no reference
-    counterpart; the reference loops over transforms on the CPU)."""
+def fft_dit_batched(reals, imags, n: int, direction: Direction, planner, dist: int | None = None) -> None:
+    """Device-resident batch: transform b lives at ``[b*dist, b*dist + n)`` of ``reals``/``imags`` (``dist`` defaults
+    to ``n``: transforms back to back).  No reference counterpart -- the reference loops over transforms on the CPU."""
     dtype, sfx = planner._dtype, planner._sfx
     re, im = _Slice(reals, dtype, "reals"), _Slice(imags, dtype, "imags")
     if not _same_place(re, im):
         raise TypeError("fft_dit_batched needs device tensors")
     if re.len != im.len:
         _check(2)
-    if n == 0 or re.len % n:
-        raise ValueError("length must be a multiple of n")
-    _check(getattr(_lib.lib(), f"phast_fft_{sfx}_dit_dev")(re.ptr, im.ptr, C.c_size_t(n), C.c_size_t(re.len // n),
-                                                           C.c_size_t(n), C.c_int(int(direction)), planner._h,
+    dist = n if dist is None else dist
+    if n == 0 or dist < n or re.len < n or (re.len - n) % dist:
+        raise ValueError("length must be (batch-1)*dist + n")
+    batch = (re.len - n) // dist + 1
+    _check(getattr(_lib.lib(), f"phast_fft_{sfx}_dit_dev")(re.ptr, im.ptr, C.c_size_t(n), C.c_size_t(batch),
+                                                           C.c_size_t(dist), C.c_int(int(direction)), planner._h,
                                                            _stream()))
+
+
+def r2c_fft_batched(input_re, output_re, output_im, planner, batch: int) -> None:
+    """Device-resident batch of R2C transforms: inputs ``n`` apart, outputs ``n/2 + 1`` apart."""
+    fs = "f64" if planner._dtype == np.float64 else "f32"
+    i, ore, oim = (_Slice(x, planner._dtype, w) for x, w in ((input_re, "input_re"), (output_re, "output_re"),
+                                                              (output_im, "output_im")))
+    n, out = planner.n, planner.n // 2 + 1
+    if not _same_place(i, ore, oim) or i.len != batch * n or ore.len != batch * out or oim.len != batch * out:
+        raise ValueError("need device tensors of batch*n, batch*(n/2+1), batch*(n/2+1) elements")
+    _check(getattr(_lib.lib(), f"phast_r2c_fft_{fs}_dev")(i.ptr, ore.ptr, oim.ptr, C.c_size_t(batch), C.c_size_t(n),
+                                                          C.c_size_t(out), planner._h, _stream()))
+
+
+def c2r_fft_batched(input_re, input_im, output, planner, batch: int) -> None:
+    """Device-resident batch of C2R transforms: inputs ``n/2 + 1`` apart, outputs ``n`` apart."""
+    fs = "f64" if planner._dtype == np.float64 else "f32"
+    ire, iim, out = (_Slice(x, planner._dtype, w) for x, w in ((input_re, "input_re"), (input_im, "input_im"),
+                                                                (output, "output")))
+    n, half1 = planner.n, planner.n // 2 + 1
+    if not _same_place(ire, iim, out) or out.len != batch * n or ire.len != batch * half1 or iim.len != batch * half1:
+        raise ValueError("need device tensors of batch*(n/2+1), batch*(n/2+1), batch*n elements")
+    _check(getattr(_lib.lib(), f"phast_c2r_fft_{fs}_dev")(ire.ptr, iim.ptr, out.ptr, C.c_size_t(batch), C.c_size_t(half1),
+                                                          C.c_size_t(n), planner._h, _stream()))
 
 
 # ---------------------------------------------------------------------------------------------

@@ -1,0 +1,189 @@
+// host_api_test.cpp -- the reference's own tests (lib.rs:238-461, r2c.rs:914-1540), re-read through the C++ host
+// side (include/phastft.hpp) over libphastft_hip.so.  Built by tests/test_cpp_host.py; with a GPU it runs the
+// numerical checks, without one it checks that argument asserts still panic and compute calls fail loudly.
+#include <cmath>
+#include <complex>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "phastft.hpp"
+
+using namespace phastft;
+
+static int failures = 0;
+#define EXPECT(cond)                                                            \
+    do {                                                                        \
+        if (!(cond)) {                                                          \
+            std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond);         \
+            ++failures;                                                         \
+        }                                                                       \
+    } while (0)
+
+template <typename F> static std::string panic_message(F &&f) {
+    try {
+        f();
+    } catch (const Panic &p) {
+        return p.what();
+    } catch (const HipError &e) {
+        return std::string("HipError: ") + e.what();
+    }
+    return "<no panic>";
+}
+
+// O(N^2) long-double DFT: the independent oracle for small N (RustFFT's role in lib.rs:298-338)
+static void naive_dft(const std::vector<double> &re, const std::vector<double> &im, std::vector<double> &ore,
+                      std::vector<double> &oim) {
+    const size_t n = re.size();
+    const long double tau = 6.283185307179586476925286766559005768L;
+    ore.assign(n, 0);
+    oim.assign(n, 0);
+    for (size_t k = 0; k < n; ++k) {
+        long double sr = 0, si = 0;
+        for (size_t j = 0; j < n; ++j) {
+            const long double a = -tau * (long double)((k * j) % n) / (long double)n;
+            const long double c = cosl(a), s = sinl(a);
+            sr += re[j] * c - im[j] * s;
+            si += re[j] * s + im[j] * c;
+        }
+        ore[k] = (double)sr;
+        oim[k] = (double)si;
+    }
+}
+
+int main(int argc, char **argv) {
+    const bool have_gpu = argc > 1 && std::strcmp(argv[1], "gpu") == 0;
+
+    // ---- panics that need no device (planner.rs:66,195; lib.rs:238-257; bravo.rs:228) ----
+    EXPECT(panic_message([] { PlannerDit64 p(5); }) == "assertion failed: num_points > 0 && num_points.is_power_of_two()");
+    EXPECT(panic_message([] { PlannerDit32 p(5); }) == "assertion failed: num_points > 0 && num_points.is_power_of_two()");
+    EXPECT(panic_message([] { PlannerR2c64 p(6); }) == "n must be a power of 2 >= 4");
+    EXPECT(panic_message([] { PlannerR2c32 p(2); }) == "n must be a power of 2 >= 4");
+    {
+        std::vector<double> d(10);
+        EXPECT(panic_message([&] { bit_rev_bravo_f64(d, 3); }) == "Data length must be 2^n");
+    }
+    const Options o = Options::guess_options(size_t(1) << 20);  // options.rs:38-43
+    EXPECT(o.multithreaded_bit_reversal && o.smallest_parallel_chunk_size == 16384);
+    EXPECT(!Options::guess_options(size_t(1) << 15).multithreaded_bit_reversal);
+    EXPECT(static_cast<int>(Direction::Forward) == 1 && static_cast<int>(Direction::Reverse) == -1);
+
+    if (!have_gpu) {  // no CPU fallback: compute must fail loudly and leave the data alone
+        std::vector<double> re(16, 1.0), im(16, 0.0);
+        const std::string m = panic_message([&] { fft_64_dit(re, im, Direction::Forward); });
+        EXPECT(m.rfind("HipError:", 0) == 0);
+        EXPECT(re[3] == 1.0);
+        std::printf("host_api_test (no GPU): %d failure(s)\n", failures);
+        return failures ? 1 : 0;
+    }
+
+    // ---- fft_correctness (lib.rs:298-338): ramp vs an independent DFT, abs 0.01 ----
+    for (int k = 4; k <= 10; ++k) {
+        const size_t n = size_t(1) << k;
+        std::vector<double> re(n), im(n), ore, oim;
+        for (size_t i = 0; i < n; ++i) re[i] = im[i] = double(i + 1);
+        naive_dft(re, im, ore, oim);
+        fft_64_dit(re, im, Direction::Forward);
+        for (size_t i = 0; i < n; ++i) EXPECT(std::fabs(re[i] - ore[i]) < 0.01 && std::fabs(im[i] - oim[i]) < 0.01);
+    }
+    // ---- round trip with a planner, both precisions (lib.rs:381-461) ----
+    for (int k = 4; k <= 14; ++k) {
+        const size_t n = size_t(1) << k;
+        std::vector<double> re(n), im(n);
+        double norm = 0;
+        for (size_t i = 0; i < n; ++i) {
+            re[i] = std::sin(0.37 * double(i) + 1.0);
+            im[i] = std::cos(1.91 * double(i));
+            norm += re[i] * re[i] + im[i] * im[i];
+        }
+        for (size_t i = 0; i < n; ++i) {
+            re[i] /= std::sqrt(norm);
+            im[i] /= std::sqrt(norm);
+        }
+        const std::vector<double> re0 = re, im0 = im;
+        PlannerDit64 planner = PlannerDit64::with_mode(n, PlannerMode::Tune);
+        fft_64_dit_with_planner(re, im, Direction::Forward, planner);
+        fft_64_dit_with_planner_and_opts(re, im, Direction::Reverse, planner, Options::guess_options(n));
+        for (size_t i = 0; i < n; ++i) EXPECT(std::fabs(re[i] - re0[i]) < 1e-10 && std::fabs(im[i] - im0[i]) < 1e-10);
+        std::vector<float> fr(re0.begin(), re0.end()), fi(im0.begin(), im0.end());
+        const std::vector<float> fr0 = fr, fi0 = fi;
+        fft_32_dit(fr, fi, Direction::Forward);
+        fft_32_dit(fr, fi, Direction::Reverse);
+        for (size_t i = 0; i < n; ++i) EXPECT(std::fabs(fr[i] - fr0[i]) < 1e-6f && std::fabs(fi[i] - fi0[i]) < 1e-6f);
+    }
+    // ---- wrong_num_points_in_planner (lib.rs:259-296) and mismatched slices ----
+    {
+        PlannerDit64 planner(16);
+        std::vector<double> re(1 << 16), im(1 << 16);
+        EXPECT(panic_message([&] { fft_64_dit_with_planner(re, im, Direction::Forward, planner); }) ==
+               "assertion `left == right` failed: log_n == planner.log_n");
+        std::vector<double> a(8), b(16);
+        EXPECT(panic_message([&] { fft_64_dit(a, b, Direction::Forward); }) ==
+               "assertion `left == right` failed: reals.len() == imags.len()");
+    }
+    // ---- interleaved == planar (lib.rs:340-378) ----
+    {
+        const size_t n = 1024;
+        std::vector<std::complex<double>> sig(n);
+        std::vector<double> re(n), im(n, 0.0);
+        for (size_t i = 0; i < n; ++i) {
+            sig[i] = {double(i + 1), 0.0};
+            re[i] = double(i + 1);
+        }
+        fft_64_interleaved(sig, Direction::Forward);
+        fft_64_dit(re, im, Direction::Forward);
+        for (size_t i = 0; i < n; ++i) EXPECT(std::fabs(sig[i].real() - re[i]) < 1e-10 * 1e6 && std::fabs(sig[i].imag() - im[i]) < 1e-10 * 1e6);
+    }
+    // ---- R2C known answers and panics (r2c.rs:1235-1540), R2C -> C2R round trip (r2c.rs:958-976) ----
+    {
+        const size_t n = 16, half = 8;
+        std::vector<double> in(n, 1.0), ore(half + 1, 7.0), oim(half + 1, 7.0);
+        r2c_fft_f64(in, ore, oim);  // dc_only
+        EXPECT(std::fabs(ore[0] - double(n)) < 1e-10);
+        for (size_t k = 1; k <= half; ++k) EXPECT(std::fabs(ore[k]) < 1e-10 && std::fabs(oim[k]) < 1e-10);
+        for (size_t i = 0; i < n; ++i) in[i] = (i % 2 == 0) ? 1.0 : -1.0;  // nyquist_only
+        r2c_fft_f64(in, ore, oim);
+        for (size_t k = 0; k <= half; ++k) EXPECT(std::fabs(ore[k] - (k == half ? double(n) : 0.0)) < 1e-10 && std::fabs(oim[k]) < 1e-10);
+        std::vector<double> bad(half);
+        EXPECT(panic_message([&] { r2c_fft_f64(in, bad, oim); }) == "output_re must have length N/2 + 1");
+        EXPECT(panic_message([&] { r2c_fft_f64(in, ore, bad); }) == "output_im must have length N/2 + 1");
+        PlannerR2c64 planner(n);
+        std::vector<double> shortin(8);
+        EXPECT(panic_message([&] { r2c_fft_f64_with_planner(shortin, ore, oim, planner); }) == "input length must match planner size");
+        std::vector<double> out(n), s7(7), s8(8);
+        EXPECT(panic_message([&] { c2r_fft_f64_with_planner_and_scratch(ore, oim, out, planner, s7, s8); }) == "scratch_re must have length N/2");
+        EXPECT(panic_message([&] { c2r_fft_f64_with_planner_and_scratch(ore, oim, out, planner, s8, s7); }) == "scratch_im must have length N/2");
+        EXPECT(panic_message([&] { c2r_fft_f64(bad, oim, out); }) == "input_re must have length N/2 + 1");
+        EXPECT(panic_message([&] { c2r_fft_f64(ore, bad, out); }) == "input_im must have length N/2 + 1");
+        EXPECT(panic_message([&] { c2r_fft_f64_with_planner(ore, oim, s8, planner); }) == "output length must match planner size");
+    }
+    for (int k = 2; k <= 16; ++k) {
+        const size_t n = size_t(1) << k;
+        std::vector<double> x(n), ore(n / 2 + 1), oim(n / 2 + 1), back(n);
+        for (size_t i = 0; i < n; ++i) x[i] = double(i + 1);
+        r2c_fft_f64(x, ore, oim);
+        c2r_fft_f64(ore, oim, back);
+        for (size_t i = 0; i < n; ++i) EXPECT(std::fabs(back[i] - x[i]) < 1e-6);
+        std::vector<float> xf(x.begin(), x.end()), fre(n / 2 + 1), fim(n / 2 + 1), fback(n);
+        r2c_fft_f32(xf, fre, fim);
+        c2r_fft_f32(fre, fim, fback);
+        for (size_t i = 0; i < n; ++i) EXPECT(std::fabs(fback[i] - xf[i]) < 1e-2f * (1.0f + std::fabs(xf[i])));
+    }
+    // ---- bit reversal exact (bravo.rs:373-407) ----
+    for (unsigned nb = 2; nb <= 18; ++nb) {
+        const size_t n = size_t(1) << nb;
+        std::vector<double> d(n);
+        for (size_t i = 0; i < n; ++i) d[i] = double(i);
+        bit_rev_bravo_f64(d, nb);
+        bool ok = true;
+        for (size_t i = 0; i < n && ok; ++i) {
+            size_t r = 0;
+            for (unsigned b = 0; b < nb; ++b) r |= ((i >> b) & 1) << (nb - 1 - b);
+            ok = d[i] == double(r);
+        }
+        EXPECT(ok);
+    }
+    std::printf("host_api_test (GPU): %d failure(s)\n", failures);
+    return failures ? 1 : 0;
+}

@@ -402,3 +402,52 @@ def test_large_sizes_properties(gpu, k, dt):
     fwd(re, im, gpu.Direction.Reverse, planner)
     lim = 1e-10 if dt == "f64" else 2e-5
     assert float((re - re0).abs().max()) < lim and float((im - im0).abs().max()) < lim
+
+
+def test_strided_batches_and_untouched_gaps(gpu, oracle):
+    """Batched device path with dist > n: every transform right, the gaps between transforms untouched; both
+    plan families (small-LDS kernel at 2^9, tile passes at 2^13)."""
+    import torch
+
+    for k, batch, gap in ((9, 5, 7), (13, 3, 64), (16, 2, 8)):
+        n = 1 << k
+        dist = n + gap
+        total = (batch - 1) * dist + n
+        re = torch.full((total,), 123.0, dtype=torch.float64, device="cuda")
+        im = torch.full((total,), -321.0, dtype=torch.float64, device="cuda")
+        for b in range(batch):
+            r, m = oracle.fill(n, np.float64, transform_id=50 + b)
+            re[b * dist:b * dist + n] = torch.from_numpy(r).cuda()
+            im[b * dist:b * dist + n] = torch.from_numpy(m).cuda()
+        planner = gpu.PlannerDit64(n)
+        gpu.fft_dit_batched(re, im, n, gpu.Direction.Forward, planner, dist=dist)
+        hre, him = re.cpu().numpy(), im.cpu().numpy()
+        for b in range(batch):
+            r, m = oracle.fill(n, np.float64, transform_id=50 + b)
+            oracle.fft_64_dit(r, m, oracle.FORWARD)
+            assert rel_l2(hre[b * dist:b * dist + n], him[b * dist:b * dist + n], r, m) <= F64_REL, (k, b)
+            if b + 1 < batch:
+                assert np.all(hre[b * dist + n:(b + 1) * dist] == 123.0) and np.all(him[b * dist + n:(b + 1) * dist] == -321.0)
+
+
+def test_batched_r2c_c2r(gpu, oracle):
+    import torch
+
+    for k, batch in ((8, 9), (14, 5)):
+        n = 1 << k
+        x = torch.empty(batch * n, dtype=torch.float32, device="cuda")
+        gpu.fill_uniform(x, None, n, seed=0xCAFE, first_id=300)
+        ore = torch.empty(batch * (n // 2 + 1), dtype=torch.float32, device="cuda")
+        oim = torch.empty_like(ore)
+        planner = gpu.PlannerR2c32(n)
+        gpu.r2c_fft_batched(x, ore, oim, planner, batch)
+        hre, him = ore.cpu().numpy(), oim.cpu().numpy()
+        for b in range(batch):
+            hx, _ = oracle.fill(n, np.float32, seed=0xCAFE, transform_id=300 + b)
+            rr, ri = np.zeros(n // 2 + 1, np.float32), np.zeros(n // 2 + 1, np.float32)
+            oracle.r2c_fft_f32(hx, rr, ri)
+            sl = slice(b * (n // 2 + 1), (b + 1) * (n // 2 + 1))
+            assert rel_l2(hre[sl], him[sl], rr, ri) <= F32_REL, (k, b)
+        back = torch.empty_like(x)
+        gpu.c2r_fft_batched(ore, oim, back, planner, batch)
+        assert float((back - x).abs().max()) < 1e-5
