@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly from Python")
     ap.add_argument("--shard", type=int, default=SHARD, help="transforms per GPU when --gpus > 1")
     ap.add_argument("--extra", action="store_true", help="also measure N=2^26 and the batched shard at --gpus 1")
+    ap.add_argument("--plan", default=None, help="experiment: force a plan, e.g. 6,8,6@12p8 (default: the library's own)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for dry runs)")
     ap.add_argument("--same-gpu", action="store_true", help="dry run: every rank uses cuda:0 (needs --backend gloo)")
     return ap.parse_args()
@@ -63,11 +64,55 @@ def cpu_baseline(budget_s: float = 12.0):
     per = max(t1 / 3, 1e-4)
     iters = max(10, min(2000, int(budget_s / per)))
     total = O.time_fft_64_dit(N, iters)
+    # the crate's optional `parallel` feature emulated: a short second leg, reported beside
+    # the default-features number above, never instead of it
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    best = None
+    for threads in [c for c in (2, 4, 8, 16, 32, 64) if c <= avail] or [1]:
+        O.time_fft_64_dit_parallel(N, 2, threads=threads)
+        p_iters = max(5, min(200, int(0.04 * budget_s / per)))
+        p_total = O.time_fft_64_dit_parallel(N, p_iters, threads=threads)
+        if best is None or p_total / p_iters < best[1] / best[2]:
+            best = (threads, p_total, p_iters)
+    threads, p_total, p_iters = best
     return {
         "value": iters * N / total / 1e9, "unit": "GSamples/s", "cores": 1, "kind": "port",
         "sample": f"{iters} forward fft_64_dit_with_planner calls at N=2^{LOG_N} "
                   f"({total:.1f} s of CPU work, {1e3 * total / iters:.2f} ms each), oracle/ C restatement, 1 thread",
+        "parallel_feature": {"value": p_iters * N / p_total / 1e9, "unit": "GSamples/s", "cores": threads,
+                             "sample": f"{p_iters} calls, {1e3 * p_total / p_iters:.2f} ms each, best of 2..64 threads "
+                                       f"({avail} schedulable); rayon::join emulated with OpenMP tasks (2-way bit "
+                                       f"reversal, recursive join while size > 16384, spanning stages serial)"},
     }
+
+
+def kernel_tags(plan_text: str, latency: bool):
+    """'<double, LR, LC, LP,' template-argument prefixes of the pass kernels of the plan that ran, parsed from
+    planner.describe() -- used to check that a committed PMC profile belongs to this plan."""
+    import math
+    import re
+
+    part = plan_text.split("latency=")[1] if (latency and "latency=" in plan_text) else plan_text.split("latency=")[0]
+    tags = []
+    for rows, cols, pts in re.findall(r"\[(\d+)x(\d+)A? p(\d+)", part):
+        tags.append(f"<double, {int(math.log2(int(rows)))}, {int(math.log2(int(cols)))}, {int(math.log2(int(pts)))},")
+    return tags
+
+
+def hbm_copy_probe(torch, dev, mib: int = 1024, reps: int = 10):
+    """Device-to-device copy of ``mib`` MiB (read + write counted): what this box's HBM gives a plain streaming
+    kernel, reported beside the 8 TB/s spec peak (SURVEY.md 8d "bounding roofline")."""
+    src = torch.empty(mib << 17, dtype=torch.float64, device=dev).fill_(1.0)
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * src.numel() * 8 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
 def main():
@@ -98,6 +143,10 @@ def main():
 
     dev = torch.device("cuda", local_rank if multi else 0)
     planner = P.PlannerDit64(N)
+    if args.plan:
+        lrs_s, rest = args.plan.split("@")
+        tl_s, p_s = rest.split("p")
+        planner.set_plan(tuple(int(x) for x in lrs_s.split(",")), int(tl_s), {8: 3, 16: 4, 32: 5}[int(p_s)])
     plan_text = planner.describe()
 
     if n_gpus == 1:
@@ -236,9 +285,13 @@ def main():
         if n_gpus > 1:
             out["config"]["digest_gather"] = f"all_gather of {samples_per_step // N} x 32 B digests over RCCL"
             out["config"]["digest_ok"] = digest_ok
-        traffic = load_profiled_traffic(n_gpus)
+        traffic = load_profiled_traffic(n_gpus, dom, len(pass_ms), kernel_tags(plan_text, n_gpus == 1))
         if traffic is not None:
             roofline.update(traffic)
+        if n_gpus == 1:
+            probe = hbm_copy_probe(torch, dev)
+            roofline["copy_probe_GBps"] = probe          # measured d2d copy rate of this box, same run
+            roofline["frac_of_copy_probe"] = achieved / probe
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         if n_gpus == 1 and args.extra:
@@ -251,7 +304,7 @@ def main():
         dist.destroy_process_group()
 
 
-def load_profiled_traffic(n_gpus):
+def load_profiled_traffic(n_gpus, dom, n_passes, kernel_tags):
     """HBM bytes per launch of the dominant pass kernel from the rocprofv3 PMC runs committed under
     profiles/ (FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md's HBM
     section prescribes for gfx950).  bench.py cannot collect PMC counters itself; the file records which
@@ -265,12 +318,29 @@ def load_profiled_traffic(n_gpus):
     key = "single_2p20" if n_gpus == 1 else "batch_2p20"
     if key not in t:
         return None
-    return {"traffic": t[key]["hbm_bytes_per_launch"], "traffic_source": t[key]["source"]}
+    ks = t[key].get("kernels", [])
+    if len(ks) != n_passes or any(tag not in ks[i]["kernel"] for i, tag in enumerate(kernel_tags)):
+        return None  # the profile was taken with another plan
+    return {"traffic": ks[dom]["hbm_bytes_per_launch"], "traffic_source": t[key]["source"],
+            "traffic_kernel": ks[dom]["kernel"]}
 
 
 def extra_measurements(P, torch, dev):
-    """N=2^26 single transform and the 1024-transform shard on one GPU (reported beside the headline)."""
+    """The other BASELINE configs on one GPU, reported beside the headline: N=2^26 forward and the forward+inverse
+    round trip (configs[2]), f32 R2C at N=2^24 (configs[3]), one GPU's 1024-transform shard (configs[4]), and the
+    host-slice (drop-in, PCIe-inclusive) call at N=2^20."""
+    import numpy as np
+
     res = {}
+
+    def wall(fn, reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / reps
+
     n26 = 1 << 26
     pl = P.PlannerDit64(n26)
     re = torch.empty(n26, dtype=torch.float64, device=dev)
@@ -281,8 +351,45 @@ def extra_measurements(P, torch, dev):
     ms = pl.time_passes(re, im, n26, reps=3)
     res["n2p26_single"] = {"plan": pl.describe(), "pass_ms": ms, "gsamples_per_s": n26 / (sum(ms) * 1e-3) / 1e9,
                            "transform_frac": 32 * n26 / (sum(ms) * 1e-3) / 1e9 / HBM_PEAK_GBS}
-    del re, im, pl
+    # configs[2]: forward + inverse round trip on the same buffers, error against the input
+    P.fill_uniform(re, im, n26)
+    ref_re, ref_im = re.clone(), im.clone()
+
+    def roundtrip():
+        P.fft_64_dit_with_planner(re, im, P.Direction.Forward, pl)
+        P.fft_64_dit_with_planner(re, im, P.Direction.Reverse, pl)
+
+    roundtrip()
+    ms_rt = wall(roundtrip, 3)
+    err = max(float((re - ref_re).abs().max()), float((im - ref_im).abs().max()))
+    res["n2p26_roundtrip"] = {"ms": ms_rt, "gsamples_per_s": 2 * n26 / (ms_rt * 1e-3) / 1e9,
+                              "max_abs_err_after_4_roundtrips": err}
+    del re, im, pl, ref_re, ref_im
+    # configs[3]: f32 R2C, N=2^24 (algorithmic bytes 4N + 8(N/2+1))
+    n24 = 1 << 24
+    plr = P.PlannerR2c32(n24)
+    x = torch.empty(n24, dtype=torch.float32, device=dev)
+    P.fill_uniform(x, None, n24)
+    ore = torch.empty(n24 // 2 + 1, dtype=torch.float32, device=dev)
+    oim = torch.empty_like(ore)
+    P.r2c_fft_f32_with_planner(x, ore, oim, plr)
+    ms_r2c = wall(lambda: P.r2c_fft_f32_with_planner(x, ore, oim, plr), 20)
+    r2c_bytes = 4 * n24 + 8 * (n24 // 2 + 1)
+    res["r2c_f32_2p24"] = {"ms": ms_r2c, "gsamples_per_s": n24 / (ms_r2c * 1e-3) / 1e9,
+                           "algorithmic_GBps": r2c_bytes / (ms_r2c * 1e-3) / 1e9,
+                           "transform_frac": r2c_bytes / (ms_r2c * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    del x, ore, oim, plr
+    # the drop-in call on host slices: H2D + transform + D2H, blocking (never the headline value)
     pl = P.PlannerDit64(N)
+    h_re = np.random.default_rng(1).uniform(-1, 1, N)
+    h_im = np.random.default_rng(2).uniform(-1, 1, N)
+    P.fft_64_dit_with_planner(h_re, h_im, P.Direction.Forward, pl)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        P.fft_64_dit_with_planner(h_re, h_im, P.Direction.Forward, pl)
+    ms_host = 1e3 * (time.perf_counter() - t0) / 5
+    res["n2p20_host_slices"] = {"ms": ms_host, "gsamples_per_s": N / (ms_host * 1e-3) / 1e9,
+                                "note": "pageable numpy arrays, PCIe both ways inside the call"}
     re = torch.empty(SHARD * N, dtype=torch.float64, device=dev)
     im = torch.empty_like(re)
     P.fill_uniform(re, im, N)

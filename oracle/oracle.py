@@ -49,6 +49,8 @@ def lib() -> C.CDLL:
         _lib.pho_strerror.restype = C.c_char_p
         _lib.pho_time_fft_64_dit.restype = C.c_double
         _lib.pho_time_fft_64_dit.argtypes = [C.c_size_t, C.c_int, C.c_ulonglong]
+        _lib.pho_time_fft_64_dit_parallel.restype = C.c_double
+        _lib.pho_time_fft_64_dit_parallel.argtypes = [C.c_size_t, C.c_int, C.c_ulonglong, C.c_int]
         _lib.pho_time_r2c_fft_f32.restype = C.c_double
         _lib.pho_time_r2c_fft_f32.argtypes = [C.c_size_t, C.c_int, C.c_ulonglong]
         for name in ("pho_planner_dit64_stage", "pho_planner_dit32_stage"):
@@ -151,6 +153,19 @@ def fft_64_dit(reals, imags, direction=FORWARD):
 
 def fft_32_dit(reals, imags, direction=FORWARD):
     _fft("pho_fft_32_dit", np.float32, reals, imags, direction)
+
+
+def fft_64_dit_with_planner_parallel(reals, imags, direction, planner: PlannerDit64):
+    """feature ``parallel`` emulated (rayon::join -> OpenMP tasks); bit-identical to the serial call."""
+    _req(reals, np.float64), _req(imags, np.float64)
+    _check(lib().pho_fft_64_dit_with_planner_parallel(_p(reals), _sz(reals.size), _p(imags), _sz(imags.size),
+                                                      C.c_int(direction), planner._h))
+
+
+def fft_32_dit_with_planner_parallel(reals, imags, direction, planner: PlannerDit32):
+    _req(reals, np.float32), _req(imags, np.float32)
+    _check(lib().pho_fft_32_dit_with_planner_parallel(_p(reals), _sz(reals.size), _p(imags), _sz(imags.size),
+                                                      C.c_int(direction), planner._h))
 
 
 def fft_64_dit_with_planner(reals, imags, direction, planner: PlannerDit64):
@@ -262,6 +277,14 @@ def fill(n: int, dtype, seed: int = 0xCAFE, transform_id: int = 0):
 
 def time_fft_64_dit(n: int, iters: int, seed: int = 0xCAFE) -> float:
     return lib().pho_time_fft_64_dit(n, iters, seed)
+
+
+def time_fft_64_dit_parallel(n: int, iters: int, seed: int = 0xCAFE, threads: int = 0) -> float:
+    return lib().pho_time_fft_64_dit_parallel(n, iters, seed, threads)
+
+
+def parallel_threads() -> int:
+    return lib().pho_parallel_threads()
 
 
 def time_r2c_fft_f32(n: int, iters: int, seed: int = 0xCAFE) -> float:

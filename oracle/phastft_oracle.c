@@ -7,6 +7,7 @@
 #include "phastft_oracle.h"
 
 #include <math.h>
+#include <omp.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -171,7 +172,15 @@ static double pho_now(void) {
     return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
-double pho_time_fft_64_dit(size_t n, int iters, unsigned long long seed) {
+static double time_fft_64(size_t n, int iters, unsigned long long seed, int par);
+double pho_time_fft_64_dit(size_t n, int iters, unsigned long long seed) { return time_fft_64(n, iters, seed, 0); }
+double pho_time_fft_64_dit_parallel(size_t n, int iters, unsigned long long seed, int threads) {
+    if (threads > 0) omp_set_num_threads(threads);
+    return time_fft_64(n, iters, seed, 1);
+}
+int pho_parallel_threads(void) { return omp_get_max_threads(); }
+
+static double time_fft_64(size_t n, int iters, unsigned long long seed, int par) {
     pho_planner_dit64 *planner;
     if (pho_planner_dit64_new(n, &planner)) return -1.0;
     double *re = malloc(n * sizeof(double)), *im = malloc(n * sizeof(double));
@@ -179,7 +188,8 @@ double pho_time_fft_64_dit(size_t n, int iters, unsigned long long seed) {
     for (int it = 0; it < iters && re && im; ++it) {
         pho_fill_f64(re, im, n, seed, (unsigned long long)it);
         double t0 = pho_now();
-        pho_fft_64_dit_with_planner(re, n, im, n, PHO_FORWARD, planner);
+        if (par) pho_fft_64_dit_with_planner_parallel(re, n, im, n, PHO_FORWARD, planner);
+        else pho_fft_64_dit_with_planner(re, n, im, n, PHO_FORWARD, planner);
         total += pho_now() - t0;
     }
     free(re);

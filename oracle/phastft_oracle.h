@@ -85,6 +85,14 @@ int pho_fft_64_dit_with_planner(double *reals, size_t re_len, double *imags, siz
 int pho_fft_32_dit_with_planner(float *reals, size_t re_len, float *imags, size_t im_len, int direction,
                                 const pho_planner_dit32 *planner);
 
+/* the same with the crate's optional `parallel` feature emulated (Cargo.toml:34, parallel.rs:6-25): two-way
+ * join of the bit reversals when log2 N >= 16, recursive two-way join while size > 16384, the stages spanning
+ * both halves serial.  Results are bit-identical to the single-threaded entry points. */
+int pho_fft_64_dit_with_planner_parallel(double *reals, size_t re_len, double *imags, size_t im_len, int direction,
+                                         const pho_planner_dit64 *planner);
+int pho_fft_32_dit_with_planner_parallel(float *reals, size_t re_len, float *imags, size_t im_len, int direction,
+                                         const pho_planner_dit32 *planner);
+
 /* algorithms/bravo.rs:303-345 (bench-internals surface) */
 void pho_bit_rev_f64(double *data, unsigned log_n);
 void pho_bit_rev_f32(float *data, unsigned log_n);
@@ -136,6 +144,8 @@ const char *pho_strerror(int code);
  * examples/benchmark.rs:19-63 does; returns the SUM of the timed seconds.
  */
 double pho_time_fft_64_dit(size_t n, int iters, unsigned long long seed);
+double pho_time_fft_64_dit_parallel(size_t n, int iters, unsigned long long seed, int threads); /* feature `parallel` emulated; threads <= 0: OpenMP default */
+int pho_parallel_threads(void);
 double pho_time_r2c_fft_f32(size_t n, int iters, unsigned long long seed);
 
 /* counter-based synthetic input shared with the HIP fill kernel:

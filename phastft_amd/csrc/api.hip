@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <mutex>
 #include <new>
 #include <string>
@@ -142,7 +143,6 @@ template <typename T> struct Planner {
     unsigned log_n = 0;
     std::vector<PassDesc> passes;      // throughput plan; empty => small path
     std::vector<PassDesc> passes_lat;  // latency plan (one small transform); may equal `passes`
-    static constexpr size_t kLatencyWork = (size_t)1 << 22;  // batch*n below this uses the latency plan
     void *d_small_tw = nullptr;
     mutable T *d_scratch = nullptr;  // [cap][2][n]: re plane then im plane per transform
     mutable size_t scratch_cap = 0;
@@ -171,10 +171,18 @@ template <typename T> struct Planner {
         scratch_cap = 0;
     }
 
+    // the latency plan serves batches too small to fill the chip with the throughput plan's tiles
+    bool use_latency_plan(size_t batch) const {
+        if (passes_lat.empty() || passes.empty()) return false;
+        unsigned tl = 0;
+        for (const PassDesc &p : passes) tl = std::max(tl, p.lr + p.lc);
+        return batch * n < throughput_work(tl);
+    }
+
     // which: 0 = both plans, 1 = throughput plan only, 2 = latency plan only; lp = log2(points per thread)
     int set_plan(const std::vector<unsigned> &lrs, const std::vector<unsigned> &tls, int which = 0, unsigned lp = 4) {
         std::vector<PassGeom> geo;
-        if (!make_passes(log_n, lrs, tls, geo, lp)) return PHAST_ERR_INVALID_ARG;
+        if (!make_passes(log_n, lrs, tls, geo, lp, sizeof(T))) return PHAST_ERR_INVALID_ARG;
         std::vector<PassDesc> ps(geo.size());
         for (size_t i = 0; i < geo.size(); ++i) static_cast<PassGeom &>(ps[i]) = geo[i];
         size_t tb = 0;
@@ -226,14 +234,18 @@ template <typename T> struct Planner {
             table_bytes = h.size() * sizeof(cx_t<T>);
             return upload<T>(h, &d_small_tw);
         }
-        std::vector<unsigned> lrs, tls, lrs_l, tls_l;
-        heuristic_plan<T>(log_n, false, lrs, tls);
-        rc = set_plan(lrs, tls, 1);
+        return default_plans();
+    }
+
+    // the library's own two plans (plan.hpp: heuristic_plan)
+    int default_plans() {
+        std::vector<unsigned> lrs, tls;
+        unsigned lp = 4;
+        heuristic_plan<T>(log_n, false, lrs, tls, lp);
+        int rc = set_plan(lrs, tls, 1, lp);
         if (rc) return rc;
-        heuristic_plan<T>(log_n, true, lrs_l, tls_l);
-        // latency plan: 8 points per thread (twice the waves) when those tiles exist, else 16
-        if (set_plan(lrs_l, tls_l, 2, 3) != PHAST_OK && (lrs_l != lrs || tls_l != tls)) rc = set_plan(lrs_l, tls_l, 2, 4);
-        return rc;
+        heuristic_plan<T>(log_n, true, lrs, tls, lp);
+        return set_plan(lrs, tls, 2, lp);
     }
 
     // scratch for `want` transforms in flight (capped by the target footprint, at least 1)
@@ -320,7 +332,7 @@ template <typename T> struct Planner {
         if (rc) return rc;
         T *s_re = d_scratch;               // plane layout: all re planes, then all im planes
         T *s_im = d_scratch + cap * n;
-        const std::vector<PassDesc> &passes = (!passes_lat.empty() && batch * n < kLatencyWork) ? passes_lat : this->passes;
+        const std::vector<PassDesc> &passes = use_latency_plan(batch) ? passes_lat : this->passes;
         const size_t np = passes.size();
         for (size_t b0 = 0; b0 < batch; b0 += cap) {
             const size_t nb = batch - b0 < cap ? batch - b0 : cap;
@@ -519,7 +531,7 @@ template <typename T>
 static int time_passes(const Planner<T> *pl, T *d_re, T *d_im, size_t batch, size_t dist, int reps, float *pass_ms,
                        int *n_passes, hipStream_t s) {
     if (!pl || !d_re || !d_im || !pass_ms || !n_passes || reps < 1) return PHAST_ERR_INVALID_ARG;
-    const bool lat = !pl->passes_lat.empty() && batch * pl->n < Planner<T>::kLatencyWork;
+    const bool lat = pl->use_latency_plan(batch);
     const int np = pl->passes.empty() ? 1 : (int)(lat ? pl->passes_lat.size() : pl->passes.size());
     double acc[3] = {0, 0, 0};
     for (int r = 0; r < reps; ++r) {
@@ -688,19 +700,13 @@ static int set_plan_c(Planner<T> *p, const unsigned *log_rows, const unsigned *t
     if (p->log_n <= kSmallMaxLog) return n_passes == 0 ? PHAST_OK : PHAST_ERR_INVALID_ARG;
     std::vector<unsigned> lrs, tls;
     if (n_passes == 0) {
-        heuristic_plan<T>(p->log_n, false, lrs, tls);
-        int rc = p->set_plan(lrs, tls, 1);
-        if (rc) return rc;
-        std::vector<unsigned> lrs_l, tls_l;
-        heuristic_plan<T>(p->log_n, true, lrs_l, tls_l);
-        if (p->set_plan(lrs_l, tls_l, 2, 3) == PHAST_OK) return PHAST_OK;
-        return (lrs_l != lrs || tls_l != tls) ? p->set_plan(lrs_l, tls_l, 2, 4) : PHAST_OK;
+        return p->default_plans();
     } else {
         if (!log_rows || !tile_logs) return PHAST_ERR_INVALID_ARG;
         lrs.assign(log_rows, log_rows + n_passes);
         tls.assign(tile_logs, tile_logs + n_passes);
     }
-    if (points_log != 3 && points_log != 4) return PHAST_ERR_INVALID_ARG;
+    if (points_log < 3 || points_log > 5) return PHAST_ERR_INVALID_ARG;
     return p->set_plan(lrs, tls, 0, points_log);
 }
 

@@ -94,15 +94,25 @@ template <typename T> inline std::vector<cx_t<T>> host_small_tw(size_t n) {
 
 // ---- tile shapes that exist as kernels: log2(rows), log2(cols) ----
 // log2(rows), log2(cols), log2(points per thread).  16 points per thread: 4096-, 8192- and 16384-point tiles
-// (256 / 512 / 1024 threads); 8 points per thread: 4096-point tiles with 512 threads (latency plans).
+// (256 / 512 / 1024 threads); 8 points per thread: 4096-point tiles with 512 threads (latency plans); 32 points
+// per thread: 16384-point tiles with 512 threads (rows twice as wide at the same thread count, one LDS exchange
+// fewer for 1024-point tile FFTs), plus the 8192- and 4096-point forms for comparison.
 #define PHAST_TILE_SHAPES(X)                                                                                  \
     X(6, 6, 4) X(7, 5, 4) X(8, 4, 4) X(9, 3, 4) X(10, 2, 4) X(7, 6, 4) X(8, 5, 4) X(9, 4, 4) X(10, 3, 4)      \
-    X(8, 6, 4) X(9, 5, 4) X(10, 4, 4) X(6, 6, 3) X(7, 5, 3) X(8, 4, 3) X(9, 3, 3) X(10, 2, 3)
+    X(8, 6, 4) X(9, 5, 4) X(10, 4, 4) X(6, 6, 3) X(7, 5, 3) X(8, 4, 3) X(9, 3, 3) X(10, 2, 3)                 \
+    X(10, 4, 5) X(9, 5, 5) X(8, 6, 5) X(10, 3, 5) X(9, 4, 5) X(8, 5, 5) X(10, 2, 5)
 
-inline bool shape_exists(unsigned lr, unsigned lc, unsigned lp = 4) {
+// 4-byte elements only: 32768-point tiles (1024 threads x 32 points), rows twice as wide again; an f64 tile
+// of that size does not fit the LDS.
+#define PHAST_TILE_SHAPES_F32(X) X(10, 5, 5) X(9, 6, 5) X(8, 7, 5)
+
+inline bool shape_exists(unsigned lr, unsigned lc, unsigned lp, size_t elem_bytes) {
 #define PHAST_CHK(LR_, LC_, LP_) \
     if (lr == LR_ && lc == LC_ && lp == LP_) return true;
     PHAST_TILE_SHAPES(PHAST_CHK)
+    if (elem_bytes == 4) {
+        PHAST_TILE_SHAPES_F32(PHAST_CHK)
+    }
 #undef PHAST_CHK
     return false;
 }
@@ -117,39 +127,65 @@ struct PassGeom {
     unsigned log_mod() const { return lr + log_s_in; }  // the inter-pass twiddle is W_{2^log_mod}^{row*lo}
 };
 
-// Default factorisations of L = log2 N (L > kSmallMaxLog), from the MI355X sweeps in profiles/ (DESIGN.md
-// section 5).  What the sweeps say: a pass runs at the copy rate of its access pattern, and that rate is set
-// by the contiguous segment a tile row covers (f64: 64 B ~3.0-3.7 TB/s, 128 B ~4.4, >= 256 B ~5.0-5.8), so
-//   * `throughput` (many transforms in flight): as few passes as possible while rows stay >= 128 B wide,
-//     8192-point tiles; N = 2^19, 2^20 take two 1024 x 8 passes (one fewer pass beats wider rows there);
+// Default factorisations of L = log2 N (L > kSmallMaxLog), from the exhaustive MI355X sweeps in profiles/
+// (r01_sweep_all_*.log).  What the sweeps say: a pass runs at the copy rate of its access
+// pattern, and that rate is set by the contiguous segment a tile row covers (64 B rows ~3.0-3.7 TB/s, 128 B ~4.4,
+// >= 256 B ~4.6-5.3; 64-byte-row WRITES are the worst case), so
+//   * `throughput` (>= kThroughputWork points in flight): as few passes as possible with the widest rows the
+//     register file and LDS allow -- 16384-point tiles with 32 points per thread where a tile FFT is 256..1024
+//     long, 8192-point tiles with 16 points per thread otherwise;
 //   * `latency` (one small transform: launch- and latency-bound, not bandwidth-bound): fewest passes with
-//     4096-point tiles so that every CU gets a workgroup.
+//     4096-point tiles and 8 points per thread, so that every CU gets a workgroup and every SIMD two waves.
+// `lp` = log2(points per thread) of the plan.
 template <typename T>
-inline void heuristic_plan(unsigned L, bool latency, std::vector<unsigned> &lrs, std::vector<unsigned> &tls) {
+inline void heuristic_plan(unsigned L, bool latency, std::vector<unsigned> &lrs, std::vector<unsigned> &tls, unsigned &lp) {
     lrs.clear();
     tls.assign(1, 12);
+    lp = 4;
     if (L <= kSmallMaxLog) return;
     auto split = [&](unsigned np) {
         lrs.clear();
         for (unsigned i = 0; i < np; ++i) lrs.push_back(L / np + (i < L % np ? 1 : 0));  // balanced, larger first
     };
     const bool f64 = sizeof(T) == 8;
-    if (latency && (f64 || L <= 16)) {
-        split(L <= 20 ? 2 : 3);
-        tls.assign(1, lrs[0] <= 10 ? 12 : 13);
+    if (latency) {
+        split(L <= 19 ? 2 : 3);
+        // three passes: short outer FFTs (64 x 64 tiles: 512-byte rows) around a longer middle one; measured
+        // 27.9 vs 31.6 us for one f64 2^20 against two 1024 x 4 passes (profiles/r01_sweep_all_f64_single.log)
+        if (lrs.size() == 3 && L - 2 * (L / 3) <= 8) lrs = {L / 3, L - 2 * (L / 3), L / 3};  // middle rows stay >= 16 wide
+        lp = 3;
         return;
     }
-    if (L <= 14) {  // 128 x 32 tiles and smaller: rows >= 128 B in both types
+    if (L <= 13) {  // 64 x 64 / 128 x 32 tiles: rows >= 128 B in both types
         split(2);
-        tls.assign(1, 12);
-    } else if (L <= 17 || (f64 && L <= 20)) {  // (three passes need L >= 18: tile FFTs are at least 64 long)
+    } else if (L <= (f64 ? 17u : 15u)) {
         split(2);
         tls.assign(1, 13);
-    } else {
+    } else if (L <= 20) {  // tile FFTs of 256..1024 points: 32 x 8 .. 32 x 32 in registers, one LDS exchange
+        split(2);
+        tls.assign(1, (!f64 && L >= 17) ? 15 : 14);  // f32: 32768-point tiles keep the rows at 128 B
+        lp = 5;
+    } else if (L <= 23) {  // (three passes need tile FFTs of at least 64 points)
         split(3);
-        // measured (profiles/r01_sweep_*): f64 wants 8192-point tiles from LR = 8 up, f32 only from LR = 9 up
-        tls.assign(1, lrs[0] <= (f64 ? 7u : 8u) ? 12 : 13);
+        if (!f64 && L % 3 == 1) std::swap(lrs[0], lrs[1]);  // f32: the odd one out in the middle (+2..8 %)
+        tls.assign(1, 13);
+    } else if (L <= 27 || !f64) {
+        split(3);
+        tls.assign(1, (!f64 && L >= 26) ? 15 : 14);
+        lp = 5;
+    } else {  // f64, L >= 28: the last pass's twiddle tables leave no room for a 16384-point tile
+        split(3);
+        if (L % 3 == 1) std::swap(lrs[0], lrs[1]);
+        tls.assign(1, 13);
+        lp = 5;
     }
+}
+
+// points in flight (batch * n) from which the throughput plan is used; below it the chip is better filled by the
+// latency plan's 4096-point tiles (measured crossovers, profiles/r01_sweep_batch_f64.log and the single-transform
+// sweeps: 8192- and 16384-point tiles win from 2^24 points on, 32768-point tiles from 2^25)
+inline size_t throughput_work(unsigned tile_log) {
+    return (size_t)1 << (tile_log >= 15 ? 25 : tile_log >= 13 ? 24 : 22);
 }
 
 // N = 2^L as 2 passes (a, b) or 3 passes (a, b, c):
@@ -157,7 +193,7 @@ inline void heuristic_plan(unsigned L, bool latency, std::vector<unsigned> &lrs,
 //              --C: FFT over u--> x[kc][kb][q]            (2 passes: S[r][q] --B--> x[kb][q])
 // `tile_logs` gives log2(points per tile) of every pass (one entry = the same for all passes).
 inline bool make_passes(unsigned L, const std::vector<unsigned> &lrs, const std::vector<unsigned> &tile_logs,
-                        std::vector<PassGeom> &ps, unsigned lp = 4) {
+                        std::vector<PassGeom> &ps, unsigned lp, size_t elem_bytes) {
     unsigned sum = 0;
     for (unsigned lr : lrs) sum += lr;
     if (lrs.size() < 2 || lrs.size() > 3 || sum != L) return false;
@@ -166,7 +202,7 @@ inline bool make_passes(unsigned L, const std::vector<unsigned> &lrs, const std:
     const unsigned a = lrs[0], b = lrs[1], c = lrs.size() == 3 ? lrs[2] : 0;
     for (size_t i = 0; i < lrs.size(); ++i) {
         const unsigned tl = tile_logs.size() == 1 ? tile_logs[0] : tile_logs[i];
-        if (lrs[i] > tl || !shape_exists(lrs[i], tl - lrs[i], lp)) return false;
+        if (lrs[i] > tl || !shape_exists(lrs[i], tl - lrs[i], lp, elem_bytes)) return false;
         ps[i].lr = lrs[i];
         ps[i].lc = tl - lrs[i];
         ps[i].lp = lp;

@@ -15,9 +15,12 @@ hipError_t launch_tile_mode(int lr, int lc, int lp, unsigned grid, hipStream_t s
                             bool query_only, int *blocks_per_cu, size_t *lds, hipEvent_t e0, hipEvent_t e1) {
 #define PHAST_CASE(LR_, LC_, LP_)                                                                                  \
     if (lr == LR_ && lc == LC_ && lp == LP_)                                                                       \
-        return launch_tile_inst<T, LR_, LC_, LP_, PRE_TW, TRANSPOSE, (sizeof(T) == 8 && LP_ == 4)>(                 \
+        return launch_tile_inst<T, LR_, LC_, LP_, PRE_TW, TRANSPOSE, plane_seq_v<T, LP_>>(                 \
             grid, stream, a, query_only, blocks_per_cu, lds, e0, e1);
     PHAST_TILE_SHAPES(PHAST_CASE)
+    if constexpr (sizeof(T) == 4) {
+        PHAST_TILE_SHAPES_F32(PHAST_CASE)
+    }
 #undef PHAST_CASE
     return hipErrorInvalidValue;
 }

@@ -28,7 +28,20 @@
 
 namespace phast {
 
-// ---- literal twiddles: (re, im) *= W_N^J = exp(-2*pi*i*J/N), N in {2,4,8,16}, 0 <= J < N/2 ----
+// ---- literal twiddles: (re, im) *= W_N^J = exp(-2*pi*i*J/N), N in {2,4,8,16,32}, 0 <= J < N/2 ----
+// cos(a*pi/16), a = 0..8, correctly rounded
+template <typename T> PHAST_HD constexpr T cos_pi16(int a) {
+    constexpr long double c[9] = {1.0L,
+                                  0.98078528040323044912618223613423903697L,
+                                  0.92387953251128675612818318939678828682L,
+                                  0.83146961230254523707878837761790575673L,
+                                  0.70710678118654752440084436210484903928L,
+                                  0.55557023301960222474283081394853287438L,
+                                  0.38268343236508977172845998403039886676L,
+                                  0.19509032201612826784828486847702224093L,
+                                  0.0L};
+    return a <= 8 ? (T)c[a] : (T)-c[16 - a];
+}
 template <typename T, int N, int J> PHAST_HD void mul_w(T &re, T &im) {
     constexpr T S = (T)0.70710678118654752440L;
     if constexpr (J == 0) {
@@ -47,11 +60,10 @@ template <typename T, int N, int J> PHAST_HD void mul_w(T &re, T &im) {
         re = r;
         im = i;
     } else {
-        static_assert(N == 16, "general twiddle only for N=16");
-        constexpr T C1 = (T)0.92387953251128675613L;  // cos(pi/8)
-        constexpr T S1 = (T)0.38268343236508977173L;  // sin(pi/8)
-        constexpr T c = (J == 1) ? C1 : (J == 3) ? S1 : (J == 5) ? -S1 : -C1;
-        constexpr T s = (J == 1 || J == 7) ? S1 : C1;
+        static_assert(N == 16 || N == 32, "general twiddle only for N = 16, 32");
+        constexpr int A = J * (32 / N);                 // angle in units of pi/16, 0 < A < 16
+        constexpr T c = cos_pi16<T>(A);
+        constexpr T s = cos_pi16<T>(A <= 8 ? 8 - A : A - 8);  // sin(A pi/16) = cos((8 - A) pi/16) > 0
         T r = re * c + im * s;
         T i = im * c - re * s;
         re = r;
@@ -116,7 +128,7 @@ template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool 
     // rows share their line with the neighbouring tile and NEED the L2 (nt loads cost 25 % there).
     static constexpr bool NT_HINT = COLS * sizeof(T) >= 128;
     static_assert(LR >= 6 && LR <= 10, "tile FFT length 64..1024");
-    static_assert(LP == 3 || LP == 4, "8 or 16 points per thread");
+    static_assert(LP >= 3 && LP <= 5, "8, 16 or 32 points per thread");
     static_assert(NT <= 1024 && NT >= 64, "64..1024 threads per workgroup");
     static_assert(S >= 2, "at least two radix steps (ROWS > P)");
 
@@ -165,7 +177,10 @@ template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool 
         const unsigned lo0 = r.g0 & ((1u << a.log_s_in) - 1u);
         const size_t ubase = (size_t)r.xform * a.in_dist + (((size_t)(r.g0 >> a.log_s_in) << (a.log_s_in + LR)) | lo0);
         const unsigned voff = ((unsigned)tau << a.log_s_in) + (unsigned)col;
-        if (!a.in_interleaved) {
+        // only a first pass (never PRE_TW) can see interleaved input, only a last pass (never TRANSPOSE) writes
+        // interleaved output: the other kernels do not carry those paths (they cost registers: 4-dword loads
+        // plus selects double the live state of a 32-point thread)
+        if (PRE_TW || !a.in_interleaved) {
             const T *pr = reinterpret_cast<const T *>(a.in_re) + ubase;
             const T *pi = reinterpret_cast<const T *>(a.in_im) + ubase;
             static_for<0, P>([&](auto j) {
@@ -199,6 +214,7 @@ template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool 
                 T wr, wi;
                 tw3_lookup<T>(sh.tw3, a.tw_bits, e0 + decltype(j)::value * de, wr, wi);
                 cmul(r.re[j], r.im[j], wr, wi);
+                if constexpr (P > 16 && (decltype(j)::value & 3) == 3) PHAST_SCHED_FENCE();
             });
         }
     }
@@ -223,6 +239,7 @@ template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool 
                     twr_lookup(sh, (n_rest * KI) << KB, wr, wi);
                     cmul(r.re[decltype(i)::value * R + decltype(p)::value], r.im[decltype(i)::value * R + decltype(p)::value],
                          wr, wi);
+                    if constexpr (P > 16 && (decltype(p)::value & 3) == 3) PHAST_SCHED_FENCE();
                 });
             });
         }
@@ -291,7 +308,7 @@ template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool 
     }
     PHAST_HD static void put(const TileArgs &a, size_t ubase, unsigned voff, T re, T im) {
         const T scale = (T)a.scale;
-        if (!a.out_interleaved) {
+        if (TRANSPOSE || !a.out_interleaved) {
             if constexpr (NT_HINT) {
                 __builtin_nontemporal_store(re * scale, reinterpret_cast<T *>(a.out_re) + ubase + voff);
                 __builtin_nontemporal_store(im * scale, reinterpret_cast<T *>(a.out_im) + ubase + voff);
@@ -342,6 +359,10 @@ template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool 
     }
 };
 
+// LDS exchange flavour per instantiation: f64 tiles with 16 points per thread and every 32-point tile exchange
+// the re and im planes one after the other (half the LDS); the rest exchange both planes at once.
+template <typename T, int LP> inline constexpr bool plane_seq_v = (sizeof(T) == 8 && LP == 4) || LP == 5;
+
 #ifndef PHAST_MIN_WAVES
 #define PHAST_MIN_WAVES(LR, LC) 1
 #endif
@@ -357,7 +378,7 @@ __global__ void __launch_bounds__(1 << (LR + LC - LP), PHAST_MIN_WAVES(LR, LC)) 
     cx *l_twr = l_tw3 + (PRE_TW ? (3u << a.tw_bits) : 0u);
     const typename Body::Shared sh{ex_re, Body::PLANE_SEQ ? ex_re : ex_re + Body::EXCH, l_tw3, l_twr};
 
-    const int tid = threadIdx.x;
+    int tid = threadIdx.x;
     // Phase stamps exist only in the -DPHAST_TRACE build (tools/trace_tile.py): even behind a uniform branch the
     // drains below wreck register allocation (256 VGPRs + 300 spills), so the product kernels carry none.
 #ifdef PHAST_TRACE
@@ -398,12 +419,17 @@ __global__ void __launch_bounds__(1 << (LR + LC - LP), PHAST_MIN_WAVES(LR, LC)) 
             Body::template ex_read<E>(sh, tid, r, 0);
             Body::template ex_read<E>(sh, tid, r, 1);
         } else {
-            for (int plane = 0; plane < 2; ++plane) {
-                __syncthreads();
-                Body::template ex_write<E>(sh, tid, r, plane);
-                __syncthreads();
-                Body::template ex_read<E>(sh, tid, r, plane);
-            }
+            // `plane` must be a literal at every call: a run-time plane makes &r.re / &r.im a select and sends
+            // the register arrays to scratch memory as soon as the compiler stops unrolling this loop (it does
+            // at 32 points per thread)
+            __syncthreads();
+            Body::template ex_write<E>(sh, tid, r, 0);
+            __syncthreads();
+            Body::template ex_read<E>(sh, tid, r, 0);
+            __syncthreads();
+            Body::template ex_write<E>(sh, tid, r, 1);
+            __syncthreads();
+            Body::template ex_read<E>(sh, tid, r, 1);
         }
         stamp();
     };
@@ -413,6 +439,10 @@ __global__ void __launch_bounds__(1 << (LR + LC - LP), PHAST_MIN_WAVES(LR, LC)) 
     };
 
     while (t < a.tiles_total) {
+        // Launder the thread id once per tile: everything derived from it (LDS exchange and twiddle-table
+        // addresses, ~100 values) is then recomputed per tile with a few integer ops instead of being hoisted out
+        // of this loop and kept live -- or spilled -- across it.
+        asm volatile("" : "+v"(tid));
         Body::pre_twiddle(a, sh, tid, r);
         stamp();  // 2: tile loaded (+ pre-twiddle)
         Body::chain(do_step, exchange);
@@ -436,6 +466,10 @@ hipError_t launch_tile_inst(unsigned grid, hipStream_t stream, const TileArgs &a
     if (lds_out) *lds_out = lds;
     // raise the dynamic-LDS limit only when it grows: the steady state issues no runtime call besides the
     // launch itself, so a launch sequence can be captured into a HIP graph
+    if (lds > (size_t)160 * 1024) {  // does not fit one CU: the planner rejects the plan, nothing is asked of HIP
+        if (query_only && blocks_per_cu) *blocks_per_cu = 0;
+        return query_only ? hipSuccess : hipErrorInvalidValue;
+    }
     static size_t lds_limit = 0;
     if (lds > lds_limit) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),

@@ -31,12 +31,14 @@ def run(emu, re, im, direction=1, lrs=(), tile_log=12, points_log=4):
 
 # (log2 rows, log2 cols, log2 points per thread) -- PHAST_TILE_SHAPES of csrc/plan.hpp
 SHAPES = [(6, 6, 4), (7, 5, 4), (8, 4, 4), (9, 3, 4), (10, 2, 4), (7, 6, 4), (8, 5, 4), (9, 4, 4), (10, 3, 4), (8, 6, 4),
-          (9, 5, 4), (10, 4, 4), (6, 6, 3), (7, 5, 3), (8, 4, 3), (9, 3, 3), (10, 2, 3)]
+          (9, 5, 4), (10, 4, 4), (6, 6, 3), (7, 5, 3), (8, 4, 3), (9, 3, 3), (10, 2, 3),
+          (10, 4, 5), (9, 5, 5), (8, 6, 5), (10, 3, 5), (9, 4, 5), (8, 5, 5), (10, 2, 5)]
+SHAPES_F32_ONLY = [(10, 5, 5), (9, 6, 5), (8, 7, 5)]  # PHAST_TILE_SHAPES_F32: 32768-point tiles
 
 
 @pytest.mark.parametrize("is_f64", [1, 0])
 def test_lds_exchanges_in_bounds_permutations_and_conflict_free(emu, is_f64):
-    for lr, lc, lp in SHAPES:
+    for lr, lc, lp in SHAPES + ([] if is_f64 else SHAPES_F32_ONLY):
         for transpose in (1, 0):
             r, w = C.c_int(), C.c_int()
             errors = emu.phast_emu_audit_lds(is_f64, lr, lc, lp, transpose, C.byref(r), C.byref(w))
@@ -49,7 +51,10 @@ PLANS = [(12, (6, 6), 12, 4), (13, (7, 6), 12, 4), (15, (8, 7), 12, 4), (16, (8,
          (20, (7, 7, 6), 12, 4), (18, (6, 6, 6), 12, 4), (21, (7, 7, 7), 13, 4), (22, (8, 7, 7), 13, 4),
          # 8 points per thread (latency tiles): every 4096-point shape, 2..4 radix steps
          (12, (6, 6), 12, 3), (13, (7, 6), 12, 3), (15, (8, 7), 12, 3), (17, (9, 8), 12, 3), (19, (10, 9), 12, 3),
-         (20, (10, 10), 12, 3), (21, (7, 7, 7), 12, 3)]
+         (20, (10, 10), 12, 3), (21, (7, 7, 7), 12, 3),
+         # 32 points per thread: 32x32, 32x16 and 32x8 chains, 16384-/8192-/4096-point tiles
+         (20, (10, 10), 14, 5), (19, (10, 9), 14, 5), (18, (9, 9), 13, 5), (16, (8, 8), 13, 5), (20, (10, 10), 12, 5),
+         (20, (10, 10), 13, 5)]
 
 
 @pytest.mark.parametrize("L,lrs,tl,lp", PLANS)
@@ -69,17 +74,29 @@ def test_default_plans_both_types_and_inverse(emu, oracle, L):
     for is_f64, dtype, tol, ofn in ((1, np.float64, 1e-13, oracle.fft_64_dit), (0, np.float32, 1e-5, oracle.fft_32_dit)):
         for latency in (0, 1):
             lrs = (C.c_uint * 3)()
-            tl = C.c_uint()
-            npass = emu.phast_emu_default_plan(is_f64, latency, L, lrs, C.byref(tl))
+            tl, lp = C.c_uint(), C.c_uint()
+            npass = emu.phast_emu_default_plan(is_f64, latency, L, lrs, C.byref(tl), C.byref(lp))
             assert npass in (2, 3)
             re, im = oracle.fill(n, dtype, transform_id=7 * L + latency)
             a, b = re.copy(), im.copy()
             direction = -1 if latency else 1
-            assert run(emu, a, b, direction, tuple(lrs)[:npass], tl.value, 3 if (latency and tl.value == 12) else 4) == 0
+            assert run(emu, a, b, direction, tuple(lrs)[:npass], tl.value, lp.value) == 0
             ofn(re, im, oracle.REVERSE if latency else oracle.FORWARD)
             err = np.sqrt(np.sum((a.astype(np.float64) - re) ** 2 + (b.astype(np.float64) - im) ** 2) /
                           np.sum(re.astype(np.float64) ** 2 + im.astype(np.float64) ** 2))
             assert err <= tol, (L, is_f64, latency, err)
+
+
+@pytest.mark.parametrize("L,lrs", [(20, (10, 10)), (19, (10, 9)), (17, (9, 8)), (16, (8, 8))])
+def test_f32_32768_point_tiles_vs_oracle(emu, oracle, L, lrs):
+    n = 1 << L
+    re, im = oracle.fill(n, np.float32, transform_id=L)
+    a, b = re.copy(), im.copy()
+    assert run(emu, a, b, 1, lrs, 15, 5) == 0
+    oracle.fft_32_dit(re, im, oracle.FORWARD)
+    err = np.sqrt(np.sum((a.astype(np.float64) - re) ** 2 + (b.astype(np.float64) - im) ** 2) /
+                  np.sum(re.astype(np.float64) ** 2 + im.astype(np.float64) ** 2))
+    assert err <= 1e-5, err
 
 
 def test_interleaved_load_and_swapped_interleaved_store(emu, oracle):

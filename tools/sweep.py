@@ -52,6 +52,17 @@ def run(log_n, batch, plans, wgs, reps):
     del re, im
 
 
+if a.what == "p32":  # 32 points per thread (16384-point tiles with 512 threads) against the defaults
+    print("batch of 256 x 2^20")
+    run(20, 256, [((), 12), ((10, 10), 14, 5), ((10, 10), 13, 5), ((10, 10), 14, 4)], [0], 3)
+    print("single 2^20")
+    run(20, 1, [((), 12), ((10, 10), 12, 5), ((10, 10), 13, 5), ((10, 10), 14, 5)], [0], 20)
+    print("batch of 64 x 2^18, 2^19")
+    run(18, 1024, [((), 12), ((9, 9), 14, 5), ((9, 9), 13, 5), ((10, 8), 14, 5)], [0], 3)
+    run(19, 512, [((), 12), ((10, 9), 14, 5), ((10, 9), 13, 5)], [0], 3)
+    print("single 2^26, 2^24")
+    run(26, 1, [((), 12), ((9, 9, 8), 14, 5), ((10, 8, 8), 14, 5), ((9, 9, 8), 13, 5)], [0], 3)
+    run(24, 1, [((), 12), ((8, 8, 8), 14, 5), ((8, 8, 8), 13, 5)], [0], 3)
 if a.what in ("batch20", "all"):
     print("batch of 256 x 2^20")
     run(20, 256, [((), 12), ((10, 10), 13), ((7, 7, 6), 12), ((8, 6, 6), (13, 12, 12))], [0], 3)
