@@ -243,7 +243,10 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
         elapsed = max_over_ranks(time.perf_counter() - t0, dist, dev)
-        # the trivial gather (RCCL over xGMI): one 32-byte digest per transform -> (total, 4) on every rank
+        # the trivial gather (RCCL over xGMI): one 32-byte digest per transform -> (total, 4) on every rank.  Taken
+        # from one step on fresh inputs so that it stays finite whatever K was (values grow 2^10-fold per step)
+        refill()
+        sb.step()
         digests = sb.gather_digests(dist)
         digest_ok = bool(torch.isfinite(digests).all()) and digests.shape[0] == total
         samples_per_step = sb.samples_per_step()
