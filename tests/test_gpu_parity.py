@@ -138,13 +138,15 @@ def test_inverse_matches_oracle(gpu, oracle):
         assert rel_l2(d_re.cpu().numpy(), d_im.cpu().numpy(), re, im) <= F64_REL
 
 
-@pytest.mark.parametrize("plan", [((10, 10), 13), ((7, 7, 6), 12), ((9, 8, 3), 12)])
+@pytest.mark.parametrize("plan", [((10, 10), 13, 4), ((7, 7, 6), 12, 4), ((9, 8, 3), 12, 4), ((10, 10), 14, 5),
+                                  ((10, 10), 14, 4), ((10, 10), 13, 5), ((10, 10), 12, 5), ((6, 8, 6), 12, 3),
+                                  ((10, 10), 12, 3)])
 def test_forced_plans_agree_2p20(gpu, oracle, plan):
     n = 1 << 20
-    lrs, tl = plan
+    lrs, tl, lp = plan
     planner = gpu.PlannerDit64(n)
     try:
-        planner.set_plan(lrs, tl)
+        planner.set_plan(lrs, tl, lp)
     except gpu.PhastPanic:
         pytest.skip(f"plan {plan} not instantiable")
     re, im = oracle.fill(n, np.float64, transform_id=5)
@@ -200,6 +202,33 @@ def test_batched_matches_single(gpu, oracle):
         r, m = oracle.fill(n, np.float64, seed=0xCAFE, transform_id=1000 + b)
         oracle.fft_64_dit(r, m, oracle.FORWARD)
         assert rel_l2(re[b * n:(b + 1) * n].cpu().numpy(), im[b * n:(b + 1) * n].cpu().numpy(), r, m) <= F64_REL, b
+
+
+@pytest.mark.parametrize("dt", ["f64", "f32"])
+@pytest.mark.parametrize("k", list(range(12, 24)))
+def test_throughput_plans_vs_oracle(gpu, oracle, k, dt):
+    """A single small transform runs the latency plan; this drives the THROUGHPUT plan of every size (2^25 points
+    in flight is past every crossover of plan.hpp: throughput_work): first / second / last transform against the
+    oracle, every transform through Parseval."""
+    import torch
+
+    n = 1 << k
+    batch = (1 << 25) // n
+    tdt, ndt, tol = (torch.float64, np.float64, F64_REL) if dt == "f64" else (torch.float32, np.float32, F32_REL)
+    planner = (gpu.PlannerDit64 if dt == "f64" else gpu.PlannerDit32)(n)
+    re = torch.empty(n * batch, dtype=tdt, device="cuda")
+    im = torch.empty_like(re)
+    gpu.fill_uniform(re, im, n, seed=0xBEEF, first_id=7)
+    e_in = (re.double() ** 2 + im.double() ** 2).view(batch, n).sum(dim=1)
+    gpu.fft_dit_batched(re, im, n, gpu.Direction.Forward, planner)
+    e_out = (re.double() ** 2 + im.double() ** 2).view(batch, n).sum(dim=1)
+    assert float((e_out / (n * e_in) - 1.0).abs().max()) < (1e-12 if dt == "f64" else 1e-5), planner.describe()
+    ofn = oracle.fft_64_dit if dt == "f64" else oracle.fft_32_dit
+    for b in (0, 1, batch - 1):
+        r, m = oracle.fill(n, ndt, seed=0xBEEF, transform_id=7 + b)
+        ofn(r, m, oracle.FORWARD)
+        sl = slice(b * n, (b + 1) * n)
+        assert rel_l2(re[sl].cpu().numpy(), im[sl].cpu().numpy(), r, m) <= tol, (b, planner.describe())
 
 
 # ---------------------------------------------------------------- planner misuse (lib.rs:238-296)
@@ -369,7 +398,8 @@ def test_interleaved_matches_planar(gpu):
         assert np.max(np.abs(sig - orig)) < (1e-9 if fdt == np.float64 else 1e-3) * max(1.0, float(np.max(np.abs(orig)))), k
 
 
-@pytest.mark.parametrize("k,dt", [(24, "f64"), (27, "f64"), (28, "f64"), (25, "f32"), (27, "f32")])
+@pytest.mark.parametrize("k,dt", [(24, "f64"), (26, "f64"), (27, "f64"), (28, "f64"), (29, "f64"), (24, "f32"),
+                                  (25, "f32"), (26, "f32"), (27, "f32"), (29, "f32")])
 def test_large_sizes_properties(gpu, k, dt):
     """Sizes past what the oracle finishes in seconds: size-independent properties instead --
     Parseval, sampled bins against a direct O(N) DFT (exact integer phase reduction), and the round trip."""
@@ -451,3 +481,29 @@ def test_batched_r2c_c2r(gpu, oracle):
         back = torch.empty_like(x)
         gpu.c2r_fft_batched(ore, oim, back, planner, batch)
         assert float((back - x).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("k,batch,dt", [(20, 64, "f32"), (18, 256, "f32"), (20, 64, "f64"), (24, 4, "f64")])
+def test_batched_r2c_c2r_throughput_plans(gpu, oracle, k, batch, dt):
+    """Enough real transforms in flight that the inner complex FFT runs its throughput plan (wide tiles with the
+    fused deinterleaving load / interleaving store): R2C against the oracle, C2R back to the input."""
+    import torch
+
+    n = 1 << k
+    tdt, ndt, tol = (torch.float64, np.float64, 1e-9) if dt == "f64" else (torch.float32, np.float32, F32_REL)
+    planner = (gpu.PlannerR2c64 if dt == "f64" else gpu.PlannerR2c32)(n)
+    x = torch.empty(batch * n, dtype=tdt, device="cuda")
+    gpu.fill_uniform(x, None, n, seed=0xF00D, first_id=11)
+    ore = torch.empty(batch * (n // 2 + 1), dtype=tdt, device="cuda")
+    oim = torch.empty_like(ore)
+    gpu.r2c_fft_batched(x, ore, oim, planner, batch)
+    ofn = oracle.r2c_fft_f64 if dt == "f64" else oracle.r2c_fft_f32
+    for b in (0, batch // 2, batch - 1):
+        hx, _ = oracle.fill(n, ndt, seed=0xF00D, transform_id=11 + b)
+        rr, ri = np.zeros(n // 2 + 1, ndt), np.zeros(n // 2 + 1, ndt)
+        ofn(hx, rr, ri)
+        sl = slice(b * (n // 2 + 1), (b + 1) * (n // 2 + 1))
+        assert rel_l2(ore[sl].cpu().numpy(), oim[sl].cpu().numpy(), rr, ri) <= tol, (k, b)
+    back = torch.empty_like(x)
+    gpu.c2r_fft_batched(ore, oim, back, planner, batch)
+    assert float((back - x).abs().max()) < (1e-12 if dt == "f64" else 2e-5)
