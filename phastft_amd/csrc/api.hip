@@ -230,7 +230,7 @@ template <typename T> struct Planner {
         int rc = ensure_device();
         if (rc) return rc;
         if (log_n <= kSmallMaxLog) {
-            std::vector<cx_t<T>> h = host_small_tw<T>(n);
+            std::vector<cx_t<T>> h = host_twr<T>((unsigned)n);  // W_N^j two-level table of the one-pass kernel
             table_bytes = h.size() * sizeof(cx_t<T>);
             return upload<T>(h, &d_small_tw);
         }
@@ -305,9 +305,10 @@ template <typename T> struct Planner {
              PassTimer *timer = nullptr) const {
         if (batch == 0) return PHAST_OK;
         if (passes.empty()) {
-            for (size_t b0 = 0; b0 < batch; b0 += 0x7fffffffu) {
+            const size_t chunk = (size_t)1 << 30;  // transforms per launch: the tile count stays below 2^32
+            for (size_t b0 = 0; b0 < batch; b0 += chunk) {
                 SmallArgs sa{};
-                const size_t nb = batch - b0 < 0x7fffffffu ? batch - b0 : 0x7fffffffu;
+                const size_t nb = batch - b0 < chunk ? batch - b0 : chunk;
                 const size_t isz = in_mode ? 2 * sizeof(T) : sizeof(T), osz = out_mode ? 2 * sizeof(T) : sizeof(T);
                 sa.in_re = (const char *)in_re + b0 * in_dist * isz;
                 sa.in_im = in_im ? (const char *)in_im + b0 * in_dist * isz : nullptr;

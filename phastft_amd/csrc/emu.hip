@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "plan.hpp"
+#include "row_fft.hpp"
 #include "tile_fft.hpp"
 
 namespace phast {
@@ -124,6 +125,53 @@ template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE> stati
     return errors;
 }
 
+// the small-transform kernel (row_fft.hpp): its exchanges are TileBody's, plus the parked tile -- park() must write
+// every word it later pick()s exactly once, inside the buffer, without bank conflicts either way
+template <typename T, int LR, int LC, int LP> static int audit_small_shape(int *max_read_ways, int *max_write_ways) {
+    using RB = RowBody<T, LR, LC, LP>;
+    int errors = audit_shape<T, LR, LC, LP, false, true>(max_read_ways, max_write_ways);
+    constexpr int NT = RB::NT, PP = RB::P;
+    std::vector<int> written(RB::PLANE, 0);
+    std::vector<std::vector<int>> wa(PP, std::vector<int>(NT)), ra(PP, std::vector<int>(NT));
+    for (int t = 0; t < NT; ++t)
+        for (int i = 0; i < PP; ++i) {
+            const int f = i * NT + t;
+            wa[i][t] = (f >> LR) * RB::PITCH + (f & (RB::ROWS - 1));
+            ra[i][t] = RB::Body::col_of(t) * RB::PITCH + RB::Body::tau_of(t) + i * RB::M;
+        }
+    for (int i = 0; i < PP; ++i)
+        for (int t = 0; t < NT; ++t) {
+            if (wa[i][t] < 0 || wa[i][t] >= RB::PLANE) { ++errors; continue; }
+            if (written[wa[i][t]]++) ++errors;
+        }
+    for (int i = 0; i < PP; ++i)
+        for (int t = 0; t < NT; ++t)
+            if (ra[i][t] < 0 || ra[i][t] >= RB::PLANE || !written[ra[i][t]]) ++errors;
+    auto ways = [&](const std::vector<int> &addr, int group) {
+        int worst = 1;
+        for (int base = 0; base < NT; base += group) {
+            int cnt[32] = {0};
+            std::vector<int> seen;
+            for (int l = 0; l < group; ++l) {
+                const int a = addr[base + l];
+                bool dup = false;
+                for (int s_ : seen) dup |= (s_ == a);
+                if (dup) continue;
+                seen.push_back(a);
+                const int w = ++cnt[a & 31];
+                if (w > worst) worst = w;
+            }
+        }
+        return worst;
+    };
+    for (int i = 0; i < PP; ++i) {
+        const int r_ = ways(ra[i], 32), w_ = ways(wa[i], sizeof(T) == 8 ? 16 : 32);
+        if (r_ > *max_read_ways) *max_read_ways = r_;
+        if (w_ > *max_write_ways) *max_write_ways = w_;
+    }
+    return errors;
+}
+
 }  // namespace phast
 
 extern "C" int phast_emu_audit_lds(int is_f64, unsigned lr, unsigned lc, unsigned lp, int transpose, int *max_read_ways,
@@ -168,6 +216,50 @@ int phast_emu_fft_f32_modes(const float *in_re, const float *in_im, unsigned in_
     const size_t n = (size_t)1 << log_n;
     return phast::emu_exec<float>(in_re, in_im, in_mode, out_re, out_im, out_mode, log_n, 1, n, n, scale, lrs, np, tile_log);
 }
+// batches of small transforms (N = 2..2048) through the one-pass kernel's body (row_fft.hpp); modes as above
+static int emu_small(int is_f64, const void *in_re, const void *in_im, unsigned in_mode, void *out_re, void *out_im,
+                     unsigned out_mode, unsigned log_n, size_t batch, size_t in_dist, size_t out_dist, double scale) {
+    phast::RowArgs r{};
+    r.in_re = in_re;
+    r.in_im = in_im;
+    r.out_re = out_re;
+    r.out_im = out_im;
+    r.in_dist = in_dist;
+    r.out_dist = out_dist;
+    r.batch = batch;
+    r.in_interleaved = in_mode;
+    r.out_interleaved = out_mode;
+    r.scale = scale;
+    const unsigned lc = phast::row_tile_cols_log(log_n);
+    r.tiles_total = (unsigned)((batch + ((1ull << lc) - 1)) >> lc);
+    const std::vector<phast::cx_t<double>> t64 = phast::host_twr<double>(1u << log_n);
+    const std::vector<phast::cx_t<float>> t32 = phast::host_twr<float>(1u << log_n);
+    r.twr = is_f64 ? (const void *)t64.data() : (const void *)t32.data();
+#define PHAST_ROW_EMU(LR_, LC_, LP_)                                      \
+    if (log_n == LR_) {                                                   \
+        if (is_f64) phast::emulate_row_fft<double, LR_, LC_, LP_>(r);     \
+        else phast::emulate_row_fft<float, LR_, LC_, LP_>(r);             \
+        return 0;                                                         \
+    }
+    PHAST_ROW_SHAPES(PHAST_ROW_EMU)
+#undef PHAST_ROW_EMU
+    return 1;
+}
+int phast_emu_small_fft(int is_f64, const void *in_re, const void *in_im, unsigned in_mode, void *out_re, void *out_im,
+                        unsigned out_mode, unsigned log_n, size_t batch, size_t in_dist, size_t out_dist, double scale) {
+    return emu_small(is_f64, in_re, in_im, in_mode, out_re, out_im, out_mode, log_n, batch, in_dist, out_dist, scale);
+}
+// LDS audit of the small-transform kernel: park / pick and every exchange in bounds, permutations, conflict-free
+int phast_emu_audit_small(int is_f64, unsigned log_n, int *max_read_ways, int *max_write_ways) {
+#define PHAST_ROW_AUD(LR_, LC_, LP_)                                                                          \
+    if (log_n == LR_)                                                                                         \
+        return is_f64 ? phast::audit_small_shape<double, LR_, LC_, LP_>(max_read_ways, max_write_ways)        \
+                      : phast::audit_small_shape<float, LR_, LC_, LP_>(max_read_ways, max_write_ways);
+    PHAST_ROW_SHAPES(PHAST_ROW_AUD)
+#undef PHAST_ROW_AUD
+    return -1;
+}
+
 // the default plan of the library for (type, log_n): fills lrs[3], returns the number of passes
 int phast_emu_default_plan(int is_f64, int latency, unsigned log_n, unsigned *lrs, unsigned *tile_log,
                            unsigned *points_log) {

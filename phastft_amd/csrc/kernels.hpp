@@ -5,13 +5,13 @@
 
 namespace phast {
 
-// ---- small_fft.hip: one workgroup per transform, whole transform in LDS (N <= 2048) ----
+// ---- small_fft.hip: batches of whole small transforms on chip, one pass (N <= 8192; row_fft.hpp) ----
 struct SmallArgs {
     const void *in_re;
     const void *in_im;
     void *out_re;
     void *out_im;
-    const void *tw;  // [N/2] complex W_N^j
+    const void *tw;  // plan.hpp host_twr(N)  (unused for N = 1)
     unsigned long long in_dist;
     unsigned long long out_dist;
     unsigned log_n;
@@ -20,7 +20,7 @@ struct SmallArgs {
     unsigned out_interleaved;  // 1 = (re, im), 2 = (im, re)
     double scale;
 };
-constexpr unsigned kSmallMaxLog = 11;
+constexpr unsigned kSmallMaxLog = 13;
 template <typename T>
 hipError_t launch_small_fft(const SmallArgs &a, hipStream_t stream, hipEvent_t ev_start = nullptr,
                             hipEvent_t ev_stop = nullptr);

@@ -75,20 +75,13 @@ template <typename T> inline std::vector<cx_t<T>> host_tw3(unsigned log_mod, uns
     return h;
 }
 
-// [2][32]: W_rows^j and W_rows^(32 j)   (TileBody::twr_lookup)
+// [32 + max(64, rows/32)]: W_rows^j (j < 32) and W_rows^(32 j)   (TileBody::twr_lookup; the tile kernels stage
+// the first 64 entries, enough for rows <= 1024, the small-transform kernel all of them)
+inline unsigned twr_entries(unsigned rows) { return 32u + (rows / 32u > 64u ? rows / 32u : 64u); }
 template <typename T> inline std::vector<cx_t<T>> host_twr(unsigned rows) {
-    std::vector<cx_t<T>> h(64);
-    for (unsigned j = 0; j < 32; ++j) {
-        h[j] = twiddle_t<T>(j, rows);
-        h[32 + j] = twiddle_t<T>(32ull * j, rows);
-    }
-    return h;
-}
-
-// [n/2]: W_n^j   (small_fft.hip)
-template <typename T> inline std::vector<cx_t<T>> host_small_tw(size_t n) {
-    std::vector<cx_t<T>> h(n / 2 ? n / 2 : 1);
-    for (size_t j = 0; j < h.size(); ++j) h[j] = twiddle_t<T>(j, n);
+    std::vector<cx_t<T>> h(twr_entries(rows));
+    for (unsigned j = 0; j < 32; ++j) h[j] = twiddle_t<T>(j, rows);
+    for (unsigned j = 0; j + 32 < h.size(); ++j) h[32 + j] = twiddle_t<T>(32ull * j, rows);
     return h;
 }
 

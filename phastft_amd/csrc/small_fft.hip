@@ -1,81 +1,71 @@
-// small_fft.hip -- whole-transform-in-LDS radix-2 DIT FFT for N <= 2048 (gfx950).
+// small_fft.hip -- N <= 2048: launcher of the one-pass small-transform kernels (row_fft.hpp).
 //
-// GPU counterpart of the reference's L1-resident leaf: bit-reverse (algorithms/bravo.rs:225-251,
-// scalar/BRAVO regimes) then stages 0..log_n-1 (algorithms/dit.rs:44-65, kernels/dit.rs).  One
-// workgroup per transform; the bit reversal is the LDS store index of the load, each stage is one
-// sweep over LDS with W_{2^(s+1)}^j read from a W_N table.  Small N is launch-bound, not a
-// bandwidth problem, so this kernel favours being obviously correct.
-#include <hip/hip_ext.h>
+// GPU counterpart of the reference's leaf (algorithms/dit.rs:44-65) for transforms that fit on chip whole:
+// a workgroup runs 2..256 transforms at once through the register/LDS digit chain of tile_fft.hpp; N = 1 is a
+// scaled copy (the reference's recursion does nothing for a single point, algorithms/dit.rs:33-43).
+#include "row_fft.hpp"
 
 #include "kernels.hpp"
 
 namespace phast {
 
-template <typename T> __global__ void __launch_bounds__(256) small_fft_kernel(const SmallArgs a) {
+template <typename T> __global__ void __launch_bounds__(256) one_point_kernel(const SmallArgs a) {
     using cx = cx_t<T>;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const unsigned n = 1u << a.log_n;
-    T *s_re = reinterpret_cast<T *>(smem);
-    T *s_im = s_re + n;
-    const cx *tw = reinterpret_cast<const cx *>(a.tw);
-
-    for (unsigned xf = blockIdx.x; xf < a.batch; xf += gridDim.x) {
-        __syncthreads();
-        for (unsigned i = threadIdx.x; i < n; i += blockDim.x) {
-            const unsigned j = a.log_n ? (__brev(i) >> (32u - a.log_n)) : 0u;
-            if (a.in_interleaved) {
-                cx v = reinterpret_cast<const cx *>(a.in_re)[(size_t)xf * a.in_dist + i];
-                s_re[j] = a.in_interleaved == 2 ? v.y : v.x;
-                s_im[j] = a.in_interleaved == 2 ? v.x : v.y;
-            } else {
-                s_re[j] = reinterpret_cast<const T *>(a.in_re)[(size_t)xf * a.in_dist + i];
-                s_im[j] = reinterpret_cast<const T *>(a.in_im)[(size_t)xf * a.in_dist + i];
-            }
+    const T scale = (T)a.scale;
+    for (size_t xf = (size_t)blockIdx.x * blockDim.x + threadIdx.x; xf < a.batch; xf += (size_t)gridDim.x * blockDim.x) {
+        T re, im;
+        if (a.in_interleaved) {
+            const cx v = reinterpret_cast<const cx *>(a.in_re)[xf * a.in_dist];
+            re = a.in_interleaved == 2 ? v.y : v.x;
+            im = a.in_interleaved == 2 ? v.x : v.y;
+        } else {
+            re = reinterpret_cast<const T *>(a.in_re)[xf * a.in_dist];
+            im = reinterpret_cast<const T *>(a.in_im)[xf * a.in_dist];
         }
-        for (unsigned s = 0; s < a.log_n; ++s) {
-            __syncthreads();
-            const unsigned dist = 1u << s;
-            for (unsigned b = threadIdx.x; b < (n >> 1); b += blockDim.x) {
-                const unsigned j = b & (dist - 1u);
-                const unsigned i0 = ((b >> s) << (s + 1)) | j;
-                const unsigned i1 = i0 + dist;
-                const cx w = tw[j << (a.log_n - 1u - s)];
-                const T br = s_re[i1], bi = s_im[i1];
-                const T tr = br * w.x - bi * w.y;
-                const T ti = br * w.y + bi * w.x;
-                const T ar = s_re[i0], ai = s_im[i0];
-                s_re[i0] = ar + tr;
-                s_im[i0] = ai + ti;
-                s_re[i1] = ar - tr;
-                s_im[i1] = ai - ti;
-            }
-        }
-        __syncthreads();
-        const T scale = (T)a.scale;
-        for (unsigned i = threadIdx.x; i < n; i += blockDim.x) {
-            const T r = s_re[i] * scale, m = s_im[i] * scale;
-            if (a.out_interleaved) {
-                cx v;
-                v.x = a.out_interleaved == 2 ? m : r;
-                v.y = a.out_interleaved == 2 ? r : m;
-                reinterpret_cast<cx *>(a.out_re)[(size_t)xf * a.out_dist + i] = v;
-            } else {
-                reinterpret_cast<T *>(a.out_re)[(size_t)xf * a.out_dist + i] = r;
-                reinterpret_cast<T *>(a.out_im)[(size_t)xf * a.out_dist + i] = m;
-            }
+        re *= scale;
+        im *= scale;
+        if (a.out_interleaved) {
+            cx v;
+            v.x = a.out_interleaved == 2 ? im : re;
+            v.y = a.out_interleaved == 2 ? re : im;
+            reinterpret_cast<cx *>(a.out_re)[xf * a.out_dist] = v;
+        } else {
+            reinterpret_cast<T *>(a.out_re)[xf * a.out_dist] = re;
+            reinterpret_cast<T *>(a.out_im)[xf * a.out_dist] = im;
         }
     }
 }
 
 template <typename T>
 hipError_t launch_small_fft(const SmallArgs &a, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
-    const size_t lds = (size_t)2 * sizeof(T) << a.log_n;
-    const unsigned grid = a.batch < 65536u ? a.batch : 65536u;
-    if (ev_start && ev_stop)
-        hipExtLaunchKernelGGL(small_fft_kernel<T>, dim3(grid), dim3(256), (uint32_t)lds, stream, ev_start, ev_stop, 0, a);
-    else
-        hipLaunchKernelGGL(small_fft_kernel<T>, dim3(grid), dim3(256), lds, stream, a);
-    return hipGetLastError();
+    if (a.batch == 0) return hipSuccess;
+    if (a.log_n == 0) {
+        const unsigned grid = (unsigned)((a.batch + 255) / 256 < 4096 ? (a.batch + 255) / 256 : 4096);
+        if (ev_start && ev_stop)
+            hipExtLaunchKernelGGL(one_point_kernel<T>, dim3(grid), dim3(256), 0, stream, ev_start, ev_stop, 0, a);
+        else
+            hipLaunchKernelGGL(one_point_kernel<T>, dim3(grid), dim3(256), 0, stream, a);
+        return hipGetLastError();
+    }
+    RowArgs r{};
+    r.in_re = a.in_re;
+    r.in_im = a.in_im;
+    r.out_re = a.out_re;
+    r.out_im = a.out_im;
+    r.twr = a.tw;
+    r.in_dist = a.in_dist;
+    r.out_dist = a.out_dist;
+    r.batch = a.batch;
+    r.in_interleaved = a.in_interleaved;
+    r.out_interleaved = a.out_interleaved;
+    r.scale = a.scale;
+    const unsigned lc = row_tile_cols_log(a.log_n);
+    r.tiles_total = (unsigned)((a.batch + ((1ull << lc) - 1)) >> lc);
+#define PHAST_ROW_CASE(LR_, LC_, LP_) \
+    if (a.log_n == LR_) return launch_row_inst<T, LR_, LC_, LP_>(r, stream, ev_start, ev_stop);
+    PHAST_ROW_SHAPES(PHAST_ROW_CASE)
+#undef PHAST_ROW_CASE
+    return hipErrorInvalidValue;
 }
 
 template hipError_t launch_small_fft<float>(const SmallArgs &, hipStream_t, hipEvent_t, hipEvent_t);

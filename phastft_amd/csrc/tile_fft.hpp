@@ -127,10 +127,10 @@ template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool 
     // per pass, and the strided-copy microbenchmark gains 5-10 % (profiles/r01_strided_copy_nt.log).  Narrower
     // rows share their line with the neighbouring tile and NEED the L2 (nt loads cost 25 % there).
     static constexpr bool NT_HINT = COLS * sizeof(T) >= 128;
-    static_assert(LR >= 6 && LR <= 10, "tile FFT length 64..1024");
-    static_assert(LP >= 3 && LP <= 5, "8, 16 or 32 points per thread");
+    static_assert(LR >= 1 && LR <= 13, "tile FFT length 2..8192 (the multi-pass plans use 64..1024)");
+    static_assert(LP >= 1 && LP <= 5 && LP <= LR, "2..32 points per thread");
     static_assert(NT <= 1024 && NT >= 64, "64..1024 threads per workgroup");
-    static_assert(S >= 2, "at least two radix steps (ROWS > P)");
+    static_assert(S >= 1, "at least one radix step");
 
     // log2 of radix R_i (1-based) and of K_i = R_1...R_i
     static constexpr int rbits(int i) { return i < S ? LP : LR - LP * (S - 1); }

@@ -68,7 +68,7 @@ def test_forced_plans_vs_oracle_f64(emu, oracle, L, lrs, tl, lp):
     assert err <= 1e-13, err
 
 
-@pytest.mark.parametrize("L", list(range(12, 23)))
+@pytest.mark.parametrize("L", list(range(14, 23)))  # up to 2^13 the one-pass small-transform kernel runs
 def test_default_plans_both_types_and_inverse(emu, oracle, L):
     n = 1 << L
     for is_f64, dtype, tol, ofn in ((1, np.float64, 1e-13, oracle.fft_64_dit), (0, np.float32, 1e-5, oracle.fft_32_dit)):
@@ -120,3 +120,74 @@ def test_interleaved_load_and_swapped_interleaved_store(emu, oracle):
     r, m = re.copy(), im.copy()
     oracle.fft_32_dit(r, m, oracle.REVERSE)
     assert np.max(np.abs(zz[0::2] - r)) < 1e-6 and np.max(np.abs(zz[1::2] - m)) < 1e-6
+
+
+# ---------------------------------------------------------------- small transforms (row_fft.hpp)
+def _small(emu, is_f64, in_re, in_im, in_mode, out_re, out_im, out_mode, log_n, batch, in_dist, out_dist, scale=1.0):
+    p = lambda x: None if x is None else x.ctypes.data_as(C.c_void_p)
+    emu.phast_emu_small_fft.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_uint,
+                                        C.c_uint, C.c_size_t, C.c_size_t, C.c_size_t, C.c_double]
+    return emu.phast_emu_small_fft(is_f64, p(in_re), p(in_im), in_mode, p(out_re), p(out_im), out_mode, log_n, batch,
+                                   in_dist, out_dist, scale)
+
+
+@pytest.mark.parametrize("is_f64", [1, 0])
+def test_small_kernel_lds_audit(emu, is_f64):
+    for log_n in range(1, 14):
+        r, w = C.c_int(), C.c_int()
+        errors = emu.phast_emu_audit_small(is_f64, log_n, C.byref(r), C.byref(w))
+        assert errors == 0, log_n
+        # N <= 16: a pad word every N < 32 words leaves 2-way conflicts; N = 4096 (one transform per workgroup, a
+        # 32-lane group spans 32 rows): one bank pair collides in the first exchange
+        worst = 2 if (log_n <= 4 or log_n == 12) else 1
+        assert r.value <= worst and w.value <= worst, (log_n, r.value, w.value)
+
+
+@pytest.mark.parametrize("log_n", list(range(1, 14)))
+def test_small_transforms_vs_oracle_ragged_batches(emu, oracle, log_n):
+    """Every small size, in place, with a batch that does not fill the last tile and transforms `dist` apart."""
+    n = 1 << log_n
+    for dtype, is_f64, tol, ofn in ((np.float64, 1, 1e-13, oracle.fft_64_dit), (np.float32, 0, 1e-5, oracle.fft_32_dit)):
+        lc_full = {1: 256, 2: 256, 3: 256, 4: 256, 5: 128}.get(log_n, max(1, 4096 // n))
+        batch = lc_full + max(1, lc_full // 2) + 1
+        dist = n + 3
+        re = np.full(batch * dist, 7.0, dtype)
+        im = np.full(batch * dist, -7.0, dtype)
+        want = []
+        for b in range(batch):
+            r, m = oracle.fill(n, dtype, transform_id=100 * log_n + b)
+            re[b * dist:b * dist + n], im[b * dist:b * dist + n] = r, m
+            if b in (0, 1, lc_full - 1, lc_full, batch - 1):
+                ofn(r, m, oracle.FORWARD)
+                want.append((b, r, m))
+        assert _small(emu, is_f64, re, im, 0, re, im, 0, log_n, batch, dist, dist) == 0
+        for b, r, m in want:
+            gr, gm = re[b * dist:b * dist + n].astype(np.float64), im[b * dist:b * dist + n].astype(np.float64)
+            err = np.sqrt(np.sum((gr - r) ** 2 + (gm - m) ** 2) / np.sum(r.astype(np.float64) ** 2 + m.astype(np.float64) ** 2))
+            assert err <= tol, (log_n, b, err)
+        gaps = np.concatenate([re[b * dist + n:(b + 1) * dist] for b in range(batch)])
+        assert np.all(gaps == 7.0)
+
+
+def test_small_transforms_interleaved_modes(emu, oracle):
+    """(re, im) pairs in -> planar out (R2C's inner transform) and planar in -> (im, re) pairs out (C2R's)."""
+    log_n, batch = 7, 45
+    n = 1 << log_n
+    z = np.empty(2 * n * batch, np.float64)
+    refs = []
+    for b in range(batch):
+        r, m = oracle.fill(n, np.float64, transform_id=b)
+        z[2 * b * n:2 * (b + 1) * n:2], z[2 * b * n + 1:2 * (b + 1) * n:2] = r, m
+        oracle.fft_64_dit(r, m, oracle.FORWARD)
+        refs.append((r, m))
+    out_re, out_im = np.zeros(n * batch), np.zeros(n * batch)
+    assert _small(emu, 1, z, None, 1, out_re, out_im, 0, log_n, batch, n, n) == 0
+    for b, (r, m) in enumerate(refs):
+        assert np.max(np.abs(out_re[b * n:(b + 1) * n] - r)) < 1e-11 and np.max(np.abs(out_im[b * n:(b + 1) * n] - m)) < 1e-11
+    zz = np.zeros(2 * n * batch)
+    assert _small(emu, 1, out_re, out_im, 0, zz, None, 2, log_n, batch, n, n, 0.5) == 0
+    back_im, back_re = zz[0::2], zz[1::2]
+    # same arithmetic through planar output, scaled the same way
+    pr, pi = np.zeros(n * batch), np.zeros(n * batch)
+    assert _small(emu, 1, out_re, out_im, 0, pr, pi, 0, log_n, batch, n, n, 0.5) == 0
+    assert np.array_equal(back_re, pr) and np.array_equal(back_im, pi)
