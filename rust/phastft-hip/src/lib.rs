@@ -49,6 +49,12 @@ extern "C" {
         sim_len: usize) -> c_int;
     fn phast_fft_64_dit_dev(re: *mut f64, im: *mut f64, n: usize, batch: usize, dist: usize, direction: c_int,
         planner: *const Opaque, stream: *mut c_void) -> c_int;
+    #[cfg(feature = "complex-nums")]
+    fn phast_fft_64_interleaved_with_planner_and_opts(signal: *mut f64, n: usize, direction: c_int,
+        planner: *const Opaque, opts: *const PhastOptions) -> c_int;
+    #[cfg(feature = "complex-nums")]
+    fn phast_fft_32_interleaved_with_planner_and_opts(signal: *mut f32, n: usize, direction: c_int,
+        planner: *const Opaque, opts: *const PhastOptions) -> c_int;
 }
 
 #[track_caller]
@@ -238,3 +244,38 @@ pub unsafe fn fft_64_dit_dev(d_reals: *mut f64, d_imags: *mut f64, n: usize, bat
                              direction: Direction, planner: &PlannerDit64, stream: *mut c_void) {
     check(phast_fft_64_dit_dev(d_reals, d_imags, n, batch, dist, direction as c_int, planner.h, stream));
 }
+
+/// Interleaved `Complex<T>` signals (reference: feature `complex-nums`, lib.rs:41-140).  The reference copies into
+/// two planar Vecs, runs the planar path and copies back; the library fuses the (de)interleave into the first
+/// pass's load and the last pass's store, so there is no extra sweep.  `Complex<T>` is `repr(C)` (re, im).
+#[cfg(feature = "complex-nums")]
+pub use num_complex::Complex;
+
+#[cfg(feature = "complex-nums")]
+macro_rules! impl_interleaved {
+    ($t:ty, $planner:ident, $with_opts:ident, $with_planner:ident, $plain:ident, $c_fn:ident) => {
+        /// lib.rs:50
+        pub fn $with_opts(signal: &mut [Complex<$t>], direction: Direction, planner: &$planner, opts: &Options) {
+            let c_opts = opts.to_c();
+            check(unsafe {
+                $c_fn(signal.as_mut_ptr() as *mut $t, signal.len(), direction as c_int, planner.h, &c_opts)
+            });
+        }
+        /// lib.rs:87
+        pub fn $with_planner(signal: &mut [Complex<$t>], direction: Direction, planner: &$planner) {
+            let opts = Options::guess_options(signal.len());
+            $with_opts(signal, direction, planner, &opts);
+        }
+        /// lib.rs:120
+        pub fn $plain(signal: &mut [Complex<$t>], direction: Direction) {
+            let planner = <$planner>::new(signal.len());
+            $with_planner(signal, direction, &planner);
+        }
+    };
+}
+#[cfg(feature = "complex-nums")]
+impl_interleaved!(f64, PlannerDit64, fft_64_interleaved_with_planner_and_opts, fft_64_interleaved_with_planner,
+                  fft_64_interleaved, phast_fft_64_interleaved_with_planner_and_opts);
+#[cfg(feature = "complex-nums")]
+impl_interleaved!(f32, PlannerDit32, fft_32_interleaved_with_planner_and_opts, fft_32_interleaved_with_planner,
+                  fft_32_interleaved, phast_fft_32_interleaved_with_planner_and_opts);
