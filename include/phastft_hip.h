@@ -16,10 +16,10 @@
  *     stream; they are what bench.py measures.  `batch` independent transforms, transform b at
  *     pointer + b*dist elements.
  *
- * Planners are immutable after creation and may be shared by concurrent callers on DIFFERENT
- * data only when each caller uses its own stream AND its own planner scratch; in this version a
- * planner owns one device scratch buffer, so calls on one planner are serialised by an internal
- * mutex on the host-slice path and must be stream-ordered by the caller on the _dev path.
+ * Planners may be shared by concurrent host threads (planner.rs:38-39): a planner owns one device scratch
+ * buffer, so an internal lock makes every call's launch sequence atomic -- the blocking host-slice calls hold it
+ * for the whole call, the _dev calls while they enqueue.  _dev calls on one planner must therefore be issued on
+ * ONE stream (or be ordered by the caller across streams); use one planner per stream for concurrent streams.
  */
 #ifndef PHASTFT_HIP_H
 #define PHASTFT_HIP_H

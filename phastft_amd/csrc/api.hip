@@ -148,9 +148,30 @@ template <typename T> struct Planner {
     mutable size_t scratch_cap = 0;
     mutable size_t reserve = 1;
     mutable std::mutex mu;
+    // One transform sequence at a time per planner: the passes of a call share the planner's scratch, so the
+    // enqueue of a call (and, on the host-slice path, the whole blocking call) holds this lock.  Recursive: the
+    // host-slice entry points call exec() while holding it.
+    mutable std::recursive_mutex call_mu;
+    mutable void *d_stage = nullptr;  // device staging of the host-slice entry points (grow-only)
+    mutable size_t stage_bytes = 0;
     mutable size_t table_bytes = 0;
 
     ~Planner() { release(); }
+    // device staging buffer of at least `bytes` (call with call_mu held)
+    int stage(size_t bytes, void **out) const {
+        if (stage_bytes < bytes) {
+            if (d_stage) {
+                hipDeviceSynchronize();
+                hipFree(d_stage);
+                d_stage = nullptr;
+                stage_bytes = 0;
+            }
+            PHAST_HIP(hipMalloc(&d_stage, bytes ? bytes : 1));
+            stage_bytes = bytes;
+        }
+        *out = d_stage;
+        return PHAST_OK;
+    }
     static void free_passes(std::vector<PassDesc> &v) {
         for (auto &p : v) {
             if (p.d_tw3) hipFree(p.d_tw3);
@@ -166,9 +187,11 @@ template <typename T> struct Planner {
         release_passes();
         if (d_small_tw) hipFree(d_small_tw);
         if (d_scratch) hipFree(d_scratch);
+        if (d_stage) hipFree(d_stage);
         d_small_tw = nullptr;
         d_scratch = nullptr;
-        scratch_cap = 0;
+        d_stage = nullptr;
+        scratch_cap = stage_bytes = 0;
     }
 
     // the latency plan serves batches too small to fill the chip with the throughput plan's tiles
@@ -304,6 +327,7 @@ template <typename T> struct Planner {
              size_t out_dist, unsigned out_mode, size_t batch, double scale, hipStream_t stream,
              PassTimer *timer = nullptr) const {
         if (batch == 0) return PHAST_OK;
+        std::lock_guard<std::recursive_mutex> call_lock(call_mu);
         if (passes.empty()) {
             const size_t chunk = (size_t)1 << 30;  // transforms per launch: the tile count stays below 2^32
             for (size_t b0 = 0; b0 < batch; b0 += chunk) {
@@ -432,6 +456,7 @@ template <typename T> struct PlannerR2c {
     int r2c(const T *d_in, T *d_ore, T *d_oim, size_t batch, size_t in_dist, size_t out_dist, hipStream_t s) const {
         const size_t half = n / 2;
         if (in_dist & 1) return PHAST_ERR_INVALID_ARG;  // the input is read as (even, odd) pairs
+        std::lock_guard<std::recursive_mutex> call_lock(dit.call_mu);
         int rc = dit.exec(d_in, nullptr, in_dist / 2, 1, d_ore, d_oim, out_dist, 0, batch, 1.0, s);
         if (rc) return rc;
         for (size_t b0 = 0; b0 < batch; b0 += 65535) {
@@ -453,6 +478,7 @@ template <typename T> struct PlannerR2c {
             hipStream_t s) const {
         const size_t half = n / 2;
         if (out_dist & 1) return PHAST_ERR_INVALID_ARG;
+        std::lock_guard<std::recursive_mutex> call_lock(dit.call_mu);
         size_t cap = 0;
         int rc = ensure_z(batch, &cap);
         if (rc) return rc;
@@ -586,10 +612,11 @@ static int fft_host(T *re, size_t re_len, T *im, size_t im_len, int direction, c
     if (!is_pow2(re_len)) return PHAST_ERR_NOT_POW2;          // dit.rs:285
     if (ilog2(re_len) != pl->log_n) return PHAST_ERR_PLANNER_SIZE;  // dit.rs:289
     const size_t n = re_len, bytes = n * sizeof(T);
-    DevBuf buf;
-    int rc = buf.alloc(2 * bytes);
+    std::lock_guard<std::recursive_mutex> call_lock(pl->call_mu);
+    void *stage = nullptr;
+    int rc = pl->stage(2 * bytes, &stage);
     if (rc) return rc;
-    T *d_re = reinterpret_cast<T *>(buf.p), *d_im = d_re + n;
+    T *d_re = reinterpret_cast<T *>(stage), *d_im = d_re + n;
     PHAST_HIP(hipMemcpy(d_re, re, bytes, hipMemcpyHostToDevice));
     PHAST_HIP(hipMemcpy(d_im, im, bytes, hipMemcpyHostToDevice));
     rc = fft_dev<T>(d_re, d_im, n, 1, n, direction, pl, nullptr);
@@ -604,14 +631,15 @@ template <typename T> static int fft_interleaved_host(T *signal, size_t n, int d
     if (!pl || (!signal && n)) return PHAST_ERR_INVALID_ARG;
     if (!is_pow2(n)) return PHAST_ERR_NOT_POW2;
     if (ilog2(n) != pl->log_n) return PHAST_ERR_PLANNER_SIZE;
-    DevBuf buf;
-    int rc = buf.alloc(2 * n * sizeof(T));
+    std::lock_guard<std::recursive_mutex> call_lock(pl->call_mu);
+    void *stage = nullptr;
+    int rc = pl->stage(2 * n * sizeof(T), &stage);
     if (rc) return rc;
-    PHAST_HIP(hipMemcpy(buf.p, signal, 2 * n * sizeof(T), hipMemcpyHostToDevice));
-    rc = fft_interleaved_dev<T>(reinterpret_cast<T *>(buf.p), n, 1, n, direction, pl, nullptr);
+    PHAST_HIP(hipMemcpy(stage, signal, 2 * n * sizeof(T), hipMemcpyHostToDevice));
+    rc = fft_interleaved_dev<T>(reinterpret_cast<T *>(stage), n, 1, n, direction, pl, nullptr);
     if (rc) return rc;
     PHAST_HIP(hipStreamSynchronize(nullptr));
-    PHAST_HIP(hipMemcpy(signal, buf.p, 2 * n * sizeof(T), hipMemcpyDeviceToHost));
+    PHAST_HIP(hipMemcpy(signal, stage, 2 * n * sizeof(T), hipMemcpyDeviceToHost));
     return PHAST_OK;
 }
 
@@ -633,11 +661,11 @@ static int r2c_host(const T *in, size_t in_len, T *ore, size_t ore_len, T *oim, 
     if (in_len != n) return PHAST_ERR_R2C_INPUT_LEN;
     if (ore_len != half + 1) return PHAST_ERR_R2C_OUT_RE_LEN;
     if (oim_len != half + 1) return PHAST_ERR_R2C_OUT_IM_LEN;
-    DevBuf bin, bout;
-    int rc = bin.alloc(n * sizeof(T));
-    if (!rc) rc = bout.alloc(2 * (half + 1) * sizeof(T));
+    std::lock_guard<std::recursive_mutex> call_lock(pl->dit.call_mu);
+    void *stage = nullptr;
+    int rc = pl->dit.stage((n + 2 * (half + 1)) * sizeof(T), &stage);
     if (rc) return rc;
-    T *d_in = reinterpret_cast<T *>(bin.p), *d_ore = reinterpret_cast<T *>(bout.p), *d_oim = d_ore + half + 1;
+    T *d_in = reinterpret_cast<T *>(stage), *d_ore = d_in + n, *d_oim = d_ore + half + 1;
     PHAST_HIP(hipMemcpy(d_in, in, n * sizeof(T), hipMemcpyHostToDevice));
     rc = pl->r2c(d_in, d_ore, d_oim, 1, n, half + 1, nullptr);
     if (rc) return rc;
@@ -657,11 +685,11 @@ static int c2r_host(const T *ire, size_t ire_len, const T *iim, size_t iim_len, 
     if (iim_len != half + 1) return PHAST_ERR_C2R_IN_IM_LEN;
     if (check_scratch && sre_len != half) return PHAST_ERR_C2R_SCRATCH_RE;
     if (check_scratch && sim_len != half) return PHAST_ERR_C2R_SCRATCH_IM;
-    DevBuf bin, bout;
-    int rc = bin.alloc(2 * (half + 1) * sizeof(T));
-    if (!rc) rc = bout.alloc(n * sizeof(T));
+    std::lock_guard<std::recursive_mutex> call_lock(pl->dit.call_mu);
+    void *stage = nullptr;
+    int rc = pl->dit.stage((n + 2 * (half + 1)) * sizeof(T), &stage);
     if (rc) return rc;
-    T *d_ire = reinterpret_cast<T *>(bin.p), *d_iim = d_ire + half + 1, *d_out = reinterpret_cast<T *>(bout.p);
+    T *d_out = reinterpret_cast<T *>(stage), *d_ire = d_out + n, *d_iim = d_ire + half + 1;
     PHAST_HIP(hipMemcpy(d_ire, ire, (half + 1) * sizeof(T), hipMemcpyHostToDevice));
     PHAST_HIP(hipMemcpy(d_iim, iim, (half + 1) * sizeof(T), hipMemcpyHostToDevice));
     rc = pl->c2r(d_ire, d_iim, d_out, 1, half + 1, n, nullptr);

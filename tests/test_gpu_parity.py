@@ -507,3 +507,41 @@ def test_batched_r2c_c2r_throughput_plans(gpu, oracle, k, batch, dt):
     back = torch.empty_like(x)
     gpu.c2r_fft_batched(ore, oim, back, planner, batch)
     assert float((back - x).abs().max()) < (1e-12 if dt == "f64" else 2e-5)
+
+
+def test_one_planner_shared_by_host_threads(gpu, oracle):
+    """planner.rs:38-39: a planner is an immutable value any number of callers may borrow.  Here it owns device
+    scratch, so the library serialises the calls; four host threads hammer one C2C and one R2C planner with
+    different data (ctypes releases the GIL during the calls) and every result must still be right."""
+    import threading
+
+    n = 1 << 16
+    planner = gpu.PlannerDit64(n)
+    rplanner = gpu.PlannerR2c32(n)
+    errors = []
+
+    def worker(tid):
+        try:
+            for it in range(12):
+                re, im = oracle.fill(n, np.float64, transform_id=1000 * tid + it)
+                a, b = re.copy(), im.copy()
+                gpu.fft_64_dit_with_planner(a, b, gpu.Direction.Forward, planner)
+                oracle.fft_64_dit(re, im, oracle.FORWARD)
+                if rel_l2(a, b, re, im) > F64_REL:
+                    errors.append(("c2c", tid, it))
+                x, _ = oracle.fill(n, np.float32, transform_id=5000 * tid + it)
+                ore, oim = np.zeros(n // 2 + 1, np.float32), np.zeros(n // 2 + 1, np.float32)
+                gpu.r2c_fft_f32_with_planner(x, ore, oim, rplanner)
+                rr, ri = np.zeros(n // 2 + 1, np.float32), np.zeros(n // 2 + 1, np.float32)
+                oracle.r2c_fft_f32(x, rr, ri)
+                if rel_l2(ore, oim, rr, ri) > F32_REL:
+                    errors.append(("r2c", tid, it))
+        except Exception as e:  # noqa: BLE001 -- surfaced below
+            errors.append(("exception", tid, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:5]
