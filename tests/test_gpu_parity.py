@@ -545,3 +545,40 @@ def test_one_planner_shared_by_host_threads(gpu, oracle):
     for th in threads:
         th.join()
     assert not errors, errors[:5]
+
+
+@pytest.mark.parametrize("dt", ["f64", "f32"])
+def test_small_transform_batches_ragged_and_strided(gpu, oracle, dt):
+    """The one-pass kernel for N <= 8192 (row_fft.hpp): batches that do not fill the last workgroup tile,
+    transforms `dist` apart, forward and inverse; first / middle / last transform against the oracle, gaps untouched."""
+    import torch
+
+    tdt, ndt, tol = (torch.float64, np.float64, F64_REL) if dt == "f64" else (torch.float32, np.float32, F32_REL)
+    ofn = oracle.fft_64_dit if dt == "f64" else oracle.fft_32_dit
+    for k in range(0, 14):
+        n = 1 << k
+        per_tile = max(1, 4096 // n) if k >= 6 else 256
+        batch = 2 * per_tile + per_tile // 2 + 3
+        gap = 5
+        dist = n + gap
+        total = (batch - 1) * dist + n
+        planner = (gpu.PlannerDit64 if dt == "f64" else gpu.PlannerDit32)(n)
+        for direction, odir in ((gpu.Direction.Forward, oracle.FORWARD), (gpu.Direction.Reverse, oracle.REVERSE)):
+            h_re = np.full(total, 9.0, ndt)
+            h_im = np.full(total, -9.0, ndt)
+            picks = sorted({0, 1 % batch, per_tile - 1, per_tile, batch // 2, batch - 1})
+            for b in range(batch):
+                r, m = oracle.fill(n, ndt, seed=0xABCD, transform_id=b)
+                h_re[b * dist:b * dist + n], h_im[b * dist:b * dist + n] = r, m
+            re, im = torch.from_numpy(h_re).cuda(), torch.from_numpy(h_im).cuda()
+            gpu.fft_dit_batched(re, im, n, direction, planner, dist=dist)
+            g_re, g_im = re.cpu().numpy(), im.cpu().numpy()
+            for b in picks:
+                r, m = oracle.fill(n, ndt, seed=0xABCD, transform_id=b)
+                ofn(r, m, odir)
+                sl = slice(b * dist, b * dist + n)
+                assert rel_l2(g_re[sl], g_im[sl], r, m) <= tol, (k, b, direction)
+            mask = np.ones(total, bool)
+            for b in range(batch):
+                mask[b * dist:b * dist + n] = False
+            assert np.all(g_re[mask] == 9.0) and np.all(g_im[mask] == -9.0), k
