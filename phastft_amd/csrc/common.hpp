@@ -8,14 +8,7 @@
 #include <type_traits>
 
 #define PHAST_HD __host__ __device__ __forceinline__
-// Scheduling fence (device code only): the machine scheduler may not move instructions across it.  Used to
-// keep table lookups from being hoisted en bloc above the arithmetic that consumes them, which at 32 points
-// per thread costs more registers than the wave has.
-#if defined(__HIP_DEVICE_COMPILE__)
-#define PHAST_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-#else
-#define PHAST_SCHED_FENCE() ((void)0)
-#endif
+
 
 namespace phast {
 

@@ -214,7 +214,6 @@ template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool 
                 T wr, wi;
                 tw3_lookup<T>(sh.tw3, a.tw_bits, e0 + decltype(j)::value * de, wr, wi);
                 cmul(r.re[j], r.im[j], wr, wi);
-                if constexpr (P > 16 && (decltype(j)::value & 3) == 3) PHAST_SCHED_FENCE();
             });
         }
     }
@@ -239,7 +238,6 @@ template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool 
                     twr_lookup(sh, (n_rest * KI) << KB, wr, wi);
                     cmul(r.re[decltype(i)::value * R + decltype(p)::value], r.im[decltype(i)::value * R + decltype(p)::value],
                          wr, wi);
-                    if constexpr (P > 16 && (decltype(p)::value & 3) == 3) PHAST_SCHED_FENCE();
                 });
             });
         }
