@@ -143,6 +143,7 @@ template <typename T> struct Planner {
     unsigned log_n = 0;
     std::vector<PassDesc> passes;      // throughput plan; empty => small path
     std::vector<PassDesc> passes_lat;  // latency plan (one small transform); may equal `passes`
+    std::vector<PassDesc> passes_mid;  // a few transforms in flight, where that wants a plan of its own (plan.hpp)
     void *d_small_tw = nullptr;
     mutable T *d_scratch = nullptr;  // [cap][2][n]: re plane then im plane per transform
     mutable size_t scratch_cap = 0;
@@ -182,6 +183,7 @@ template <typename T> struct Planner {
     void release_passes() {
         free_passes(passes);
         free_passes(passes_lat);
+        free_passes(passes_mid);
     }
     void release() {
         release_passes();
@@ -194,15 +196,19 @@ template <typename T> struct Planner {
         scratch_cap = stage_bytes = 0;
     }
 
-    // the latency plan serves batches too small to fill the chip with the throughput plan's tiles
-    bool use_latency_plan(size_t batch) const {
-        if (passes_lat.empty() || passes.empty()) return false;
+    // the plan for `batch` transforms in flight: throughput when its tiles fill the chip, else the mid plan for
+    // more than one transform (where there is one), else the latency plan
+    const std::vector<PassDesc> &plan_for(size_t batch) const {
+        if (passes_lat.empty() || passes.empty()) return passes;
         unsigned tl = 0;
         for (const PassDesc &p : passes) tl = std::max(tl, p.lr + p.lc);
-        return batch * n < throughput_work(tl);
+        if (batch * n >= throughput_work(tl)) return passes;
+        if (batch > 1 && !passes_mid.empty()) return passes_mid;
+        return passes_lat;
     }
 
-    // which: 0 = both plans, 1 = throughput plan only, 2 = latency plan only; lp = log2(points per thread)
+    // which: 0 = one plan for every batch size, 1 = throughput plan only, 2 = latency plan only, 3 = mid plan only;
+    // lp = log2(points per thread)
     int set_plan(const std::vector<unsigned> &lrs, const std::vector<unsigned> &tls, int which = 0, unsigned lp = 4) {
         std::vector<PassGeom> geo;
         if (!make_passes(log_n, lrs, tls, geo, lp, sizeof(T))) return PHAST_ERR_INVALID_ARG;
@@ -238,10 +244,16 @@ template <typename T> struct Planner {
         if (which == 2) {
             free_passes(passes_lat);
             passes_lat = std::move(ps);
+        } else if (which == 3) {
+            free_passes(passes_mid);
+            passes_mid = std::move(ps);
         } else {
             free_passes(passes);
             passes = std::move(ps);
-            if (which == 0) free_passes(passes_lat);  // one plan for every batch size
+            if (which == 0) {  // one plan for every batch size
+                free_passes(passes_lat);
+                free_passes(passes_mid);
+            }
         }
         table_bytes = tb;
         return PHAST_OK;
@@ -268,7 +280,10 @@ template <typename T> struct Planner {
         int rc = set_plan(lrs, tls, 1, lp);
         if (rc) return rc;
         heuristic_plan<T>(log_n, true, lrs, tls, lp);
-        return set_plan(lrs, tls, 2, lp);
+        rc = set_plan(lrs, tls, 2, lp);
+        if (rc) return rc;
+        if (mid_plan<T>(log_n, lrs, tls, lp)) rc = set_plan(lrs, tls, 3, lp);
+        return rc;
     }
 
     // scratch for `want` transforms in flight (capped by the target footprint, at least 1)
@@ -317,6 +332,7 @@ template <typename T> struct Planner {
             }
         };
         add("throughput", passes);
+        if (!passes_mid.empty()) add("mid", passes_mid);
         if (!passes_lat.empty()) add("latency", passes_lat);
         return s;
     }
@@ -357,7 +373,7 @@ template <typename T> struct Planner {
         if (rc) return rc;
         T *s_re = d_scratch;               // plane layout: all re planes, then all im planes
         T *s_im = d_scratch + cap * n;
-        const std::vector<PassDesc> &passes = use_latency_plan(batch) ? passes_lat : this->passes;
+        const std::vector<PassDesc> &passes = plan_for(batch);
         const size_t np = passes.size();
         for (size_t b0 = 0; b0 < batch; b0 += cap) {
             const size_t nb = batch - b0 < cap ? batch - b0 : cap;
@@ -558,8 +574,7 @@ template <typename T>
 static int time_passes(const Planner<T> *pl, T *d_re, T *d_im, size_t batch, size_t dist, int reps, float *pass_ms,
                        int *n_passes, hipStream_t s) {
     if (!pl || !d_re || !d_im || !pass_ms || !n_passes || reps < 1) return PHAST_ERR_INVALID_ARG;
-    const bool lat = pl->use_latency_plan(batch);
-    const int np = pl->passes.empty() ? 1 : (int)(lat ? pl->passes_lat.size() : pl->passes.size());
+    const int np = pl->passes.empty() ? 1 : (int)pl->plan_for(batch).size();
     double acc[3] = {0, 0, 0};
     for (int r = 0; r < reps; ++r) {
         PassTimer tm;

@@ -174,6 +174,19 @@ inline void heuristic_plan(unsigned L, bool latency, std::vector<unsigned> &lrs,
     }
 }
 
+// A third plan for "a few transforms in flight" where neither of the two above fits: N = 2^20, whose latency plan
+// takes three passes (best for ONE transform) while 2..15 transforms are better served by two passes of
+// 8192-point tiles (64 / 68 / 75 GSamples/s at 2 / 4 / 8 transforms against 47 / 44 / 49,
+// profiles/r01_sweep_batch_f64.log).  Returns false where the latency plan already is the right one.
+template <typename T>
+inline bool mid_plan(unsigned L, std::vector<unsigned> &lrs, std::vector<unsigned> &tls, unsigned &lp) {
+    if (L != 20) return false;
+    lrs = {10, 10};
+    tls.assign(1, 13);
+    lp = 4;
+    return true;
+}
+
 // points in flight (batch * n) from which the throughput plan is used; below it the chip is better filled by the
 // latency plan's 4096-point tiles (measured crossovers, profiles/r01_sweep_batch_f64.log and the single-transform
 // sweeps: 8192- and 16384-point tiles win from 2^24 points on, 32768-point tiles from 2^25)
