@@ -93,11 +93,11 @@ template <typename T> inline std::vector<cx_t<T>> host_twr(unsigned rows) {
 #define PHAST_TILE_SHAPES(X)                                                                                  \
     X(6, 6, 4) X(7, 5, 4) X(8, 4, 4) X(9, 3, 4) X(10, 2, 4) X(7, 6, 4) X(8, 5, 4) X(9, 4, 4) X(10, 3, 4)      \
     X(8, 6, 4) X(9, 5, 4) X(10, 4, 4) X(6, 6, 3) X(7, 5, 3) X(8, 4, 3) X(9, 3, 3) X(10, 2, 3)                 \
-    X(10, 4, 5) X(9, 5, 5) X(8, 6, 5) X(10, 3, 5) X(9, 4, 5) X(8, 5, 5) X(10, 2, 5)
+    X(10, 4, 5) X(9, 5, 5) X(8, 6, 5) X(10, 3, 5) X(9, 4, 5) X(8, 5, 5) X(10, 2, 5) X(11, 3, 5)
 
 // 4-byte elements only: 32768-point tiles (1024 threads x 32 points), rows twice as wide again; an f64 tile
 // of that size does not fit the LDS.
-#define PHAST_TILE_SHAPES_F32(X) X(10, 5, 5) X(9, 6, 5) X(8, 7, 5)
+#define PHAST_TILE_SHAPES_F32(X) X(10, 5, 5) X(9, 6, 5) X(8, 7, 5) X(11, 4, 5)
 
 inline bool shape_exists(unsigned lr, unsigned lc, unsigned lp, size_t elem_bytes) {
 #define PHAST_CHK(LR_, LC_, LP_) \
@@ -157,6 +157,10 @@ inline void heuristic_plan(unsigned L, bool latency, std::vector<unsigned> &lrs,
     } else if (L <= 20) {  // tile FFTs of 256..1024 points: 32 x 8 .. 32 x 32 in registers, one LDS exchange
         split(2);
         tls.assign(1, (!f64 && L >= 17) ? 15 : 14);  // f32: 32768-point tiles keep the rows at 128 B
+        lp = 5;
+    } else if (L == 21 && f64) {  // 1024 x 16, then a 2048-point tile FFT (32 x 32 x 2) on 64-byte rows: two passes
+        lrs = {10, 11};          // still beat three (59 vs 51 GSamples/s); not so for f32 or 2^22
+        tls.assign(1, 14);
         lp = 5;
     } else if (L <= 23) {  // (three passes need tile FFTs of at least 64 points)
         split(3);

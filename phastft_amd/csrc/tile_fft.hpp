@@ -120,6 +120,7 @@ template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool 
     static constexpr bool PLANE_SEQ = SEQ;  // exchange re and im one after the other (half the LDS, twice the barriers)
     static constexpr int CS = ROWS + G;     // padded column stride of the transposing exchange
     static constexpr int E1S = P + (G > 1 ? 1 : 0);  // rows per n' in exchange 1 (P used + padding)
+    static constexpr int TWR = ROWS > 1024 ? 32 + ROWS / 32 : 64;  // staged entries of the W_ROWS table (plan.hpp: host_twr)
     static constexpr int EXCH_E1 = M * E1S * COLS;
     static constexpr int EXCH_ET = TRANSPOSE ? COLS * CS : 0;
     static constexpr int EXCH = EXCH_E1 > EXCH_ET ? EXCH_E1 : EXCH_ET;
@@ -139,7 +140,7 @@ template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool 
     static size_t lds_bytes(unsigned tw_bits) {
         size_t exch = (size_t)EXCH * sizeof(T) * (PLANE_SEQ ? 1 : 2);
         size_t tw3 = PRE_TW ? (size_t)(3u << tw_bits) * sizeof(cx) : 0;
-        return exch + tw3 + 64 * sizeof(cx);
+        return exch + tw3 + TWR * sizeof(cx);
     }
 
     // what a workgroup shares (LDS on the GPU, plain host arrays in the emulator);
@@ -400,7 +401,7 @@ __global__ void __launch_bounds__(1 << (LR + LC - LP), PHAST_MIN_WAVES(LR, LC)) 
         Body::locate(a, t, r);
         Body::load_raw(a, tid, r);
     }
-    for (int i = tid; i < 64; i += NT) l_twr[i] = reinterpret_cast<const cx *>(a.twr)[i];
+    for (int i = tid; i < Body::TWR; i += NT) l_twr[i] = reinterpret_cast<const cx *>(a.twr)[i];
     if constexpr (PRE_TW)
         for (unsigned i = tid; i < (3u << a.tw_bits); i += NT) l_tw3[i] = reinterpret_cast<const cx *>(a.tw3)[i];
     __syncthreads();

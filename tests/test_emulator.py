@@ -32,8 +32,8 @@ def run(emu, re, im, direction=1, lrs=(), tile_log=12, points_log=4):
 # (log2 rows, log2 cols, log2 points per thread) -- PHAST_TILE_SHAPES of csrc/plan.hpp
 SHAPES = [(6, 6, 4), (7, 5, 4), (8, 4, 4), (9, 3, 4), (10, 2, 4), (7, 6, 4), (8, 5, 4), (9, 4, 4), (10, 3, 4), (8, 6, 4),
           (9, 5, 4), (10, 4, 4), (6, 6, 3), (7, 5, 3), (8, 4, 3), (9, 3, 3), (10, 2, 3),
-          (10, 4, 5), (9, 5, 5), (8, 6, 5), (10, 3, 5), (9, 4, 5), (8, 5, 5), (10, 2, 5)]
-SHAPES_F32_ONLY = [(10, 5, 5), (9, 6, 5), (8, 7, 5)]  # PHAST_TILE_SHAPES_F32: 32768-point tiles
+          (10, 4, 5), (9, 5, 5), (8, 6, 5), (10, 3, 5), (9, 4, 5), (8, 5, 5), (10, 2, 5), (11, 3, 5)]
+SHAPES_F32_ONLY = [(10, 5, 5), (9, 6, 5), (8, 7, 5), (11, 4, 5)]  # PHAST_TILE_SHAPES_F32: 32768-point tiles
 
 
 @pytest.mark.parametrize("is_f64", [1, 0])
@@ -54,7 +54,9 @@ PLANS = [(12, (6, 6), 12, 4), (13, (7, 6), 12, 4), (15, (8, 7), 12, 4), (16, (8,
          (20, (10, 10), 12, 3), (21, (7, 7, 7), 12, 3),
          # 32 points per thread: 32x32, 32x16 and 32x8 chains, 16384-/8192-/4096-point tiles
          (20, (10, 10), 14, 5), (19, (10, 9), 14, 5), (18, (9, 9), 13, 5), (16, (8, 8), 13, 5), (20, (10, 10), 12, 5),
-         (20, (10, 10), 13, 5)]
+         (20, (10, 10), 13, 5),
+         # a 2048-point tile FFT (32 x 32 x 2) as second or first pass
+         (21, (10, 11), 14, 5), (21, (11, 10), 14, 5)]
 
 
 @pytest.mark.parametrize("L,lrs,tl,lp", PLANS)

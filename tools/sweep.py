@@ -63,6 +63,9 @@ if a.what == "p32":  # 32 points per thread (16384-point tiles with 512 threads)
     print("single 2^26, 2^24")
     run(26, 1, [((), 12), ((9, 9, 8), 14, 5), ((10, 8, 8), 14, 5), ((9, 9, 8), 13, 5)], [0], 3)
     run(24, 1, [((), 12), ((8, 8, 8), 14, 5), ((8, 8, 8), 13, 5)], [0], 3)
+if a.what == "lr11":  # two passes for 2^21 / 2^22 with a 2048-point tile FFT
+    run(21, 32, [((), 12), ((11, 10), 14, 5), ((10, 11), 14, 5), ((11, 10), 15, 5)], [0], 3)
+    run(22, 16, [((), 12), ((11, 11), 14, 5), ((11, 11), 15, 5)], [0], 3)
 if a.what in ("batch20", "all"):
     print("batch of 256 x 2^20")
     run(20, 256, [((), 12), ((10, 10), 13), ((7, 7, 6), 12), ((8, 6, 6), (13, 12, 12))], [0], 3)
