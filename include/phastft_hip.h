@@ -198,6 +198,22 @@ int phast_digest_f64_dev(const double *d_reals, const double *d_imags, size_t n,
 int phast_digest_f32_dev(const float *d_reals, const float *d_imags, size_t n, size_t batch, size_t dist,
                          size_t probe, double *d_digest, void *stream);
 
+/* ---- one transform spread over several GPUs (no reference counterpart: the reference's
+ * recursion, algorithms/dit.rs:33-164, never leaves one address space).  A four-step split N = N1*N2 needs, between
+ * its two local FFT stages, every element (r, c) of a rank's row-major slab multiplied by W_N^((row0 + r)*(col0 + c));
+ * a twiddle grid owns the device tables of W_N (three-level, as the planners').  The exchanges themselves are the
+ * host side's (phastft_amd/distributed.py: RCCL all-to-all through torch.distributed). ---- */
+typedef struct phast_twiddle_grid64 phast_twiddle_grid64;
+typedef struct phast_twiddle_grid32 phast_twiddle_grid32;
+int phast_twiddle_grid64_new(size_t n, phast_twiddle_grid64 **out);   /* n = N, a power of two <= 2^32 */
+int phast_twiddle_grid32_new(size_t n, phast_twiddle_grid32 **out);
+void phast_twiddle_grid64_free(phast_twiddle_grid64 *g);
+void phast_twiddle_grid32_free(phast_twiddle_grid32 *g);
+int phast_twiddle_grid64_apply_dev(const phast_twiddle_grid64 *g, double *d_re, double *d_im, size_t rows, size_t cols,
+                                   size_t row_pitch, size_t row0, size_t col0, void *stream);
+int phast_twiddle_grid32_apply_dev(const phast_twiddle_grid32 *g, float *d_re, float *d_im, size_t rows, size_t cols,
+                                   size_t row_pitch, size_t row0, size_t col0, void *stream);
+
 /* ---- tuning hook used by tools/ and tests to force a pass plan (n_passes = 0 restores the heuristic) ----
  * log_rows[i] = log2 of pass i's tile FFT length, tile_logs[i] = log2 of the points per tile of pass i
  * (12, 13 or 14), points_log = log2 of the complex points each thread holds (4, or 3 for the 4096-point

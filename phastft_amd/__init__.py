@@ -47,6 +47,7 @@ __all__ = [
     "fft_64_interleaved", "fft_32_interleaved", "fft_64_interleaved_with_planner", "fft_32_interleaved_with_planner",
     "fft_64_interleaved_with_planner_and_opts", "fft_32_interleaved_with_planner_and_opts",
     "bit_rev_bravo_f64", "bit_rev_bravo_f32", "fft_dit_batched", "r2c_fft_batched", "c2r_fft_batched", "fill_uniform", "digest", "device_info",
+    "TwiddleGrid64", "TwiddleGrid32",
 ]
 
 
@@ -180,9 +181,12 @@ class _PlannerDit:
         return cls(num_points, mode)
 
     def __del__(self):
-        if getattr(self, "_h", None) is not None and self._h.value and _lib is not None and _lib._lib is not None:
-            getattr(_lib._lib, f"phast_planner_dit{self._sfx}_free")(self._h)
-            self._h = C.c_void_p()
+        try:
+            if getattr(self, "_h", None) is not None and self._h.value and _lib is not None and _lib._lib is not None:
+                getattr(_lib._lib, f"phast_planner_dit{self._sfx}_free")(self._h)
+                self._h.value = None
+        except Exception:  # interpreter shutdown: modules may already be gone
+            pass
 
     # ---- MI355X-side extras (no reference counterpart) ----
     def describe(self) -> str:
@@ -244,9 +248,12 @@ class _PlannerR2c:
         return cls(n)
 
     def __del__(self):
-        if getattr(self, "_h", None) is not None and self._h.value and _lib is not None and _lib._lib is not None:
-            getattr(_lib._lib, f"phast_planner_r2c{self._sfx}_free")(self._h)
-            self._h = C.c_void_p()
+        try:
+            if getattr(self, "_h", None) is not None and self._h.value and _lib is not None and _lib._lib is not None:
+                getattr(_lib._lib, f"phast_planner_r2c{self._sfx}_free")(self._h)
+                self._h.value = None
+        except Exception:  # interpreter shutdown: modules may already be gone
+            pass
 
 
 class PlannerR2c64(_PlannerR2c):
@@ -424,6 +431,45 @@ def c2r_fft_batched(input_re, input_im, output, planner, batch: int) -> None:
         raise ValueError("need device tensors of batch*(n/2+1), batch*(n/2+1), batch*n elements")
     _check(getattr(_lib.lib(), f"phast_c2r_fft_{fs}_dev")(ire.ptr, iim.ptr, out.ptr, C.c_size_t(batch), C.c_size_t(half1),
                                                           C.c_size_t(n), planner._h, _stream()))
+
+
+class TwiddleGrid64:
+    """Device tables of W_N for the inter-factor twiddle of a four-step split (``include/phastft_hip.h``:
+    ``phast_twiddle_grid64_*``): ``apply`` multiplies element (r, c) of a row-major device block by
+    ``W_N^((row0 + r)*(col0 + c))`` in place.  Used by :mod:`phastft_amd.distributed`."""
+
+    _sfx = "64"
+    _dtype = np.float64
+
+    def __init__(self, n: int):
+        self._h = C.c_void_p()
+        _check(getattr(_lib.lib(), f"phast_twiddle_grid{self._sfx}_new")(C.c_size_t(n), C.byref(self._h)))
+        self.n = n
+
+    def __del__(self):
+        try:
+            h = getattr(self, "_h", None)
+            if h is not None and h.value:
+                getattr(_lib.lib(), f"phast_twiddle_grid{self._sfx}_free")(h)
+                h.value = None
+        except Exception:  # interpreter shutdown: modules may already be gone
+            pass
+
+    def apply(self, reals, imags, rows: int, cols: int, row0: int = 0, col0: int = 0, row_pitch: int | None = None):
+        re, im = _Slice(reals, self._dtype, "reals"), _Slice(imags, self._dtype, "imags")
+        if not _same_place(re, im):
+            raise TypeError("TwiddleGrid.apply needs device tensors")
+        pitch = cols if row_pitch is None else row_pitch
+        if re.len != im.len or (rows and re.len < (rows - 1) * pitch + cols):
+            raise ValueError("block does not fit the tensors")
+        _check(getattr(_lib.lib(), f"phast_twiddle_grid{self._sfx}_apply_dev")(
+            self._h, re.ptr, im.ptr, C.c_size_t(rows), C.c_size_t(cols), C.c_size_t(pitch), C.c_size_t(row0),
+            C.c_size_t(col0), _stream()))
+
+
+class TwiddleGrid32(TwiddleGrid64):
+    _sfx = "32"
+    _dtype = np.float32
 
 
 # ---------------------------------------------------------------------------------------------

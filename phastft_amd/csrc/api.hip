@@ -766,6 +766,42 @@ struct phast_planner_dit32 : Planner<float> {};
 struct phast_planner_r2c64 : PlannerR2c<double> {};
 struct phast_planner_r2c32 : PlannerR2c<float> {};
 
+// W_N^(r*c) tables of a four-step split (twiddle.hip)
+template <typename T> struct TwiddleGrid {
+    unsigned log_n = 0, tw_bits = 1;
+    void *d_tw3 = nullptr;
+    ~TwiddleGrid() {
+        if (d_tw3) hipFree(d_tw3);
+    }
+    int init(size_t n) {
+        int rc = ensure_device();
+        if (rc) return rc;
+        log_n = ilog2(n);
+        if (log_n > 32) return PHAST_ERR_INVALID_ARG;  // exponents are reduced to 32 bits
+        tw_bits = tw3_bits_for(log_n);
+        return upload<T>(host_tw3<T>(log_n, tw_bits), &d_tw3);
+    }
+    int apply(T *d_re, T *d_im, size_t rows, size_t cols, size_t row_pitch, size_t row0, size_t col0, hipStream_t s) const {
+        if ((!d_re || !d_im) && rows * cols) return PHAST_ERR_INVALID_ARG;
+        if (row_pitch < cols) return PHAST_ERR_INVALID_ARG;
+        TwiddleGridArgs a{};
+        a.re = d_re;
+        a.im = d_im;
+        a.tw3 = d_tw3;
+        a.rows = rows;
+        a.cols = cols;
+        a.row_pitch = row_pitch;
+        a.row0 = row0;
+        a.col0 = col0;
+        a.log_n = log_n;
+        a.tw_bits = tw_bits;
+        PHAST_HIP(launch_twiddle_grid<T>(a, s));
+        return PHAST_OK;
+    }
+};
+struct phast_twiddle_grid64 : TwiddleGrid<double> {};
+struct phast_twiddle_grid32 : TwiddleGrid<float> {};
+
 extern "C" {
 
 const char *phast_strerror(int code) {
@@ -972,5 +1008,18 @@ PHAST_PLANNER_API(32, float)
 
 PHAST_FFT_API(64, f64, double)
 PHAST_FFT_API(32, f32, float)
+
+#define PHAST_TWIDDLE_API(SFX, T)                                                                                   \
+    int phast_twiddle_grid##SFX##_new(size_t n, phast_twiddle_grid##SFX **out) {                                    \
+        return planner_new(n, out);                                                                                 \
+    }                                                                                                               \
+    void phast_twiddle_grid##SFX##_free(phast_twiddle_grid##SFX *g) { delete g; }                                   \
+    int phast_twiddle_grid##SFX##_apply_dev(const phast_twiddle_grid##SFX *g, T *d_re, T *d_im, size_t rows,        \
+                                            size_t cols, size_t row_pitch, size_t row0, size_t col0, void *stream) { \
+        if (!g) return PHAST_ERR_INVALID_ARG;                                                                       \
+        return g->apply(d_re, d_im, rows, cols, row_pitch, row0, col0, static_cast<hipStream_t>(stream));           \
+    }
+PHAST_TWIDDLE_API(64, double)
+PHAST_TWIDDLE_API(32, float)
 
 }  // extern "C"

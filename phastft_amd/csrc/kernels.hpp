@@ -54,6 +54,17 @@ struct C2rPreArgs {
 };
 template <typename T> hipError_t launch_c2r_preprocess(const C2rPreArgs &a, hipStream_t stream);
 
+// ---- twiddle.hip: block (r, c) *= W_N^((row0 + r) * (col0 + c)), N = 2^log_n (four-step inter-factor twiddle) ----
+struct TwiddleGridArgs {
+    void *re;  // [rows][row_pitch], in place
+    void *im;
+    const void *tw3;  // [3][1 << tw_bits]: W_N^e
+    unsigned long long rows, cols, row_pitch, row0, col0;
+    unsigned log_n;
+    unsigned tw_bits;
+};
+template <typename T> hipError_t launch_twiddle_grid(const TwiddleGridArgs &a, hipStream_t stream);
+
 // ---- fill.hip ----
 template <typename T>
 hipError_t launch_fill(T *re, T *im, size_t n, size_t batch, size_t dist, unsigned long long seed,

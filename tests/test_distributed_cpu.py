@@ -82,3 +82,65 @@ def test_two_rank_sharded_batch_gloo(tmp_path):
         O.fft_64_dit(re, im, O.FORWARD)
         assert np.allclose(got[t], [re.sum(), im.sum(), np.sum(re * re + im * im), re[1]], rtol=1e-12, atol=1e-9)
         assert abs(got[t][2] / (n * e_in) - 1) < 1e-12  # Parseval ties the digest to the input
+
+
+# ---------------------------------------------------------------- one transform over several ranks (f-3)
+def _dist_fft_worker(rank, world, port, log_n, reverse, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    from phastft_amd.distributed import DistributedFft
+
+    n = 1 << log_n
+
+    def local_fft(re, im, length, count):  # the oracle stands in for the batched HIP kernels
+        r, m = re.numpy(), im.numpy()
+        for b in range(count):
+            O.fft_64_dit(r[b * length:(b + 1) * length], m[b * length:(b + 1) * length], O.FORWARD)
+
+    def twiddle(re, im, rows, cols, row0):
+        r = torch.arange(row0, row0 + rows, dtype=torch.int64).view(rows, 1)
+        c = torch.arange(cols, dtype=torch.int64).view(1, cols)
+        ang = ((r * c) % n).to(torch.float64) * (-2.0 * np.pi / n)
+        wr, wi = torch.cos(ang).view(-1), torch.sin(ang).view(-1)
+        x, y = re.clone(), im.clone()
+        re.copy_(x * wr - y * wi)
+        im.copy_(x * wi + y * wr)
+
+    full_re, full_im = O.fill(n, np.float64, seed=0xD157, transform_id=log_n)
+    lo, hi = rank * n // world, (rank + 1) * n // world
+    re, im = torch.from_numpy(full_re[lo:hi].copy()), torch.from_numpy(full_im[lo:hi].copy())
+    DistributedFft(n, rank, world, local_fft, twiddle, dist).run(re, im, reverse=reverse)
+    np.save(os.path.join(out_dir, f"re{rank}.npy"), re.numpy())
+    np.save(os.path.join(out_dir, f"im{rank}.npy"), im.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,log_n,reverse", [(2, 10, False), (4, 11, False), (2, 13, True), (4, 8, True)])
+def test_one_transform_over_ranks_gloo(tmp_path, world, log_n, reverse):
+    """Block-distributed natural order in, natural order out, three all-to-alls: the concatenated slabs must be the
+    transform of the concatenated input (the oracle run on one rank), forward and reverse."""
+    from oracle import oracle as O
+
+    mp.spawn(_dist_fft_worker, args=(world, _free_port(), log_n, reverse, str(tmp_path)), nprocs=world, join=True)
+    n = 1 << log_n
+    got_re = np.concatenate([np.load(tmp_path / f"re{r}.npy") for r in range(world)])
+    got_im = np.concatenate([np.load(tmp_path / f"im{r}.npy") for r in range(world)])
+    re, im = O.fill(n, np.float64, seed=0xD157, transform_id=log_n)
+    O.fft_64_dit(re, im, O.REVERSE if reverse else O.FORWARD)
+    err = np.sqrt(np.sum((got_re - re) ** 2 + (got_im - im) ** 2) / np.sum(re ** 2 + im ** 2))
+    assert err < 1e-13, err
+
+
+def test_split_factors():
+    from phastft_amd.distributed import split_factors
+
+    assert split_factors(28, 8) == (1 << 14, 1 << 14)
+    assert split_factors(29, 8) == (1 << 15, 1 << 14)
+    with pytest.raises(ValueError):
+        split_factors(4, 8)   # N < ranks^2
+    with pytest.raises(ValueError):
+        split_factors(20, 3)
