@@ -319,7 +319,7 @@ template <typename T> struct Planner {
     std::string describe() const {
         char buf[512];
         if (passes.empty()) {
-            std::snprintf(buf, sizeof buf, "n=2^%u small-lds (1 kernel)", log_n);
+            std::snprintf(buf, sizeof buf, "n=2^%u one pass (whole transforms on chip)", log_n);
             return buf;
         }
         std::string s = "n=2^" + std::to_string(log_n);

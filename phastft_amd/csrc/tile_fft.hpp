@@ -8,8 +8,8 @@
 // Design.  N = 2^L is factored into 2 or 3 passes N = R_A * R_B (* R_C).  A pass
 // runs ROWS-point FFTs along a strided axis; a workgroup owns a tile of ROWS x COLS points (COLS
 // adjacent columns => every global access of a wave covers COLS*sizeof(T)-byte contiguous segments).
-// Each thread holds P = 16 (or 8) complex points in registers.  Inside the tile the ROWS-point FFT is a
-// decimation-in-frequency digit chain ROWS = R_1 * ... * R_S (R_i <= P); the radix-16/8/4/2 butterflies run
+// Each thread holds P = 8, 16 or 32 complex points in registers.  Inside the tile the ROWS-point FFT is a
+// decimation-in-frequency digit chain ROWS = R_1 * ... * R_S (R_i <= P); the radix-32/16/8/4/2 butterflies run
 // in registers with literal twiddles, and data moves between the radix steps through LDS (layouts and the
 // bank-conflict argument are with TileBody below; tests/test_emulator.py audits every shape).
 // Pass A (TRANSPOSE) additionally transposes through LDS ([col][k], padded) so that each column's ROWS
@@ -92,8 +92,9 @@ template <typename T, int R, int OFF, int P> PHAST_HD void fft_reg_dif(T (&re)[P
     });
 }
 
-// One tile pass, generic in the points per thread P = 2^LP (16: throughput plans; 8: latency plans, twice the
-// waves per tile -- a one-tile-per-CU launch is issue-stall bound with one wave per SIMD).
+// One tile pass, generic in the points per thread P = 2^LP (32: the wide throughput tiles -- twice the row width
+// at the same thread count, one exchange fewer; 16: throughput plans; 8: latency plans, twice the waves per tile --
+// a one-tile-per-CU launch is issue-stall bound with one wave per SIMD; 2..32 = N in the small-transform kernel).
 //
 // The ROWS-point FFT is a DIF digit chain ROWS = R_1 * R_2 * ... * R_S with R_i <= P (R_1 = ... = P, the last
 // takes the remainder).  K_i = R_1...R_i.  Step i consumes input digit n_i (most significant first) and
