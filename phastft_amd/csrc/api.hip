@@ -278,12 +278,23 @@ template <typename T> struct Planner {
         unsigned lp = 4;
         heuristic_plan<T>(log_n, false, lrs, tls, lp);
         int rc = set_plan(lrs, tls, 1, lp);
+        // the largest sizes: the last pass's twiddle tables (3 * 2^ceil(L/3) entries) may not leave room for the
+        // heuristic's tile -- step the tile size down until the plan fits one CU's LDS
+        while (rc == PHAST_ERR_INVALID_ARG && tls[0] > 12) {
+            tls.assign(1, tls[0] - 1);
+            if (tls[0] < 14 && lp == 5) lp = 4;
+            rc = set_plan(lrs, tls, 1, lp);
+        }
         if (rc) return rc;
+        // the other two plans are optimisations: where their tiles do not exist (N >= 2^31) the throughput plan serves
         heuristic_plan<T>(log_n, true, lrs, tls, lp);
         rc = set_plan(lrs, tls, 2, lp);
-        if (rc) return rc;
-        if (mid_plan<T>(log_n, lrs, tls, lp)) rc = set_plan(lrs, tls, 3, lp);
-        return rc;
+        if (rc != PHAST_OK && rc != PHAST_ERR_INVALID_ARG) return rc;
+        if (mid_plan<T>(log_n, lrs, tls, lp)) {
+            rc = set_plan(lrs, tls, 3, lp);
+            if (rc != PHAST_OK && rc != PHAST_ERR_INVALID_ARG) return rc;
+        }
+        return PHAST_OK;
     }
 
     // scratch for `want` transforms in flight (capped by the target footprint, at least 1)

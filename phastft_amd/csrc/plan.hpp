@@ -250,7 +250,7 @@ inline bool make_passes(unsigned L, const std::vector<unsigned> &lrs, const std:
         if (p.lc > p.log_s_in) return false;    // a tile needs COLS adjacent columns sharing the row stride
         if (p.lc > p.out_lo_bits) return false;  // ... and the output column map must be linear inside a tile
     }
-    return L <= 30;  // per-lane offsets are 32-bit element indices
+    return L <= 31;  // per-lane offsets and twiddle exponents are 32-bit element indices
 }
 
 inline void geom_to_args(const PassGeom &p, unsigned log_n, size_t n_xforms, TileArgs &ta) {

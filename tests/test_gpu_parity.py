@@ -399,7 +399,7 @@ def test_interleaved_matches_planar(gpu):
 
 
 @pytest.mark.parametrize("k,dt", [(24, "f64"), (26, "f64"), (27, "f64"), (28, "f64"), (29, "f64"), (24, "f32"),
-                                  (25, "f32"), (26, "f32"), (27, "f32"), (29, "f32")])
+                                  (25, "f32"), (26, "f32"), (27, "f32"), (29, "f32"), (30, "f32")])
 def test_large_sizes_properties(gpu, k, dt):
     """Sizes past what the oracle finishes in seconds: size-independent properties instead --
     Parseval, sampled bins against a direct O(N) DFT (exact integer phase reduction), and the round trip."""
