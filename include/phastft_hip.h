@@ -71,7 +71,9 @@ typedef struct phast_options {
 void phast_options_default(phast_options *out);               /* options.rs:26-33 */
 int phast_options_guess(size_t input_size, phast_options *out); /* options.rs:38-43 */
 
-/* ---- planner.rs:34-114 ---- */
+/* ---- planner.rs:34-114 ----
+ * num_points: a power of two (else PHAST_ERR_NOT_POW2, the reference's assert) up to 2^30 for f64 and 2^31 for
+ * f32; larger sizes return PHAST_ERR_INVALID_ARG (the reference is bounded by host memory only). */
 typedef struct phast_planner_dit64 phast_planner_dit64; /* PlannerDit64 */
 typedef struct phast_planner_dit32 phast_planner_dit32; /* PlannerDit32 */
 int phast_planner_dit64_new(size_t num_points, phast_planner_dit64 **out);                 /* planner.rs:55 */
