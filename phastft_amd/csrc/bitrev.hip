@@ -5,9 +5,9 @@
 // the B x B block {u*2^(L-beta) + t*B + v}; bit reversal sends element (u, t, v) to (rev v, rev t, rev u),
 // i.e. tile t <-> tile rev(t) with the block transposed and both coordinates bit-reversed.  One
 // workgroup stages tile t and tile rev(t) in LDS (the reference's stack buffer) and writes each into
-// the other's place: every global access is a run of B contiguous elements (256 B), and the transpose
-// happens in LDS with a +1 padded row so neither side has bank conflicts.  B = 32 for 8-byte and 64 for
-// 4-byte elements -- the reference's TILE_SIDE_F64 / TILE_SIDE_F32 (bravo.rs:19-20).  Pure data
+// the other's place: every global access is a run of B contiguous elements, and the transpose happens in LDS
+// with a +1 padded row so neither side has bank conflicts.  B = 64 for both element sizes (the reference's
+// TILE_SIDE_F32; its TILE_SIDE_F64 = 32, bravo.rs:19-20, is what the small sizes below 2^12 still use).  Pure data
 // movement: elements travel as integers, so NaN payloads and signed zeros survive.
 #include <cstdlib>
 
@@ -59,9 +59,85 @@ __global__ void __launch_bounds__(NTH) bitrev_tiled_kernel(U *data, unsigned log
     }
 }
 
-static int bitrev_variant() {  // tuning hook: PHAST_BITREV_VARIANT=0 (default) | 1 | 2 | 3 (tools/sweep_bitrev.py)
-    const char *e = getenv("PHAST_BITREV_VARIANT");
-    return e ? atoi(e) : 0;
+// Persistent form: a workgroup walks the tile pairs (t <= rev t) grid-stride, with the NEXT pair's rows already in
+// flight (registers) while the current pair goes through LDS -- the loads of pair i+1 overlap the transposing
+// reads and the stores of pair i, and the half of the index space that would exit at once never becomes a
+// workgroup.
+template <typename U, int BETA, int NTH>
+__global__ void __launch_bounds__(NTH) bitrev_persistent_kernel(U *data, unsigned log_n, size_t dist, unsigned tiles,
+                                                                unsigned long long total) {
+    constexpr int B = 1 << BETA, PER = B * B / NTH;
+    __shared__ U sa[B][B + 1];
+    __shared__ U sb[B][B + 1];
+    const unsigned tile_bits = log_n - 2 * BETA;
+    const unsigned ustride_log = log_n - BETA;
+    auto rev_t = [&](unsigned t) { return tile_bits ? (__brev(t) >> (32u - tile_bits)) : 0u; };
+    // next work item at or after `w` whose tile is the smaller of its pair
+    auto advance = [&](unsigned long long w) {
+        while (w < total) {
+            const unsigned t = (unsigned)(w % tiles);
+            if (t <= rev_t(t)) break;
+            w += gridDim.x;
+        }
+        return w;
+    };
+    U ra[PER], rb[PER];
+    auto load = [&](unsigned long long w) {
+        const unsigned t = (unsigned)(w % tiles), tr = rev_t(t);
+        U *x = data + (size_t)(w / tiles) * dist;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = i * NTH + threadIdx.x;
+            const unsigned u = idx >> BETA, v = idx & (B - 1);
+            ra[i] = x[((size_t)u << ustride_log) + ((size_t)t << BETA) + v];
+            rb[i] = x[((size_t)u << ustride_log) + ((size_t)tr << BETA) + v];
+        }
+    };
+    unsigned long long w = advance(blockIdx.x);
+    if (w < total) load(w);
+    while (w < total) {
+        const unsigned t = (unsigned)(w % tiles), tr = rev_t(t);
+        U *x = data + (size_t)(w / tiles) * dist;
+        __syncthreads();  // the previous pair's readers are done
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = i * NTH + threadIdx.x;
+            sa[idx >> BETA][idx & (B - 1)] = ra[i];
+            sb[idx >> BETA][idx & (B - 1)] = rb[i];
+        }
+        __syncthreads();
+        U oa[PER], ob[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = i * NTH + threadIdx.x;
+            const unsigned u = idx >> BETA, v = idx & (B - 1);
+            const unsigned ru = __brev(u) >> (32 - BETA), rv = __brev(v) >> (32 - BETA);
+            oa[i] = sb[rv][ru];  // what tile t receives
+            ob[i] = sa[rv][ru];  // what tile rev t receives
+        }
+        const unsigned long long wn = advance(w + gridDim.x);
+        if (wn < total) load(wn);  // in flight during the stores below
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = i * NTH + threadIdx.x;
+            const unsigned u = idx >> BETA, v = idx & (B - 1);
+            x[((size_t)u << ustride_log) + ((size_t)t << BETA) + v] = oa[i];
+            if (t != tr) x[((size_t)u << ustride_log) + ((size_t)tr << BETA) + v] = ob[i];
+        }
+        w = wn;
+    }
+}
+
+template <typename U, int BETA, int NTH>
+static hipError_t launch_bitrev_persistent(U *data, unsigned log_n, size_t batch, size_t dist, hipStream_t stream,
+                                           unsigned wg_per_cu) {
+    const unsigned tiles = 1u << (log_n - 2 * BETA);
+    const unsigned long long total = (unsigned long long)tiles * batch;
+    unsigned long long grid = 256ull * wg_per_cu;
+    if (grid > total) grid = total;
+    hipLaunchKernelGGL((bitrev_persistent_kernel<U, BETA, NTH>), dim3((unsigned)grid), dim3(NTH), 0, stream, data, log_n,
+                       dist, tiles, total);
+    return hipGetLastError();
 }
 
 template <typename U, int BETA, int NTH>
@@ -88,21 +164,31 @@ static hipError_t launch_bitrev_u(U *data, unsigned log_n, size_t batch, size_t 
     return hipGetLastError();
 }
 
+static int bitrev_variant() {  // tuning hook (tools/sweep_bitrev.py): PHAST_BITREV_VARIANT=0 (default) | 1..4
+    const char *e = getenv("PHAST_BITREV_VARIANT");
+    return e ? atoi(e) : 0;
+}
+
+// Defaults from profiles/r01_sweep_bitrev.log: the persistent kernel with 64 x 64 tiles (512-byte rows for f64,
+// 256-byte for f32), 512 threads, 4 workgroups per CU -- 3.4-3.7 TB/s at 2^26..2^30 f64, 3.4-4.6 f32.  Variant 1
+// is the one-pair-per-workgroup kernel (32 x 32 tiles for f64) the persistent one replaced.
 template <> hipError_t launch_bitrev<double>(double *data, unsigned log_n, size_t batch, size_t dist, hipStream_t s) {
     auto *p = reinterpret_cast<unsigned long long *>(data);
     const int v = bitrev_variant();
-    if (v == 1 && log_n >= 12) return launch_bitrev_u<unsigned long long, 6, 512>(p, log_n, batch, dist, s);
-    if (v == 2 && log_n >= 12) return launch_bitrev_u<unsigned long long, 6, 1024>(p, log_n, batch, dist, s);
-    if (v == 3) return launch_bitrev_u<unsigned long long, 5, 512>(p, log_n, batch, dist, s);
-    return launch_bitrev_u<unsigned long long, 5, 256>(p, log_n, batch, dist, s);
+    if (v == 1 || log_n < 12) return launch_bitrev_u<unsigned long long, 5, 256>(p, log_n, batch, dist, s);
+    if (v == 2) return launch_bitrev_persistent<unsigned long long, 5, 256>(p, log_n, batch, dist, s, 8);
+    if (v == 3) return launch_bitrev_persistent<unsigned long long, 6, 512>(p, log_n, batch, dist, s, 2);
+    if (v == 4) return launch_bitrev_persistent<unsigned long long, 6, 1024>(p, log_n, batch, dist, s, 2);
+    return launch_bitrev_persistent<unsigned long long, 6, 512>(p, log_n, batch, dist, s, 4);
 }
 template <> hipError_t launch_bitrev<float>(float *data, unsigned log_n, size_t batch, size_t dist, hipStream_t s) {
     auto *p = reinterpret_cast<unsigned *>(data);
     const int v = bitrev_variant();
-    if (v == 1) return launch_bitrev_u<unsigned, 6, 256>(p, log_n, batch, dist, s);
-    if (v == 2) return launch_bitrev_u<unsigned, 6, 1024>(p, log_n, batch, dist, s);
-    if (v == 3 && log_n >= 14) return launch_bitrev_u<unsigned, 7, 1024>(p, log_n, batch, dist, s);
-    return launch_bitrev_u<unsigned, 6, 512>(p, log_n, batch, dist, s);  // measured best (profiles/r01_sweep_bitrev.log)
+    if (v == 1 || log_n < 12) return launch_bitrev_u<unsigned, 6, 512>(p, log_n, batch, dist, s);
+    if (v == 2) return launch_bitrev_persistent<unsigned, 6, 512>(p, log_n, batch, dist, s, 8);
+    if (v == 3) return launch_bitrev_persistent<unsigned, 6, 1024>(p, log_n, batch, dist, s, 2);
+    if (v == 4 && log_n >= 14) return launch_bitrev_persistent<unsigned, 7, 1024>(p, log_n, batch, dist, s, 2);
+    return launch_bitrev_persistent<unsigned, 6, 512>(p, log_n, batch, dist, s, 4);
 }
 
 }  // namespace phast
