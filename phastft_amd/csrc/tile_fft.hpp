@@ -119,7 +119,12 @@ template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool 
     static constexpr int G = COLS >= 32 ? 1 : 32 / COLS;  // rows seen by one 32-lane LDS access group
     static constexpr int S = (LR + LP - 1) / LP;  // number of radix steps
     static constexpr bool PLANE_SEQ = SEQ;  // exchange re and im one after the other (half the LDS, twice the barriers)
-    static constexpr int CS = ROWS + G;     // padded column stride of the transposing exchange
+    // Column stride of the transposing exchange [col][k]: its WRITERS are lanes (col fastest, then tau = k), so
+    // consecutive columns must land as many cells apart as a write group holds rows -- 32-lane groups over 32 cells
+    // for 4-byte elements (G), but ds_write_b64 serves 16-lane groups over 16 eight-byte cells (MI355X_MICROARCH.md,
+    // LDS table): 16/COLS rows per group.  The readers walk k contiguously and do not care.
+    static constexpr int GW = sizeof(T) == 8 ? (COLS >= 16 ? 1 : 16 / COLS) : G;
+    static constexpr int CS = ROWS + GW;
     static constexpr int E1S = P + (G > 1 ? 1 : 0);  // rows per n' in exchange 1 (P used + padding)
     static constexpr int TWR = ROWS > 1024 ? 32 + ROWS / 32 : 64;  // staged entries of the W_ROWS table (plan.hpp: host_twr)
     static constexpr int EXCH_E1 = M * E1S * COLS;
