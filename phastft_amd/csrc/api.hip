@@ -155,9 +155,35 @@ template <typename T> struct Planner {
     mutable std::recursive_mutex call_mu;
     mutable void *d_stage = nullptr;  // device staging of the host-slice entry points (grow-only)
     mutable size_t stage_bytes = 0;
+    mutable void *h_pin = nullptr;    // pinned host mirror of the staging buffer for SMALL host-slice calls
+    mutable size_t pin_bytes = 0;
     mutable size_t table_bytes = 0;
 
     ~Planner() { release(); }
+    // Host-slice calls up to this many staged bytes go through the pinned mirror (one memcpy each way on the host,
+    // one asynchronous copy each way over PCIe): hipMemcpy from pageable memory costs 50-200 us per call
+    // whatever the size, which is all a small transform's time.  Larger calls copy straight from the slices.
+    static size_t pinned_max_bytes() {
+        static const size_t v = [] {
+            const char *e = getenv("PHAST_PINNED_MAX_KB");
+            return (size_t)(e ? atol(e) : 1024) << 10;
+        }();
+        return v;
+    }
+    int pinned(size_t bytes, void **out) const {
+        if (pin_bytes < bytes) {
+            if (h_pin) {
+                hipDeviceSynchronize();
+                hipHostFree(h_pin);
+                h_pin = nullptr;
+                pin_bytes = 0;
+            }
+            PHAST_HIP(hipHostMalloc(&h_pin, bytes ? bytes : 1, hipHostMallocDefault));
+            pin_bytes = bytes;
+        }
+        *out = h_pin;
+        return PHAST_OK;
+    }
     // device staging buffer of at least `bytes` (call with call_mu held)
     int stage(size_t bytes, void **out) const {
         if (stage_bytes < bytes) {
@@ -190,6 +216,9 @@ template <typename T> struct Planner {
         if (d_small_tw) hipFree(d_small_tw);
         if (d_scratch) hipFree(d_scratch);
         if (d_stage) hipFree(d_stage);
+        if (h_pin) hipHostFree(h_pin);
+        h_pin = nullptr;
+        pin_bytes = 0;
         d_small_tw = nullptr;
         d_scratch = nullptr;
         d_stage = nullptr;
@@ -629,6 +658,53 @@ struct DevBuf {
     }
 };
 
+// Host slices <-> the planner's device staging buffer.  `parts` are (host pointer, byte offset in the staging
+// buffer, bytes); small totals travel through the pinned mirror (see Planner::pinned_max_bytes).
+struct HostPart {
+    void *host;
+    size_t off, bytes;
+};
+template <typename T>
+static int host_in(const Planner<T> *pl, void *d_stage, const HostPart *parts, int np, size_t total, bool small) {
+    if (small) {
+        void *pin = nullptr;
+        int rc = pl->pinned(total, &pin);
+        if (rc) return rc;
+        size_t lo = total, hi = 0;
+        for (int i = 0; i < np; ++i) {
+            std::memcpy((char *)pin + parts[i].off, parts[i].host, parts[i].bytes);
+            lo = std::min(lo, parts[i].off);
+            hi = std::max(hi, parts[i].off + parts[i].bytes);
+        }
+        if (hi > lo) PHAST_HIP(hipMemcpyAsync((char *)d_stage + lo, (char *)pin + lo, hi - lo, hipMemcpyHostToDevice, nullptr));
+        return PHAST_OK;
+    }
+    for (int i = 0; i < np; ++i)
+        PHAST_HIP(hipMemcpy((char *)d_stage + parts[i].off, parts[i].host, parts[i].bytes, hipMemcpyHostToDevice));
+    return PHAST_OK;
+}
+template <typename T>
+static int host_out(const Planner<T> *pl, void *d_stage, const HostPart *parts, int np, size_t total, bool small) {
+    if (small) {
+        void *pin = nullptr;
+        int rc = pl->pinned(total, &pin);
+        if (rc) return rc;
+        size_t lo = total, hi = 0;
+        for (int i = 0; i < np; ++i) {
+            lo = std::min(lo, parts[i].off);
+            hi = std::max(hi, parts[i].off + parts[i].bytes);
+        }
+        if (hi > lo) PHAST_HIP(hipMemcpyAsync((char *)pin + lo, (char *)d_stage + lo, hi - lo, hipMemcpyDeviceToHost, nullptr));
+        PHAST_HIP(hipStreamSynchronize(nullptr));
+        for (int i = 0; i < np; ++i) std::memcpy(parts[i].host, (char *)pin + parts[i].off, parts[i].bytes);
+        return PHAST_OK;
+    }
+    PHAST_HIP(hipStreamSynchronize(nullptr));
+    for (int i = 0; i < np; ++i)
+        PHAST_HIP(hipMemcpy(parts[i].host, (char *)d_stage + parts[i].off, parts[i].bytes, hipMemcpyDeviceToHost));
+    return PHAST_OK;
+}
+
 // lib.rs:143-226 on host slices: validate as the reference asserts, stage through device memory
 template <typename T>
 static int fft_host(T *re, size_t re_len, T *im, size_t im_len, int direction, const Planner<T> *pl) {
@@ -637,20 +713,18 @@ static int fft_host(T *re, size_t re_len, T *im, size_t im_len, int direction, c
     if (re_len != im_len) return PHAST_ERR_LEN_MISMATCH;     // dit.rs:284
     if (!is_pow2(re_len)) return PHAST_ERR_NOT_POW2;          // dit.rs:285
     if (ilog2(re_len) != pl->log_n) return PHAST_ERR_PLANNER_SIZE;  // dit.rs:289
-    const size_t n = re_len, bytes = n * sizeof(T);
+    const size_t n = re_len, bytes = n * sizeof(T), total = 2 * bytes;
     std::lock_guard<std::recursive_mutex> call_lock(pl->call_mu);
     void *stage = nullptr;
-    int rc = pl->stage(2 * bytes, &stage);
+    int rc = pl->stage(total, &stage);
     if (rc) return rc;
+    const bool small = total <= Planner<T>::pinned_max_bytes();
+    const HostPart parts[2] = {{re, 0, bytes}, {im, bytes, bytes}};
     T *d_re = reinterpret_cast<T *>(stage), *d_im = d_re + n;
-    PHAST_HIP(hipMemcpy(d_re, re, bytes, hipMemcpyHostToDevice));
-    PHAST_HIP(hipMemcpy(d_im, im, bytes, hipMemcpyHostToDevice));
-    rc = fft_dev<T>(d_re, d_im, n, 1, n, direction, pl, nullptr);
-    if (rc) return rc;
-    PHAST_HIP(hipStreamSynchronize(nullptr));
-    PHAST_HIP(hipMemcpy(re, d_re, bytes, hipMemcpyDeviceToHost));
-    PHAST_HIP(hipMemcpy(im, d_im, bytes, hipMemcpyDeviceToHost));
-    return PHAST_OK;
+    rc = host_in(pl, stage, parts, 2, total, small);
+    if (!rc) rc = fft_dev<T>(d_re, d_im, n, 1, n, direction, pl, nullptr);
+    if (!rc) rc = host_out(pl, stage, parts, 2, total, small);
+    return rc;
 }
 
 template <typename T> static int fft_interleaved_host(T *signal, size_t n, int direction, const Planner<T> *pl) {
@@ -658,15 +732,16 @@ template <typename T> static int fft_interleaved_host(T *signal, size_t n, int d
     if (!is_pow2(n)) return PHAST_ERR_NOT_POW2;
     if (ilog2(n) != pl->log_n) return PHAST_ERR_PLANNER_SIZE;
     std::lock_guard<std::recursive_mutex> call_lock(pl->call_mu);
+    const size_t total = 2 * n * sizeof(T);
     void *stage = nullptr;
-    int rc = pl->stage(2 * n * sizeof(T), &stage);
+    int rc = pl->stage(total, &stage);
     if (rc) return rc;
-    PHAST_HIP(hipMemcpy(stage, signal, 2 * n * sizeof(T), hipMemcpyHostToDevice));
-    rc = fft_interleaved_dev<T>(reinterpret_cast<T *>(stage), n, 1, n, direction, pl, nullptr);
-    if (rc) return rc;
-    PHAST_HIP(hipStreamSynchronize(nullptr));
-    PHAST_HIP(hipMemcpy(signal, stage, 2 * n * sizeof(T), hipMemcpyDeviceToHost));
-    return PHAST_OK;
+    const bool small = total <= Planner<T>::pinned_max_bytes();
+    const HostPart parts[1] = {{signal, 0, total}};
+    rc = host_in(pl, stage, parts, 1, total, small);
+    if (!rc) rc = fft_interleaved_dev<T>(reinterpret_cast<T *>(stage), n, 1, n, direction, pl, nullptr);
+    if (!rc) rc = host_out(pl, stage, parts, 1, total, small);
+    return rc;
 }
 
 template <typename T> static int fft_host_noplanner(T *re, size_t re_len, T *im, size_t im_len, int direction) {
@@ -688,17 +763,18 @@ static int r2c_host(const T *in, size_t in_len, T *ore, size_t ore_len, T *oim, 
     if (ore_len != half + 1) return PHAST_ERR_R2C_OUT_RE_LEN;
     if (oim_len != half + 1) return PHAST_ERR_R2C_OUT_IM_LEN;
     std::lock_guard<std::recursive_mutex> call_lock(pl->dit.call_mu);
+    const size_t ob = (half + 1) * sizeof(T), total = n * sizeof(T) + 2 * ob;
     void *stage = nullptr;
-    int rc = pl->dit.stage((n + 2 * (half + 1)) * sizeof(T), &stage);
+    int rc = pl->dit.stage(total, &stage);
     if (rc) return rc;
+    const bool small = total <= Planner<T>::pinned_max_bytes();
     T *d_in = reinterpret_cast<T *>(stage), *d_ore = d_in + n, *d_oim = d_ore + half + 1;
-    PHAST_HIP(hipMemcpy(d_in, in, n * sizeof(T), hipMemcpyHostToDevice));
-    rc = pl->r2c(d_in, d_ore, d_oim, 1, n, half + 1, nullptr);
-    if (rc) return rc;
-    PHAST_HIP(hipStreamSynchronize(nullptr));
-    PHAST_HIP(hipMemcpy(ore, d_ore, (half + 1) * sizeof(T), hipMemcpyDeviceToHost));
-    PHAST_HIP(hipMemcpy(oim, d_oim, (half + 1) * sizeof(T), hipMemcpyDeviceToHost));
-    return PHAST_OK;
+    const HostPart pin[1] = {{const_cast<T *>(in), 0, n * sizeof(T)}};
+    const HostPart pout[2] = {{ore, n * sizeof(T), ob}, {oim, n * sizeof(T) + ob, ob}};
+    rc = host_in(&pl->dit, stage, pin, 1, total, small);
+    if (!rc) rc = pl->r2c(d_in, d_ore, d_oim, 1, n, half + 1, nullptr);
+    if (!rc) rc = host_out(&pl->dit, stage, pout, 2, total, small);
+    return rc;
 }
 
 template <typename T>
@@ -712,17 +788,18 @@ static int c2r_host(const T *ire, size_t ire_len, const T *iim, size_t iim_len, 
     if (check_scratch && sre_len != half) return PHAST_ERR_C2R_SCRATCH_RE;
     if (check_scratch && sim_len != half) return PHAST_ERR_C2R_SCRATCH_IM;
     std::lock_guard<std::recursive_mutex> call_lock(pl->dit.call_mu);
+    const size_t ib = (half + 1) * sizeof(T), total = n * sizeof(T) + 2 * ib;
     void *stage = nullptr;
-    int rc = pl->dit.stage((n + 2 * (half + 1)) * sizeof(T), &stage);
+    int rc = pl->dit.stage(total, &stage);
     if (rc) return rc;
+    const bool small = total <= Planner<T>::pinned_max_bytes();
     T *d_out = reinterpret_cast<T *>(stage), *d_ire = d_out + n, *d_iim = d_ire + half + 1;
-    PHAST_HIP(hipMemcpy(d_ire, ire, (half + 1) * sizeof(T), hipMemcpyHostToDevice));
-    PHAST_HIP(hipMemcpy(d_iim, iim, (half + 1) * sizeof(T), hipMemcpyHostToDevice));
-    rc = pl->c2r(d_ire, d_iim, d_out, 1, half + 1, n, nullptr);
-    if (rc) return rc;
-    PHAST_HIP(hipStreamSynchronize(nullptr));
-    PHAST_HIP(hipMemcpy(out, d_out, n * sizeof(T), hipMemcpyDeviceToHost));
-    return PHAST_OK;
+    const HostPart pin[2] = {{const_cast<T *>(ire), n * sizeof(T), ib}, {const_cast<T *>(iim), n * sizeof(T) + ib, ib}};
+    const HostPart pout[1] = {{out, 0, n * sizeof(T)}};
+    rc = host_in(&pl->dit, stage, pin, 2, total, small);
+    if (!rc) rc = pl->c2r(d_ire, d_iim, d_out, 1, half + 1, n, nullptr);
+    if (!rc) rc = host_out(&pl->dit, stage, pout, 1, total, small);
+    return rc;
 }
 
 template <typename T> static int bitrev_host(T *data, size_t len, unsigned log_n) {
