@@ -377,6 +377,38 @@ template <typename T> struct Planner {
         return s;
     }
 
+    // Small real transforms (the N-point core runs in the one-pass kernel): R2C untangle / C2R preprocess fused
+    // into that kernel (row_fft.hpp, RowArgs::real_mode).  rtw3 = W_{2N} tables of the R2C planner.
+    int exec_small_real(unsigned mode, const void *in_a, const void *in_b, size_t in_dist, void *out_a, void *out_b,
+                        size_t out_dist, size_t batch, double scale, const void *rtw3, unsigned rtw_bits,
+                        hipStream_t stream) const {
+        if (batch == 0) return PHAST_OK;
+        std::lock_guard<std::recursive_mutex> call_lock(call_mu);
+        const size_t chunk = (size_t)1 << 30;
+        const size_t in_el = mode == 1 ? 2 * sizeof(T) : sizeof(T), out_el = mode == 1 ? sizeof(T) : 2 * sizeof(T);
+        for (size_t b0 = 0; b0 < batch; b0 += chunk) {
+            SmallArgs sa{};
+            const size_t nb = batch - b0 < chunk ? batch - b0 : chunk;
+            sa.in_re = (const char *)in_a + b0 * in_dist * in_el;
+            sa.in_im = in_b ? (const char *)in_b + b0 * in_dist * in_el : nullptr;
+            sa.out_re = (char *)out_a + b0 * out_dist * out_el;
+            sa.out_im = out_b ? (char *)out_b + b0 * out_dist * out_el : nullptr;
+            sa.tw = d_small_tw;
+            sa.in_dist = in_dist;
+            sa.out_dist = out_dist;
+            sa.log_n = log_n;
+            sa.batch = (unsigned)nb;
+            sa.in_interleaved = mode == 1 ? 1 : 0;
+            sa.out_interleaved = mode == 1 ? 0 : 2;
+            sa.scale = scale;
+            sa.real_mode = mode;
+            sa.rtw_bits = rtw_bits;
+            sa.rtw3 = rtw3;
+            PHAST_HIP(launch_small_fft<T>(sa, stream, nullptr, nullptr));
+        }
+        return PHAST_OK;
+    }
+
     // One batched transform: in -> out (may alias for the planar in-place case), forward arithmetic,
     // output scaled by `scale`.  in_mode/out_mode: 0 planar, 1 interleaved (re,im), 2 interleaved (im,re).
     int exec(const void *in_re, const void *in_im, size_t in_dist, unsigned in_mode, void *out_re, void *out_im,
@@ -513,6 +545,8 @@ template <typename T> struct PlannerR2c {
         const size_t half = n / 2;
         if (in_dist & 1) return PHAST_ERR_INVALID_ARG;  // the input is read as (even, odd) pairs
         std::lock_guard<std::recursive_mutex> call_lock(dit.call_mu);
+        if (dit.passes.empty())  // N/2 <= 8192: one kernel, the untangle is its epilogue
+            return dit.exec_small_real(1, d_in, nullptr, in_dist / 2, d_ore, d_oim, out_dist, batch, 1.0, d_tw3, tw_bits, s);
         int rc = dit.exec(d_in, nullptr, in_dist / 2, 1, d_ore, d_oim, out_dist, 0, batch, 1.0, s);
         if (rc) return rc;
         for (size_t b0 = 0; b0 < batch; b0 += 65535) {
@@ -535,6 +569,9 @@ template <typename T> struct PlannerR2c {
         const size_t half = n / 2;
         if (out_dist & 1) return PHAST_ERR_INVALID_ARG;
         std::lock_guard<std::recursive_mutex> call_lock(dit.call_mu);
+        if (dit.passes.empty())  // N/2 <= 8192: one kernel, the preprocess is its prologue
+            return dit.exec_small_real(2, d_ire, d_iim, in_dist, d_out, nullptr, out_dist / 2, batch, 1.0 / (double)half,
+                                       d_tw3, tw_bits, s);
         size_t cap = 0;
         int rc = ensure_z(batch, &cap);
         if (rc) return rc;

@@ -221,8 +221,15 @@ int phast_emu_fft_f32_modes(const float *in_re, const float *in_im, unsigned in_
 }
 // batches of small transforms (N = 2..2048) through the one-pass kernel's body (row_fft.hpp); modes as above
 static int emu_small(int is_f64, const void *in_re, const void *in_im, unsigned in_mode, void *out_re, void *out_im,
-                     unsigned out_mode, unsigned log_n, size_t batch, size_t in_dist, size_t out_dist, double scale) {
+                     unsigned out_mode, unsigned log_n, size_t batch, size_t in_dist, size_t out_dist, double scale,
+                     unsigned real_mode = 0) {
     phast::RowArgs r{};
+    const unsigned rbits = phast::tw3_bits_for(log_n + 1);
+    const std::vector<phast::cx_t<double>> r64 = phast::host_tw3<double>(log_n + 1, rbits);
+    const std::vector<phast::cx_t<float>> r32 = phast::host_tw3<float>(log_n + 1, rbits);
+    r.real_mode = real_mode;
+    r.rtw_bits = rbits;
+    r.rtw3 = is_f64 ? (const void *)r64.data() : (const void *)r32.data();
     r.in_re = in_re;
     r.in_im = in_im;
     r.out_re = out_re;
@@ -251,6 +258,15 @@ static int emu_small(int is_f64, const void *in_re, const void *in_im, unsigned 
 int phast_emu_small_fft(int is_f64, const void *in_re, const void *in_im, unsigned in_mode, void *out_re, void *out_im,
                         unsigned out_mode, unsigned log_n, size_t batch, size_t in_dist, size_t out_dist, double scale) {
     return emu_small(is_f64, in_re, in_im, in_mode, out_re, out_im, out_mode, log_n, batch, in_dist, out_dist, scale);
+}
+// real transforms of n = 2 * 2^log_half points through the fused kernel: mode 1 = R2C (in: n reals per transform,
+// in_dist apart; out: planar n/2 + 1), mode 2 = C2R (in: planar n/2 + 1; out: n reals, scaled by 1/(n/2))
+int phast_emu_small_real(int is_f64, unsigned mode, const void *in_a, const void *in_b, void *out_a, void *out_b,
+                         unsigned log_half, size_t batch, size_t in_dist, size_t out_dist) {
+    if (mode == 1)
+        return emu_small(is_f64, in_a, nullptr, 1, out_a, out_b, 0, log_half, batch, in_dist / 2, out_dist, 1.0, 1);
+    return emu_small(is_f64, in_a, in_b, 0, out_a, nullptr, 2, log_half, batch, in_dist, out_dist / 2,
+                     1.0 / (double)((size_t)1 << log_half), 2);
 }
 // LDS audit of the small-transform kernel: park / pick and every exchange in bounds, permutations, conflict-free
 int phast_emu_audit_small(int is_f64, unsigned log_n, int *max_read_ways, int *max_write_ways) {

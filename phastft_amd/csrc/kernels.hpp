@@ -19,6 +19,11 @@ struct SmallArgs {
     unsigned in_interleaved;
     unsigned out_interleaved;  // 1 = (re, im), 2 = (im, re)
     double scale;
+    // real transforms of 2N points around this N-point core (row_fft.hpp: RowArgs::real_mode): 0 none,
+    // 1 R2C untangle as the epilogue, 2 C2R preprocess as the prologue; rtw3 = W_{2N} tables
+    unsigned real_mode;
+    unsigned rtw_bits;
+    const void *rtw3;
 };
 constexpr unsigned kSmallMaxLog = 13;
 template <typename T>

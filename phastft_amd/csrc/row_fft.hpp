@@ -31,6 +31,14 @@ struct RowArgs {
     unsigned in_interleaved;   // 0 planar, 1 (re, im) pairs, 2 (im, re) pairs
     unsigned out_interleaved;
     double scale;
+    // Real transforms of 2N points whose N-point complex core this kernel runs (REAL instantiations only):
+    //   1 = R2C: the untangle (algorithms/r2c.rs:150-242) is the epilogue -- input = the real signal read as N
+    //       (even, odd) pairs (in_interleaved = 1), output = planar X[0..N] (N + 1 values, out_dist apart);
+    //   2 = C2R: the preprocess (algorithms/r2c.rs:263-433) is the prologue -- input = planar X[0..N], output =
+    //       the real signal written as N (im, re) pairs of the swap-trick inverse (out_interleaved = 2).
+    unsigned real_mode;
+    unsigned rtw_bits;
+    const void *rtw3;          // [3][1 << rtw_bits] complex: W_{2N}^e
 };
 
 template <typename T, int LR, int LC, int LP> struct RowBody {
@@ -109,9 +117,80 @@ template <typename T, int LR, int LC, int LP> struct RowBody {
             }
         });
     }
+
+    // ---- R2C epilogue: the transposing exchange has been WRITTEN (plane [transform][k], pitch CS); pairs
+    // (k, N - k) of one transform are untangled straight from LDS into the planar output (r2c.rs:150-242) ----
+    PHAST_HD static void untangle_store(const RowArgs &a, unsigned tile, int tid, const T *z_re, const T *z_im,
+                                        const cx *rtab) {
+        constexpr int Q = ROWS / 2, CS = Body::CS;
+        const unsigned long long xf0 = (unsigned long long)tile << LC;
+        T *out_re = reinterpret_cast<T *>(a.out_re), *out_im = reinterpret_cast<T *>(a.out_im);
+        for (int g = tid; g < COLS * Q; g += NT) {  // k in [0, Q): k = 0 is the DC / Nyquist pair
+            const int col = g / Q, k = g - col * Q;
+            const unsigned long long xf = xf0 + col;
+            if (xf >= a.batch) continue;
+            const size_t o = (size_t)xf * a.out_dist;
+            const T x = z_re[col * CS + k], y = z_im[col * CS + k];
+            if (k == 0) {  // r2c.rs:161-166
+                out_re[o] = x + y;
+                out_im[o] = (T)0;
+                out_re[o + ROWS] = x - y;
+                out_im[o + ROWS] = (T)0;
+                continue;
+            }
+            T wr, wi;
+            tw3_lookup<T>(rtab, a.rtw_bits, (unsigned)k, wr, wi);
+            wr *= (T)0.5;
+            wi *= (T)0.5;
+            const T c = z_re[col * CS + ROWS - k], d = z_im[col * CS + ROWS - k];
+            const T s_re = (T)0.5 * (x + c), s_im = (T)0.5 * (y - d), t_re = y + d, t_im = c - x;
+            const T wzr = wr * t_re - wi * t_im, wzi = wr * t_im + wi * t_re;
+            out_re[o + k] = s_re + wzr;
+            out_im[o + k] = s_im + wzi;
+            out_re[o + ROWS - k] = s_re - wzr;
+            out_im[o + ROWS - k] = wzi - s_im;
+        }
+        for (int col = tid; col < COLS; col += NT) {  // k = Q: r2c.rs:233-236
+            const unsigned long long xf = xf0 + col;
+            if (xf >= a.batch) continue;
+            T wr, wi;
+            tw3_lookup<T>(rtab, a.rtw_bits, (unsigned)Q, wr, wi);
+            const T x = z_re[col * CS + Q], y = z_im[col * CS + Q];
+            if (Q == 0) continue;
+            out_re[(size_t)xf * a.out_dist + Q] = x + wr * y;  // 2 * (0.5 w) = w
+            out_im[(size_t)xf * a.out_dist + Q] = wi * y;
+        }
+    }
+    // ---- C2R prologue: z[k] from X[k], X[N - k] (r2c.rs:263-433), parked with re and im swapped -- the
+    // swap-trick inverse (algorithms/dit.rs:297-300) runs the forward chain on (z_im, z_re) ----
+    PHAST_HD static void c2r_park(const RowArgs &a, unsigned tile, int tid, T *st_re, T *st_im, const cx *rtab) {
+        const unsigned long long xf0 = (unsigned long long)tile << LC;
+        const T *in_re = reinterpret_cast<const T *>(a.in_re), *in_im = reinterpret_cast<const T *>(a.in_im);
+        for (int g = tid; g < COLS * ROWS; g += NT) {
+            const int col = g >> LR, k = g & (ROWS - 1);
+            const unsigned long long xf = xf0 + col;
+            T zr = (T)0, zi = (T)0;
+            if (xf < a.batch) {
+                const size_t o = (size_t)xf * a.in_dist;
+                T c_h, s_h;
+                tw3_lookup<T>(rtab, a.rtw_bits, (unsigned)k, c_h, s_h);
+                c_h *= (T)0.5;
+                s_h *= (T)0.5;
+                const T re_first = in_re[o + k], im_first = in_im[o + k];
+                const T re_second = in_re[o + ROWS - k], im_second = -in_im[o + ROWS - k];
+                const T zx_re = (T)0.5 * (re_first + re_second), zx_im = (T)0.5 * (im_first + im_second);
+                const T dr = re_first - re_second, di = im_first - im_second;
+                const T zy_re = c_h * dr + s_h * di, zy_im = c_h * di - s_h * dr;
+                zr = zx_re - zy_im;
+                zi = zx_im + zy_re;
+            }
+            st_re[col * PITCH + k] = zi;  // swapped on purpose
+            st_im[col * PITCH + k] = zr;
+        }
+    }
 };
 
-template <typename T, int LR, int LC, int LP>
+template <typename T, int LR, int LC, int LP, bool REAL>
 __global__ void __launch_bounds__(1 << (LR + LC - LP)) row_fft_kernel(const RowArgs a) {
     using RB = RowBody<T, LR, LC, LP>;
     using Body = typename RB::Body;
@@ -119,13 +198,17 @@ __global__ void __launch_bounds__(1 << (LR + LC - LP)) row_fft_kernel(const RowA
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T *buf = reinterpret_cast<T *>(smem);
     cx *l_twr = reinterpret_cast<cx *>(smem + (size_t)2 * RB::PLANE * sizeof(T));
+    cx *l_rtw = l_twr + RB::TWR;  // REAL only: W_{2N} three-level tables
     const typename Body::Shared sh{buf, buf + RB::PLANE, nullptr, l_twr};
+    const unsigned mode = REAL ? a.real_mode : 0u;
 
     int tid = threadIdx.x;
     typename Body::Regs r;
     unsigned t = blockIdx.x;
-    if (t < a.tiles_total) RB::load_flat(a, t, tid, r);  // in flight while the table arrives
+    if (mode != 2 && t < a.tiles_total) RB::load_flat(a, t, tid, r);  // in flight while the tables arrive
     for (int i = tid; i < RB::TWR; i += RB::NT) l_twr[i] = reinterpret_cast<const cx *>(a.twr)[i];
+    if constexpr (REAL)
+        for (unsigned i = tid; i < (3u << a.rtw_bits); i += RB::NT) l_rtw[i] = reinterpret_cast<const cx *>(a.rtw3)[i];
 
     auto exchange = [&](auto e) {
         constexpr int E = decltype(e)::value;
@@ -133,6 +216,7 @@ __global__ void __launch_bounds__(1 << (LR + LC - LP)) row_fft_kernel(const RowA
         Body::template ex_write<E>(sh, tid, r, 0);
         Body::template ex_write<E>(sh, tid, r, 1);
         __syncthreads();
+        if (REAL && E == Body::S && mode == 1) return;  // R2C: the untangle reads the transposed tile from LDS itself
         Body::template ex_read<E>(sh, tid, r, 0);
         Body::template ex_read<E>(sh, tid, r, 1);
     };
@@ -140,22 +224,24 @@ __global__ void __launch_bounds__(1 << (LR + LC - LP)) row_fft_kernel(const RowA
 
     while (t < a.tiles_total) {
         asm volatile("" : "+v"(tid));  // per-tile address recomputation instead of ~100 hoisted values (tile_fft.hpp)
-        __syncthreads();               // the previous tile's readers are done with the LDS buffer
-        RB::park(buf, buf + RB::PLANE, tid, r);
+        __syncthreads();               // the previous tile's readers are done with the LDS buffer (and the tables are in)
+        if (REAL && mode == 2) RB::c2r_park(a, t, tid, buf, buf + RB::PLANE, l_rtw);
+        else RB::park(buf, buf + RB::PLANE, tid, r);
         __syncthreads();
         RB::pick(buf, buf + RB::PLANE, tid, r);
         Body::chain(do_step, exchange);
-        RB::store_flat(a, t, tid, r);
+        if (REAL && mode == 1) RB::untangle_store(a, t, tid, buf, buf + RB::PLANE, l_rtw);
+        else RB::store_flat(a, t, tid, r);
         t += gridDim.x;
-        if (t < a.tiles_total) RB::load_flat(a, t, tid, r);
+        if (mode != 2 && t < a.tiles_total) RB::load_flat(a, t, tid, r);
     }
 }
 
-template <typename T, int LR, int LC, int LP>
+template <typename T, int LR, int LC, int LP, bool REAL>
 hipError_t launch_row_inst(const RowArgs &a, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     using RB = RowBody<T, LR, LC, LP>;
-    auto kern = row_fft_kernel<T, LR, LC, LP>;
-    const size_t lds = RB::lds_bytes();
+    auto kern = row_fft_kernel<T, LR, LC, LP, REAL>;
+    const size_t lds = RB::lds_bytes() + (REAL ? ((size_t)3 << a.rtw_bits) * sizeof(cx_t<T>) : 0);
     static bool raised = false;  // once per instantiation: nothing but the launch in the steady state (graph capture)
     if (!raised) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -194,9 +280,12 @@ template <typename T, int LR, int LC, int LP> void emulate_row_fft(const RowArgs
     using RB = RowBody<T, LR, LC, LP>;
     using Body = typename RB::Body;
     using Regs = typename Body::Regs;
+    using cx = cx_t<T>;
     constexpr int NT = RB::NT;
     T *buf = new T[(size_t)2 * RB::PLANE];
-    const typename Body::Shared sh{buf, buf + RB::PLANE, nullptr, reinterpret_cast<const cx_t<T> *>(a.twr)};
+    const typename Body::Shared sh{buf, buf + RB::PLANE, nullptr, reinterpret_cast<const cx *>(a.twr)};
+    const cx *rtab = reinterpret_cast<const cx *>(a.rtw3);
+    const unsigned mode = a.real_mode;
     Regs *regs = new Regs[NT];
     auto exchange = [&](auto e) {
         constexpr int E = decltype(e)::value;
@@ -204,6 +293,7 @@ template <typename T, int LR, int LC, int LP> void emulate_row_fft(const RowArgs
             Body::template ex_write<E>(sh, t, regs[t], 0);
             Body::template ex_write<E>(sh, t, regs[t], 1);
         }
+        if (E == Body::S && mode == 1) return;
         for (int t = 0; t < NT; ++t) {
             Body::template ex_read<E>(sh, t, regs[t], 0);
             Body::template ex_read<E>(sh, t, regs[t], 1);
@@ -213,11 +303,19 @@ template <typename T, int LR, int LC, int LP> void emulate_row_fft(const RowArgs
         for (int t = 0; t < NT; ++t) Body::template step<decltype(i)::value>(sh, t, regs[t]);
     };
     for (unsigned tile = 0; tile < a.tiles_total; ++tile) {
-        for (int t = 0; t < NT; ++t) RB::load_flat(a, tile, t, regs[t]);
-        for (int t = 0; t < NT; ++t) RB::park(buf, buf + RB::PLANE, t, regs[t]);
+        if (mode == 2) {
+            for (int t = 0; t < NT; ++t) RB::c2r_park(a, tile, t, buf, buf + RB::PLANE, rtab);
+        } else {
+            for (int t = 0; t < NT; ++t) RB::load_flat(a, tile, t, regs[t]);
+            for (int t = 0; t < NT; ++t) RB::park(buf, buf + RB::PLANE, t, regs[t]);
+        }
         for (int t = 0; t < NT; ++t) RB::pick(buf, buf + RB::PLANE, t, regs[t]);
         Body::chain(do_step, exchange);
-        for (int t = 0; t < NT; ++t) RB::store_flat(a, tile, t, regs[t]);
+        if (mode == 1) {
+            for (int t = 0; t < NT; ++t) RB::untangle_store(a, tile, t, buf, buf + RB::PLANE, rtab);
+        } else {
+            for (int t = 0; t < NT; ++t) RB::store_flat(a, tile, t, regs[t]);
+        }
     }
     delete[] regs;
     delete[] buf;

@@ -39,7 +39,7 @@ template <typename T> __global__ void __launch_bounds__(256) one_point_kernel(co
 template <typename T>
 hipError_t launch_small_fft(const SmallArgs &a, hipStream_t stream, hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (a.batch == 0) return hipSuccess;
-    if (a.log_n == 0) {
+    if (a.log_n == 0) {  // (never with real_mode: a real transform has at least 4 points, its core 2)
         const unsigned grid = (unsigned)((a.batch + 255) / 256 < 4096 ? (a.batch + 255) / 256 : 4096);
         if (ev_start && ev_stop)
             hipExtLaunchKernelGGL(one_point_kernel<T>, dim3(grid), dim3(256), 0, stream, ev_start, ev_stop, 0, a);
@@ -59,10 +59,15 @@ hipError_t launch_small_fft(const SmallArgs &a, hipStream_t stream, hipEvent_t e
     r.in_interleaved = a.in_interleaved;
     r.out_interleaved = a.out_interleaved;
     r.scale = a.scale;
+    r.real_mode = a.real_mode;
+    r.rtw_bits = a.rtw_bits;
+    r.rtw3 = a.rtw3;
     const unsigned lc = row_tile_cols_log(a.log_n);
     r.tiles_total = (unsigned)((a.batch + ((1ull << lc) - 1)) >> lc);
-#define PHAST_ROW_CASE(LR_, LC_, LP_) \
-    if (a.log_n == LR_) return launch_row_inst<T, LR_, LC_, LP_>(r, stream, ev_start, ev_stop);
+#define PHAST_ROW_CASE(LR_, LC_, LP_)                                                                       \
+    if (a.log_n == LR_)                                                                                     \
+        return a.real_mode ? launch_row_inst<T, LR_, LC_, LP_, true>(r, stream, ev_start, ev_stop)          \
+                           : launch_row_inst<T, LR_, LC_, LP_, false>(r, stream, ev_start, ev_stop);
     PHAST_ROW_SHAPES(PHAST_ROW_CASE)
 #undef PHAST_ROW_CASE
     return hipErrorInvalidValue;

@@ -193,3 +193,42 @@ def test_small_transforms_interleaved_modes(emu, oracle):
     pr, pi = np.zeros(n * batch), np.zeros(n * batch)
     assert _small(emu, 1, out_re, out_im, 0, pr, pi, 0, log_n, batch, n, n, 0.5) == 0
     assert np.array_equal(back_re, pr) and np.array_equal(back_im, pi)
+
+
+@pytest.mark.parametrize("log_half", list(range(1, 14)))
+def test_small_real_transforms_fused_untangle_and_preprocess(emu, oracle, log_half):
+    """R2C with the untangle as the one-pass kernel's epilogue and C2R with the preprocess as its prologue
+    (n = 4 .. 16384 real points), ragged batches, against the oracle's r2c / c2r."""
+    emu.phast_emu_small_real.argtypes = [C.c_int, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint,
+                                         C.c_size_t, C.c_size_t, C.c_size_t]
+    p = lambda x: None if x is None else x.ctypes.data_as(C.c_void_p)
+    n = 2 << log_half
+    half = n // 2
+    per_tile = {1: 256, 2: 256, 3: 256, 4: 256, 5: 128}.get(log_half, max(1, 4096 // half))
+    batch = per_tile + max(1, per_tile // 2) + 1
+    for dtype, is_f64, tol, r2c, c2r in ((np.float64, 1, 1e-9, oracle.r2c_fft_f64, oracle.c2r_fft_f64),
+                                         (np.float32, 0, 1e-5, oracle.r2c_fft_f32, oracle.c2r_fft_f32)):
+        x = np.empty(batch * n, dtype)
+        for b in range(batch):
+            x[b * n:(b + 1) * n] = oracle.fill(n, dtype, transform_id=31 * log_half + b)[0]
+        ore = np.zeros(batch * (half + 1), dtype)
+        oim = np.zeros(batch * (half + 1), dtype)
+        assert emu.phast_emu_small_real(is_f64, 1, p(x), None, p(ore), p(oim), log_half, batch, n, half + 1) == 0
+        for b in (0, per_tile - 1, per_tile, batch - 1):
+            rr, ri = np.zeros(half + 1, dtype), np.zeros(half + 1, dtype)
+            r2c(x[b * n:(b + 1) * n].copy(), rr, ri)
+            sl = slice(b * (half + 1), (b + 1) * (half + 1))
+            num = np.sqrt(np.sum((ore[sl].astype(np.float64) - rr) ** 2 + (oim[sl].astype(np.float64) - ri) ** 2))
+            den = np.sqrt(np.sum(rr.astype(np.float64) ** 2 + ri.astype(np.float64) ** 2))
+            assert num / den <= tol, (log_half, b, num / den)
+        back = np.zeros(batch * n, dtype)
+        assert emu.phast_emu_small_real(is_f64, 2, p(ore), p(oim), p(back), None, log_half, batch, half + 1, n) == 0
+        assert np.max(np.abs(back - x)) < (1e-12 if is_f64 else 2e-5), log_half
+        b = batch - 1  # and against the oracle's own c2r of the oracle's spectrum
+        rr, ri = np.zeros(half + 1, dtype), np.zeros(half + 1, dtype)
+        r2c(x[b * n:(b + 1) * n].copy(), rr, ri)
+        want = np.zeros(n, dtype)
+        c2r(rr, ri, want)
+        got = np.zeros(n, dtype)
+        assert emu.phast_emu_small_real(is_f64, 2, p(rr), p(ri), p(got), None, log_half, 1, half + 1, n) == 0
+        assert np.max(np.abs(got - want)) < (1e-12 if is_f64 else 2e-5)
