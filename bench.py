@@ -17,6 +17,9 @@ second over the whole job, inputs resident in HBM when the timed region starts.
     path has no exchange step, so there is no data-path collective; RCCL (torch.distributed "nccl") only
     carries the barrier, the max-over-ranks time and the trivial digest gather.
 
+At N = 1 the line also carries "weak_scaling_reference": one rank's shard of the N > 1 workload timed on this one
+GPU -- the denominator for scaling efficiency (the N = 1 headline is ONE transform, a different workload).
+
 Extra objects on the JSON line: "roofline" (HIP-event duration of the dominant pass kernel vs the
 8 TB/s HBM peak) and "cpu_baseline" (the oracle -- a C restatement of the
 reference's CPU algorithm -- timed on this host on a bounded sample; rank 0, N = 1 only).
@@ -84,6 +87,27 @@ def cpu_baseline(budget_s: float = 12.0):
                                        f"({avail} schedulable); rayon::join emulated with OpenMP tasks (2-way bit "
                                        f"reversal, recursive join while size > 16384, spanning stages serial)"},
     }
+
+
+def shard_on_one_gpu(P, torch, dev, shard: int, steps: int = 3):
+    """The per-GPU workload of the --gpus N > 1 runs (BASELINE configs[4]: `shard` transforms of 2^20 per GPU,
+    transformed in place per step) timed on this one GPU: the denominator for weak-scaling efficiency.  The N = 1
+    headline above is a different workload (ONE transform, configs[1]) and must not be used for that."""
+    pl = P.PlannerDit64(N)
+    re = torch.empty(shard * N, dtype=torch.float64, device=dev)
+    im = torch.empty_like(re)
+    P.fill_uniform(re, im, N, seed=0xCAFE, first_id=0)
+    P.fft_dit_batched(re, im, N, P.Direction.Forward, pl)  # warm-up (scratch allocation)
+    P.fill_uniform(re, im, N, seed=0xCAFE, first_id=0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        P.fft_dit_batched(re, im, N, P.Direction.Forward, pl)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"workload": f"{shard} independent f64 forward FFTs N=2^{LOG_N} on 1 GPU, in place (one rank's shard of "
+                        f"BASELINE configs[4])", "value": shard * N * steps / dt / 1e9, "unit": "GSamples/s",
+            "steps": steps, "ms_per_step": 1e3 * dt / steps}
 
 
 def kernel_tags(plan_text: str, latency: bool):
@@ -295,6 +319,8 @@ def main():
             probe = hbm_copy_probe(torch, dev)
             roofline["copy_probe_GBps"] = probe          # measured d2d copy rate of this box, same run
             roofline["frac_of_copy_probe"] = achieved / probe
+        if n_gpus == 1:
+            out["weak_scaling_reference"] = shard_on_one_gpu(P, torch, dev, args.shard)
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         if n_gpus == 1 and args.extra:
