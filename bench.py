@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly from Python")
+    ap.add_argument("--no-scaling-reference", action="store_true",
+                    help="skip the one-GPU run of the sharded workload (profiling runs of the headline kernels)")
     ap.add_argument("--shard", type=int, default=SHARD, help="transforms per GPU when --gpus > 1")
     ap.add_argument("--extra", action="store_true", help="also measure N=2^26 and the batched shard at --gpus 1")
     ap.add_argument("--plan", default=None, help="experiment: force a plan, e.g. 6,8,6@12p8 (default: the library's own)")
@@ -319,7 +321,7 @@ def main():
             probe = hbm_copy_probe(torch, dev)
             roofline["copy_probe_GBps"] = probe          # measured d2d copy rate of this box, same run
             roofline["frac_of_copy_probe"] = achieved / probe
-        if n_gpus == 1:
+        if n_gpus == 1 and not args.no_scaling_reference:
             out["weak_scaling_reference"] = shard_on_one_gpu(P, torch, dev, args.shard)
         if n_gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
@@ -348,10 +350,19 @@ def load_profiled_traffic(n_gpus, dom, n_passes, kernel_tags):
     if key not in t:
         return None
     ks = t[key].get("kernels", [])
-    if len(ks) != n_passes or any(tag not in ks[i]["kernel"] for i, tag in enumerate(kernel_tags)):
-        return None  # the profile was taken with another plan
-    return {"traffic": ks[dom]["hbm_bytes_per_launch"], "traffic_source": t[key]["source"],
-            "traffic_kernel": ks[dom]["kernel"]}
+    # the profile may hold other kernels too: pick, pass by pass, the entries of THIS plan (first / later passes differ
+    # in the PRE_TW, TRANSPOSE flags that follow the shape in the kernel's name)
+    picked = []
+    for i, tag in enumerate(kernel_tags):
+        flags = " false, true," if i == 0 else " true, false,"
+        hits = [k for k in ks if tag + flags in k["kernel"]]
+        if len(hits) != 1:
+            return None  # the profile was taken with another plan
+        picked.append(hits[0])
+    if len(picked) != n_passes:
+        return None
+    return {"traffic": picked[dom]["hbm_bytes_per_launch"], "traffic_source": t[key]["source"],
+            "traffic_kernel": picked[dom]["kernel"]}
 
 
 def extra_measurements(P, torch, dev):
