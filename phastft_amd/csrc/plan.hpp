@@ -93,7 +93,9 @@ template <typename T> inline std::vector<cx_t<T>> host_twr(unsigned rows) {
 #define PHAST_TILE_SHAPES(X)                                                                                  \
     X(6, 6, 4) X(7, 5, 4) X(8, 4, 4) X(9, 3, 4) X(10, 2, 4) X(7, 6, 4) X(8, 5, 4) X(9, 4, 4) X(10, 3, 4)      \
     X(8, 6, 4) X(9, 5, 4) X(10, 4, 4) X(6, 6, 3) X(7, 5, 3) X(8, 4, 3) X(9, 3, 3) X(10, 2, 3)                 \
-    X(10, 4, 5) X(9, 5, 5) X(8, 6, 5) X(10, 3, 5) X(9, 4, 5) X(8, 5, 5) X(10, 2, 5) X(11, 3, 5)
+    X(10, 4, 5) X(9, 5, 5) X(8, 6, 5) X(10, 3, 5) X(9, 4, 5) X(8, 5, 5) X(10, 2, 5) X(11, 3, 5)                \
+    X(6, 5, 3) X(7, 4, 3) X(8, 3, 3) X(6, 4, 3) X(7, 3, 3) X(6, 5, 4) X(7, 4, 4) X(8, 3, 4) X(6, 4, 4) X(7, 3, 4) \
+    X(7, 4, 5)
 
 // 4-byte elements only: 32768-point tiles (1024 threads x 32 points), rows twice as wide again; an f64 tile
 // of that size does not fit the LDS.

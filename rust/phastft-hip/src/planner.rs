@@ -1,0 +1,80 @@
+//! `phastft::planner` (planner.rs:10-212): `Direction`, `PlannerMode` and the four planners.  A planner owns
+//! device twiddle tables and device scratch inside `libphastft_hip.so`; like the reference's planners it is an
+//! immutable value any number of callers may borrow (`Send + Sync`, planner.rs:38-39) -- the library serialises
+//! the calls that share one planner's scratch.
+use crate::ffi::{self, Opaque};
+use std::ffi::c_int;
+
+/// planner.rs:10-16
+#[derive(Copy, Clone)]
+pub enum Direction {
+    Forward = 1,
+    Reverse = -1,
+}
+
+/// planner.rs:24-32 (`Tune` is accepted and ignored, as in the reference: planner.rs:65)
+#[derive(Copy, Clone, Debug, Default)]
+pub enum PlannerMode {
+    #[default]
+    Heuristic,
+    Tune,
+}
+
+macro_rules! impl_planner_dit {
+    ($name:ident, $new:ident, $free:ident) => {
+        /// planner.rs:34-114
+        pub struct $name {
+            pub(crate) h: *mut Opaque,
+        }
+        // SAFETY: the handle is immutable after creation; calls on one planner are serialised inside the library
+        unsafe impl Send for $name {}
+        unsafe impl Sync for $name {}
+        impl $name {
+            /// planner.rs:55 -- panics unless `num_points` is a power of two > 0 (planner.rs:66)
+            pub fn new(num_points: usize) -> Self {
+                Self::with_mode(num_points, PlannerMode::Heuristic)
+            }
+            /// planner.rs:65
+            pub fn with_mode(num_points: usize, mode: PlannerMode) -> Self {
+                let mut h = std::ptr::null_mut();
+                ffi::check(unsafe { ffi::$new(num_points, mode as c_int, &mut h) });
+                Self { h }
+            }
+        }
+        impl Drop for $name {
+            fn drop(&mut self) {
+                unsafe { ffi::$free(self.h) }
+            }
+        }
+    };
+}
+impl_planner_dit!(PlannerDit64, phast_planner_dit64_with_mode, phast_planner_dit64_free);
+impl_planner_dit!(PlannerDit32, phast_planner_dit32_with_mode, phast_planner_dit32_free);
+
+macro_rules! impl_planner_r2c {
+    ($name:ident, $new:ident, $free:ident) => {
+        /// planner.rs:164-212 -- one planner drives both R2C and C2R (planner.rs:171-172)
+        pub struct $name {
+            pub(crate) h: *mut Opaque,
+            pub(crate) n: usize,
+        }
+        // SAFETY: as for the DIT planners
+        unsafe impl Send for $name {}
+        unsafe impl Sync for $name {}
+        impl $name {
+            /// planner.rs:194 -- panics with "n must be a power of 2 >= 4" (planner.rs:195)
+            pub fn new(n: usize) -> Self {
+                let mut h = std::ptr::null_mut();
+                ffi::check(unsafe { ffi::$new(n, &mut h) });
+                Self { h, n }
+            }
+        }
+        impl Drop for $name {
+            fn drop(&mut self) {
+                unsafe { ffi::$free(self.h) }
+            }
+        }
+    };
+}
+impl_planner_r2c!(PlannerR2c64, phast_planner_r2c64_new, phast_planner_r2c64_free);
+impl_planner_r2c!(PlannerR2c32, phast_planner_r2c32_new, phast_planner_r2c32_free);

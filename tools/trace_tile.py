@@ -1,7 +1,13 @@
 #!/usr/bin/env python3
-"""Phase timeline of the tile kernels for one transform (s_memtime stamps).
+"""Phase timeline of the tile kernels for one transform (s_memtime stamps of every workgroup's FIRST tile).
 
-    python -m phastft_amd.build --trace && PHASTFT_HIP_LIB=phastft_amd/lib/libphastft_hip_trace.so python tools/trace_tile.py 20
+    python -m phastft_amd.build --trace
+    PHASTFT_HIP_LIB=phastft_amd/lib/libphastft_hip_trace.so python tools/trace_tile.py 20 "7,6,7@11,10,11p8" ...
+
+Prints, per pass, when each phase boundary is reached (ticks since the first workgroup entered the kernel; min /
+mean / max over the workgroups): stamp 0 = entry, 1 = tables in LDS, 2 = tile loaded (+ pre-twiddle), then one per
+radix step / exchange, last = stores retired.  The stamps drain vmcnt/lgkmcnt, so the instrumented kernel is slower
+than the product kernel; the RELATIVE sizes of the phases are what this is for.
 """
 import ctypes as C
 import os
@@ -15,13 +21,17 @@ from phastft_amd import _lib  # noqa: E402
 
 lib = _lib.lib()
 log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-plans = [((10, 10), 12), ((10, 10), 13), ((7, 7, 6), 12)] if log_n == 20 else [((), 12)]
+specs = sys.argv[2:] or ["default"]
 n = 1 << log_n
-for lrs, tl in plans:
+for spec in specs:
     pl = P.PlannerDit64(n)
-    if lrs:
-        pl.set_plan(lrs, tl)
-    re = torch.empty(n * 8, dtype=torch.float64, device="cuda")
+    if spec != "default":
+        lrs_s, rest = spec.split("@")
+        tl_s, p_s = rest.split("p")
+        pl.set_plan(tuple(int(x) for x in lrs_s.split(",")), tuple(int(x) for x in tl_s.split(",")),
+                    {8: 3, 16: 4, 32: 5}[int(p_s)])
+    ring = 40
+    re = torch.empty(n * ring, dtype=torch.float64, device="cuda")
     im = torch.empty_like(re)
     P.fill_uniform(re, im, n)
     for i in range(3):
@@ -29,11 +39,11 @@ for lrs, tl in plans:
     torch.cuda.synchronize()
     trace = torch.zeros(3 * 4096 * 16, dtype=torch.int64, device="cuda")
     lib.phast_debug_set_trace(C.c_void_p(trace.data_ptr()))
-    P.fft_dit_batched(re[4 * n:5 * n], im[4 * n:5 * n], n, P.Direction.Forward, pl)
+    P.fft_dit_batched(re[(ring - 1) * n:ring * n], im[(ring - 1) * n:ring * n], n, P.Direction.Forward, pl)
     torch.cuda.synchronize()
     lib.phast_debug_set_trace(C.c_void_p(0))
     t = trace.cpu().numpy().reshape(3, 4096, 16).astype("float64")
-    print(pl.describe())
+    print(spec, pl.describe())
     for p in range(3):
         tp = t[p]
         tp = tp[tp[:, 0] != 0]
@@ -42,8 +52,8 @@ for lrs, tl in plans:
         nst = int((tp[0] != 0).sum())
         tp = tp[:, :nst]
         t0 = tp[:, 0].min()
-        d = tp[:, 1:] - tp[:, :-1]  # per-phase ticks (s_memtime = shader cycles on gfx950)
-        print(f" pass {p}: {len(tp)} workgroups, entry spread {tp[:, 0].max() - t0:.0f} ticks, "
-              f"kernel span {tp[:, -1].max() - t0:.0f} ticks")
-        print(f"   phase ticks mean: {[int(x) for x in d.mean(0)]}")
-        print(f"   phase ticks max : {[int(x) for x in d.max(0)]}")
+        rel = tp - t0
+        print(f" pass {p}: {len(tp)} workgroups traced; stamp: min / mean / max ticks since first entry")
+        for s in range(nst):
+            print(f"   stamp {s:2d}: {rel[:, s].min():7.0f} {rel[:, s].mean():7.0f} {rel[:, s].max():7.0f}"
+                  f"   (phase mean {0 if s == 0 else (tp[:, s] - tp[:, s - 1]).mean():6.0f})")
