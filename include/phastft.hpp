@@ -150,13 +150,29 @@ inline void fft_32_interleaved_with_planner(Slice<std::complex<float>> signal, D
                                                 planner.get()));
 }
 
+inline void fft_64_interleaved_with_planner_and_opts(Slice<std::complex<double>> signal, Direction direction,
+                                                     const PlannerDit64 &planner, const Options &opts) {  // lib.rs:50
+    const phast_options o = opts.to_c();
+    check(phast_fft_64_interleaved_with_planner_and_opts(reinterpret_cast<double *>(signal.ptr), signal.len,
+                                                         static_cast<int>(direction), planner.get(), &o));
+}
+inline void fft_32_interleaved_with_planner_and_opts(Slice<std::complex<float>> signal, Direction direction,
+                                                     const PlannerDit32 &planner, const Options &opts) {
+    const phast_options o = opts.to_c();
+    check(phast_fft_32_interleaved_with_planner_and_opts(reinterpret_cast<float *>(signal.ptr), signal.len,
+                                                         static_cast<int>(direction), planner.get(), &o));
+}
+
 // ---- bit reversal (algorithms/bravo.rs:303,317) ----
+// `n` is validated BEFORE it is used as a shift count (a shift by >= 64 is undefined; the reference asserts and panics)
 inline void bit_rev_bravo_f64(Slice<double> data, unsigned n) {
-    if (data.len != (std::size_t(1) << n)) throw Panic(PHAST_ERR_INVALID_ARG, "Data length must be 2^n");  // bravo.rs:228
+    if (n >= 8 * sizeof(std::size_t) || data.len != (std::size_t(1) << n))
+        throw Panic(PHAST_ERR_INVALID_ARG, "Data length must be 2^n");  // bravo.rs:228
     check(phast_bit_rev_f64(data.ptr, data.len, n));
 }
 inline void bit_rev_bravo_f32(Slice<float> data, unsigned n) {
-    if (data.len != (std::size_t(1) << n)) throw Panic(PHAST_ERR_INVALID_ARG, "Data length must be 2^n");
+    if (n >= 8 * sizeof(std::size_t) || data.len != (std::size_t(1) << n))
+        throw Panic(PHAST_ERR_INVALID_ARG, "Data length must be 2^n");
     check(phast_bit_rev_f32(data.ptr, data.len, n));
 }
 

@@ -32,7 +32,9 @@ class OraclePanic(AssertionError):
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc if the .so is missing or older than its sources."""
     srcs = [os.path.join(_HERE, f) for f in ("phastft_oracle.c", "dit_impl.inc", "phastft_oracle.h", "Makefile")]
-    stale = force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
+    fast = os.path.join(_HERE, "libphastft_oracle_fast.so")
+    stale = force or not os.path.exists(_SO) or not os.path.exists(fast) or any(
+        os.path.getmtime(s) > min(os.path.getmtime(_SO), os.path.getmtime(fast)) for s in srcs)
     if stale:
         subprocess.run(["make", "-C", _HERE, "-B"], check=True, capture_output=True)
     return _SO
@@ -47,12 +49,7 @@ def lib() -> C.CDLL:
         build()
         _lib = C.CDLL(_SO)
         _lib.pho_strerror.restype = C.c_char_p
-        _lib.pho_time_fft_64_dit.restype = C.c_double
-        _lib.pho_time_fft_64_dit.argtypes = [C.c_size_t, C.c_int, C.c_ulonglong]
-        _lib.pho_time_fft_64_dit_parallel.restype = C.c_double
-        _lib.pho_time_fft_64_dit_parallel.argtypes = [C.c_size_t, C.c_int, C.c_ulonglong, C.c_int]
-        _lib.pho_time_r2c_fft_f32.restype = C.c_double
-        _lib.pho_time_r2c_fft_f32.argtypes = [C.c_size_t, C.c_int, C.c_ulonglong]
+        _declare_timing(_lib)
         for name in ("pho_planner_dit64_stage", "pho_planner_dit32_stage"):
             getattr(_lib, name).restype = C.c_size_t
     return _lib
@@ -275,12 +272,57 @@ def fill(n: int, dtype, seed: int = 0xCAFE, transform_id: int = 0):
     return re, im
 
 
+# The timing legs run in the TIMING build of the same source (-O3, vectorised butterfly loops; Makefile: `fast`, or
+# `native` = -march=native compiled on the box that runs the benchmark).  tests/test_oracle_pin.py checks that it
+# returns bit-identical results to the checker build above.
+_FAST_SO = os.path.join(_HERE, "libphastft_oracle_fast.so")
+_NATIVE_SO = os.path.join(_HERE, "_native", "libphastft_oracle_native.so")
+_tlib = None
+_tkind = ""
+
+
+def _declare_timing(l: C.CDLL) -> C.CDLL:
+    for name, args in (("pho_time_fft_64_dit", [C.c_size_t, C.c_int, C.c_ulonglong]),
+                       ("pho_time_fft_64_dit_parallel", [C.c_size_t, C.c_int, C.c_ulonglong, C.c_int]),
+                       ("pho_time_fft_64_roundtrip", [C.c_size_t, C.c_int, C.c_ulonglong]),
+                       ("pho_time_r2c_fft_f32", [C.c_size_t, C.c_int, C.c_ulonglong])):
+        getattr(l, name).restype = C.c_double
+        getattr(l, name).argtypes = args
+    return l
+
+
+def timing_lib(native: bool = True) -> C.CDLL:
+    """The -O3 build for the cpu_baseline legs: `make native` on this host when gcc is here (the build is keyed to
+    this CPU and never travels: oracle/_native/ is git- and gpurun-ignored), else the prebuilt AVX2+FMA one."""
+    global _tlib, _tkind
+    if _tlib is None:
+        build()
+        if native:
+            try:
+                subprocess.run(["make", "-C", _HERE, "-B", "native"], check=True, capture_output=True, timeout=120)
+                _tlib, _tkind = _declare_timing(C.CDLL(_NATIVE_SO)), "-O3 -march=native"
+            except (OSError, subprocess.SubprocessError):
+                _tlib = None
+        if _tlib is None:
+            _tlib, _tkind = _declare_timing(C.CDLL(_FAST_SO)), "-O3 -mavx2 -mfma"
+    return _tlib
+
+
+def timing_build() -> str:
+    timing_lib()
+    return _tkind
+
+
 def time_fft_64_dit(n: int, iters: int, seed: int = 0xCAFE) -> float:
-    return lib().pho_time_fft_64_dit(n, iters, seed)
+    return timing_lib().pho_time_fft_64_dit(n, iters, seed)
 
 
 def time_fft_64_dit_parallel(n: int, iters: int, seed: int = 0xCAFE, threads: int = 0) -> float:
-    return lib().pho_time_fft_64_dit_parallel(n, iters, seed, threads)
+    return timing_lib().pho_time_fft_64_dit_parallel(n, iters, seed, threads)
+
+
+def time_fft_64_roundtrip(n: int, iters: int, seed: int = 0xCAFE) -> float:
+    return timing_lib().pho_time_fft_64_roundtrip(n, iters, seed)
 
 
 def parallel_threads() -> int:
@@ -288,4 +330,4 @@ def parallel_threads() -> int:
 
 
 def time_r2c_fft_f32(n: int, iters: int, seed: int = 0xCAFE) -> float:
-    return lib().pho_time_r2c_fft_f32(n, iters, seed)
+    return timing_lib().pho_time_r2c_fft_f32(n, iters, seed)

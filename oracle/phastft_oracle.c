@@ -198,6 +198,25 @@ static double time_fft_64(size_t n, int iters, unsigned long long seed, int par)
     return total;
 }
 
+/* BASELINE configs[2]: forward then inverse on the same buffers, timed together */
+double pho_time_fft_64_roundtrip(size_t n, int iters, unsigned long long seed) {
+    pho_planner_dit64 *planner;
+    if (pho_planner_dit64_new(n, &planner)) return -1.0;
+    double *re = malloc(n * sizeof(double)), *im = malloc(n * sizeof(double));
+    double total = 0.0;
+    for (int it = 0; it < iters && re && im; ++it) {
+        pho_fill_f64(re, im, n, seed, (unsigned long long)it);
+        double t0 = pho_now();
+        pho_fft_64_dit_with_planner(re, n, im, n, PHO_FORWARD, planner);
+        pho_fft_64_dit_with_planner(re, n, im, n, PHO_REVERSE, planner);
+        total += pho_now() - t0;
+    }
+    free(re);
+    free(im);
+    pho_planner_dit64_free(planner);
+    return total;
+}
+
 double pho_time_r2c_fft_f32(size_t n, int iters, unsigned long long seed) {
     pho_planner_r2c32 *planner;
     if (pho_planner_r2c32_new(n, &planner)) return -1.0;

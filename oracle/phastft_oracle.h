@@ -146,6 +146,7 @@ const char *pho_strerror(int code);
 double pho_time_fft_64_dit(size_t n, int iters, unsigned long long seed);
 double pho_time_fft_64_dit_parallel(size_t n, int iters, unsigned long long seed, int threads); /* feature `parallel` emulated; threads <= 0: OpenMP default */
 int pho_parallel_threads(void);
+double pho_time_fft_64_roundtrip(size_t n, int iters, unsigned long long seed); /* forward + inverse per iteration */
 double pho_time_r2c_fft_f32(size_t n, int iters, unsigned long long seed);
 
 /* counter-based synthetic input shared with the HIP fill kernel:

@@ -56,22 +56,6 @@ def _compile(unit: str, force: bool, trace: bool = False, extra: tuple = (), tag
     return obj
 
 
-EMU_LIB = os.path.join(LIB_DIR, "libphastft_emu.so")
-
-
-def build_emulator(force: bool = False) -> str:
-    """CPU emulator of the tile kernels (test infrastructure; never loaded by the product package)."""
-    os.makedirs(LIB_DIR, exist_ok=True)
-    src = os.path.join(SRC, "emu.hip")
-    if force or _stale(EMU_LIB, [src] + _deps()):
-        # host code only: the kernels in the headers are compiled for the device but never launched
-        cmd = [hipcc(), *FLAGS, "-I", INCLUDE, "-shared", src, "-o", EMU_LIB]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f"hipcc failed for emu:\n{r.stdout}\n{r.stderr}")
-    return EMU_LIB
-
-
 def build(force: bool = False, jobs: int | None = None, verbose: bool = False, trace: bool = False,
           extra: tuple = (), tag: str = "") -> str:
     """trace=True builds lib/libphastft_hip_trace.so with per-phase s_memtime stamps (tools/trace_tile.py;

@@ -38,6 +38,7 @@ static int hip_fail(hipError_t e, const char *what) {
     } while (0)
 
 static int g_cus = 0;
+static int g_device = -1;  // the library keeps per-device state (CU count, raised dynamic-LDS limits): one device per process
 static int g_wg_per_cu_override = 0;
 static unsigned long long *g_trace = nullptr;  // tuning hook (phast_debug_set_trace)  // tuning hook (phast_debug_set_wg_per_cu)
 static int ensure_device() {
@@ -53,10 +54,20 @@ static int ensure_device() {
         }
         int dev = 0;
         hipGetDevice(&dev);
+        g_device = dev;
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess) g_cus = prop.multiProcessorCount;
         if (g_cus <= 0) g_cus = 256;
     });
+    if (status == PHAST_OK) {  // one process drives one device (one rank per GPU): refuse to plan on another one
+        int dev = -1;
+        if (hipGetDevice(&dev) == hipSuccess && dev != g_device) {
+            std::snprintf(g_hip_err, sizeof g_hip_err,
+                          "libphastft_hip was initialised on device %d and is now asked to plan on device %d: one "
+                          "device per process", g_device, dev);
+            return PHAST_ERR_INVALID_ARG;
+        }
+    }
     return status;
 }
 
@@ -158,6 +169,10 @@ template <typename T> struct Planner {
     mutable void *h_pin = nullptr;    // pinned host mirror of the staging buffer for SMALL host-slice calls
     mutable size_t pin_bytes = 0;
     mutable size_t table_bytes = 0;
+    // A buffer that has to grow is replaced, never freed inside a call: kernels already enqueued may still use the
+    // old one, and a hipDeviceSynchronize + hipFree in the middle of a launch sequence is a hidden device-wide sync
+    // (and illegal under stream capture).  The predecessors are released with the planner.
+    mutable std::vector<void *> retired_dev, retired_pin;
 
     ~Planner() { release(); }
     // Host-slice calls up to this many staged bytes go through the pinned mirror (one memcpy each way on the host,
@@ -173,8 +188,7 @@ template <typename T> struct Planner {
     int pinned(size_t bytes, void **out) const {
         if (pin_bytes < bytes) {
             if (h_pin) {
-                hipDeviceSynchronize();
-                hipHostFree(h_pin);
+                retired_pin.push_back(h_pin);
                 h_pin = nullptr;
                 pin_bytes = 0;
             }
@@ -188,8 +202,7 @@ template <typename T> struct Planner {
     int stage(size_t bytes, void **out) const {
         if (stage_bytes < bytes) {
             if (d_stage) {
-                hipDeviceSynchronize();
-                hipFree(d_stage);
+                retired_dev.push_back(d_stage);
                 d_stage = nullptr;
                 stage_bytes = 0;
             }
@@ -206,6 +219,13 @@ template <typename T> struct Planner {
         }
         v.clear();
     }
+    void retire_passes(std::vector<PassDesc> &v) {
+        for (auto &p : v) {
+            if (p.d_tw3) retired_dev.push_back(p.d_tw3);
+            if (p.d_twr) retired_dev.push_back(p.d_twr);
+        }
+        v.clear();
+    }
     void release_passes() {
         free_passes(passes);
         free_passes(passes_lat);
@@ -217,6 +237,10 @@ template <typename T> struct Planner {
         if (d_scratch) hipFree(d_scratch);
         if (d_stage) hipFree(d_stage);
         if (h_pin) hipHostFree(h_pin);
+        for (void *q : retired_dev) hipFree(q);
+        for (void *q : retired_pin) hipHostFree(q);
+        retired_dev.clear();
+        retired_pin.clear();
         h_pin = nullptr;
         pin_bytes = 0;
         d_small_tw = nullptr;
@@ -269,19 +293,22 @@ template <typename T> struct Planner {
                 return rc;
             }
         }
+        // exec() reads the pass vectors while holding call_mu: take it, so a plan is never swapped under a launch
+        // sequence; kernels already enqueued keep reading the old tables, which are therefore retired, not freed
+        std::lock_guard<std::recursive_mutex> call_lock(call_mu);
         std::lock_guard<std::mutex> lk(mu);
         if (which == 2) {
-            free_passes(passes_lat);
+            retire_passes(passes_lat);
             passes_lat = std::move(ps);
         } else if (which == 3) {
-            free_passes(passes_mid);
+            retire_passes(passes_mid);
             passes_mid = std::move(ps);
         } else {
-            free_passes(passes);
+            retire_passes(passes);
             passes = std::move(ps);
             if (which == 0) {  // one plan for every batch size
-                free_passes(passes_lat);
-                free_passes(passes_mid);
+                retire_passes(passes_lat);
+                retire_passes(passes_mid);
             }
         }
         table_bytes = tb;
@@ -340,8 +367,7 @@ template <typename T> struct Planner {
         if (want > batch && batch >= reserve) want = batch;
         if (scratch_cap < want) {
             if (d_scratch) {
-                hipDeviceSynchronize();
-                hipFree(d_scratch);
+                retired_dev.push_back(d_scratch);
                 d_scratch = nullptr;
                 scratch_cap = 0;
             }
@@ -507,9 +533,11 @@ template <typename T> struct PlannerR2c {
     mutable T *d_z = nullptr;  // C2R workspace [cap][2][n/2]
     mutable size_t z_cap = 0;
     mutable std::mutex mu;
+    mutable std::vector<void *> retired;  // outgrown workspaces, released with the planner (see Planner::retired_dev)
     ~PlannerR2c() {
         if (d_tw3) hipFree(d_tw3);
         if (d_z) hipFree(d_z);
+        for (void *q : retired) hipFree(q);
     }
     int init(size_t n_) {
         n = n_;
@@ -526,8 +554,7 @@ template <typename T> struct PlannerR2c {
         if (want > batch) want = batch;
         if (z_cap < want) {
             if (d_z) {
-                hipDeviceSynchronize();
-                hipFree(d_z);
+                retired.push_back(d_z);
                 d_z = nullptr;
                 z_cap = 0;
             }
@@ -904,6 +931,7 @@ template <typename T> struct TwiddleGrid {
         log_n = ilog2(n);
         if (log_n > 32) return PHAST_ERR_INVALID_ARG;  // exponents are reduced to 32 bits
         tw_bits = tw3_bits_for(log_n);
+        if (((size_t)3 << tw_bits) * sizeof(cx_t<T>) > (size_t)160 * 1024) return PHAST_ERR_INVALID_ARG;  // tables must fit one CU's LDS
         return upload<T>(host_tw3<T>(log_n, tw_bits), &d_tw3);
     }
     int apply(T *d_re, T *d_im, size_t rows, size_t cols, size_t row_pitch, size_t row0, size_t col0, hipStream_t s) const {
@@ -1003,6 +1031,7 @@ int phast_options_guess(size_t input_size, phast_options *out) {
     }                                                                                                              \
     int phast_planner_dit##SFX##_reserve_batch(phast_planner_dit##SFX *p, size_t max_batch) {                      \
         if (!p || max_batch == 0) return PHAST_ERR_INVALID_ARG;                                                    \
+        std::lock_guard<std::recursive_mutex> call_lock(p->call_mu);                                               \
         p->reserve = max_batch;                                                                                    \
         size_t cap;                                                                                                \
         return p->ensure_scratch(max_batch, &cap);                                                                 \

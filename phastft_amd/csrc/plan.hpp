@@ -1,4 +1,4 @@
-// plan.hpp -- host-only planning shared by the library (api.hip) and the CPU emulator (emu.hip):
+// plan.hpp -- host-only planning shared by the library (api.hip) and the CPU emulator (tests/emu/emu.hip):
 // twiddle tables in long double, the factorisation of N = 2^L into tile passes, and the address
 // geometry of every pass.  GPU counterpart of PlannerDit*::with_mode (planner.rs:65-100) -- but the
 // tables here are O(N^(1/3)) small (three-level factored twiddles) instead of the reference's 2(N-64)

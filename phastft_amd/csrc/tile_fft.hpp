@@ -18,7 +18,7 @@
 // tables.  No MFMA: 6 FMA-class ops per 64 B moved per radix-2 stage -- HBM-bound.
 //
 // The per-thread work is written as __host__ __device__ phase functions (TileBody) so that the very
-// same index arithmetic is executed thread-by-thread on the CPU by csrc/emu.hip (tests/test_emulator.py)
+// same index arithmetic is executed thread-by-thread on the CPU by tests/emu/emu.hip (tests/test_emulator.py)
 // -- the build container has no GPU.
 #pragma once
 

@@ -36,12 +36,13 @@ template <typename T> __global__ void __launch_bounds__(256) twiddle_grid_kernel
 template <typename T> hipError_t launch_twiddle_grid(const TwiddleGridArgs &a, hipStream_t stream) {
     if (a.rows == 0 || a.cols == 0) return hipSuccess;
     const size_t lds = ((size_t)3 << a.tw_bits) * sizeof(cx_t<T>);
-    static bool raised = false;
-    if (!raised) {
+    if (lds > (size_t)160 * 1024) return hipErrorInvalidValue;  // TwiddleGrid::init rejects such sizes up front
+    static size_t lds_limit = 0;  // raised only when the request grows (as launch_tile_inst): steady state = launch only
+    if (lds > lds_limit) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(twiddle_grid_kernel<T>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        raised = true;
+        lds_limit = lds;
     }
     unsigned gx = (unsigned)((a.cols + 255) / 256);
     if (gx > 64) gx = 64;

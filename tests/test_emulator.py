@@ -1,5 +1,5 @@
 """The tile-FFT kernels' index arithmetic, LDS layouts, twiddle tables and pass plans, executed on the
-CPU: libphastft_emu.so runs the SAME `TileBody` phase functions (csrc/tile_fft.hpp) and the SAME plan
+CPU: tests/emu/libphastft_emu.so runs the SAME `TileBody` phase functions (csrc/tile_fft.hpp) and the SAME plan
 geometry (csrc/plan.hpp) as the GPU kernels, thread by thread, and is compared with the oracle.  This is
 what keeps kernel edits honest in the GPU-less build container; the `-m gpu` tests check the real thing."""
 import ctypes as C
@@ -13,9 +13,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.fixture(scope="module")
 def emu():
-    from phastft_amd import build
+    from tests.emu import build_emulator
 
-    lib = C.CDLL(build.build_emulator())
+    lib = C.CDLL(build_emulator())
     lib.phast_emu_fft_f32_modes.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_uint, C.c_uint,
                                             C.c_double, C.c_void_p, C.c_size_t, C.c_uint]
     return lib
