@@ -4,25 +4,30 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]                     (N = 1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Metric (BASELINE.json): GSamples/s of the f64 forward planar FFT, complex samples transformed per
-second over the whole job, inputs resident in HBM when the timed region starts.
+Metric (BASELINE.json): GSamples/s of the f64 forward planar FFT at N=2^20 and 2^26 (and % of the HBM roofline),
+complex samples transformed per second over the whole job, inputs resident in HBM when the timed region starts.
 
-  * N = 1  -> configs[1]: "Single f64 forward FFT, N=2^20, 1xMI355X".  One step = one in-place
-    `fft_64_dit_with_planner` (the _dev entry point of the C ABI) on one 16 MiB transform.  Every step
-    uses a fresh buffer of a pre-filled ring (so values never overflow and the ring, > 256 MiB, defeats
-    the Infinity Cache); the K steps are captured once into a HIP graph and replayed inside the timed
-    region so that the host launch path (Python + ctypes) is not what is measured.
-  * N > 1  -> configs[4]: 8192 independent N=2^20 transforms per 8 GPUs = 1024 per GPU, fixed per-GPU
-    work ("scaling": "weak"); one step = every rank transforms its 1024-transform shard in place.  The
-    path has no exchange step, so there is no data-path collective; RCCL (torch.distributed "nccl") only
-    carries the barrier, the max-over-ranks time and the trivial digest gather.
+  * N = 1  -> `value` = configs[1]: "Single f64 forward FFT, N=2^20, 1xMI355X".  One step = one in-place
+    `fft_64_dit_with_planner` (the _dev entry point of the C ABI) on one 16 MiB transform.  Every step uses a fresh
+    buffer of a pre-filled ring (values never overflow; the ring, > 512 MiB, defeats the 256 MiB Infinity Cache);
+    the K steps are captured once into a HIP graph and replayed inside the timed region so that the host launch
+    path (Python + ctypes) is not what is measured.
+    The same line carries, under "configs", the other single-GPU BASELINE configurations measured in the same run,
+    each with its own value / ms_per_step / roofline / cpu_baseline:
+      n2p26_forward   (the second half of BASELINE's metric: N=2^26, 1 GiB per transform, three 2 GiB-traffic passes)
+      n2p26_roundtrip (configs[2]: forward + inverse on the same buffers, error against the input checked)
+      r2c_f32_2p24    (configs[3]: r2c_fft_f32, N=2^24)
+    and "weak_scaling_reference": one rank's shard of the N > 1 workload on this one GPU.
+  * N > 1  -> configs[4]: 8192 independent N=2^20 transforms per 8 GPUs = 1024 per GPU, fixed per-GPU work
+    ("scaling": "weak"); one step = every rank transforms its 1024-transform shard in place.  The path has no
+    exchange step, so there is no data-path collective; RCCL (torch.distributed "nccl") only carries the barrier,
+    the max-over-ranks time and the trivial digest gather.  After the timed region every rank checks its results:
+    Parseval on every transform of the shard and >= 8 sampled transforms against digests computed from the CPU
+    oracle's output (the oracle is the checker here, never the thing measured).
 
-At N = 1 the line also carries "weak_scaling_reference": one rank's shard of the N > 1 workload timed on this one
-GPU -- the denominator for scaling efficiency (the N = 1 headline is ONE transform, a different workload).
-
-Extra objects on the JSON line: "roofline" (HIP-event duration of the dominant pass kernel vs the
-8 TB/s HBM peak) and "cpu_baseline" (the oracle -- a C restatement of the
-reference's CPU algorithm -- timed on this host on a bounded sample; rank 0, N = 1 only).
+"roofline": HIP-event duration of the dominant pass kernel vs the 8 TB/s HBM peak (DESIGN.md section 6);
+"cpu_baseline": the -O3 build of the oracle (a C restatement of the reference's CPU algorithm, bit-identical to the
+checker build) timed on this host on a bounded sample; rank 0, N = 1 only.
 """
 from __future__ import annotations
 
@@ -51,18 +56,19 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly from Python")
     ap.add_argument("--no-scaling-reference", action="store_true",
                     help="skip the one-GPU run of the sharded workload (profiling runs of the headline kernels)")
+    ap.add_argument("--no-configs", action="store_true", help="headline only: skip N=2^26, the round trip and R2C")
     ap.add_argument("--shard", type=int, default=SHARD, help="transforms per GPU when --gpus > 1")
-    ap.add_argument("--extra", action="store_true", help="also measure N=2^26 and the batched shard at --gpus 1")
     ap.add_argument("--plan", default=None, help="experiment: force a plan, e.g. 6,8,6@12p8 (default: the library's own)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for dry runs)")
     ap.add_argument("--same-gpu", action="store_true", help="dry run: every rank uses cuda:0 (needs --backend gloo)")
     return ap.parse_args()
 
 
-def cpu_baseline(budget_s: float = 12.0):
-    """The oracle (C restatement of PhastFT's CPU path) on the host cores of this box -- the checker
-    doubling as the reported CPU baseline, examples/benchmark.rs protocol (planner outside the timer,
-    input regenerated before every timed call)."""
+# ------------------------------------------------------------------------------------------------
+# CPU baseline legs (the oracle's -O3 build on this host; examples/benchmark.rs:19-63 protocol: planner outside the
+# timer, input regenerated before every timed call)
+# ------------------------------------------------------------------------------------------------
+def cpu_baseline(budget_s: float = 8.0):
     from oracle import oracle as O
 
     t1 = O.time_fft_64_dit(N, 3)  # warm + calibrate
@@ -83,7 +89,8 @@ def cpu_baseline(budget_s: float = 12.0):
     return {
         "value": iters * N / total / 1e9, "unit": "GSamples/s", "cores": 1, "kind": "port",
         "sample": f"{iters} forward fft_64_dit_with_planner calls at N=2^{LOG_N} "
-                  f"({total:.1f} s of CPU work, {1e3 * total / iters:.2f} ms each), oracle/ C restatement, 1 thread",
+                  f"({total:.1f} s of CPU work, {1e3 * total / iters:.2f} ms each), oracle/ C restatement built "
+                  f"{O.timing_build()} (vectorised butterfly loops, bit-identical to the checker build), 1 thread",
         "parallel_feature": {"value": p_iters * N / p_total / 1e9, "unit": "GSamples/s", "cores": threads,
                              "sample": f"{p_iters} calls, {1e3 * p_total / p_iters:.2f} ms each, best of 2..64 threads "
                                        f"({avail} schedulable); rayon::join emulated with OpenMP tasks (2-way bit "
@@ -91,38 +98,67 @@ def cpu_baseline(budget_s: float = 12.0):
     }
 
 
-def shard_on_one_gpu(P, torch, dev, shard: int, steps: int = 3):
-    """The per-GPU workload of the --gpus N > 1 runs (BASELINE configs[4]: `shard` transforms of 2^20 per GPU,
-    transformed in place per step) timed on this one GPU: the denominator for weak-scaling efficiency.  The N = 1
-    headline above is a different workload (ONE transform, configs[1]) and must not be used for that."""
-    pl = P.PlannerDit64(N)
-    re = torch.empty(shard * N, dtype=torch.float64, device=dev)
-    im = torch.empty_like(re)
-    P.fill_uniform(re, im, N, seed=0xCAFE, first_id=0)
-    P.fft_dit_batched(re, im, N, P.Direction.Forward, pl)  # warm-up (scratch allocation)
-    P.fill_uniform(re, im, N, seed=0xCAFE, first_id=0)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        P.fft_dit_batched(re, im, N, P.Direction.Forward, pl)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    return {"workload": f"{shard} independent f64 forward FFTs N=2^{LOG_N} on 1 GPU, in place (one rank's shard of "
-                        f"BASELINE configs[4])", "value": shard * N * steps / dt / 1e9, "unit": "GSamples/s",
-            "steps": steps, "ms_per_step": 1e3 * dt / steps}
+def cpu_leg(kind: str, n: int, iters: int):
+    """One short CPU leg beside a "configs" entry: `kind` in forward / roundtrip / r2c_f32."""
+    from oracle import oracle as O
+
+    fn = {"forward": O.time_fft_64_dit, "roundtrip": O.time_fft_64_roundtrip, "r2c_f32": O.time_r2c_fft_f32}[kind]
+    total = fn(n, iters)
+    samples = (2 if kind == "roundtrip" else 1) * n * iters
+    return {"value": samples / total / 1e9, "unit": "GSamples/s", "cores": 1, "kind": "port",
+            "sample": f"{iters} x {kind} at N=2^{n.bit_length() - 1} ({total:.1f} s of CPU work), oracle/ C restatement "
+                      f"built {O.timing_build()}, 1 thread, planner outside the timer"}
 
 
-def kernel_tags(plan_text: str, latency: bool):
-    """'<double, LR, LC, LP,' template-argument prefixes of the pass kernels of the plan that ran, parsed from
-    planner.describe() -- used to check that a committed PMC profile belongs to this plan."""
+# ------------------------------------------------------------------------------------------------
+# helpers
+# ------------------------------------------------------------------------------------------------
+def plan_of(plan_text: str, kind: str) -> str:
+    """the '[rows x cols ...]' list of one of the plans in planner.describe()"""
+    import re
+
+    m = re.search(kind + r"=\d+p((?:\[[^\]]*\])+)", plan_text)
+    return m.group(1) if m else plan_text
+
+
+def plan_kind(P, n: int, batch: int, plan_text: str) -> str:
+    """which of the planner's plans a call with `batch` transforms runs (api.hip: Planner::plan_for)"""
+    if "latency=" not in plan_text:
+        return "throughput" if "throughput=" in plan_text else "one-pass"
+    import re
+
+    tiles = [int(r) * int(c) for r, c in re.findall(r"\[(\d+)x(\d+)", plan_of(plan_text, "throughput"))]
+    tl = max(t.bit_length() - 1 for t in tiles)
+    work = 1 << (25 if tl >= 15 else 24 if tl >= 13 else 22)   # plan.hpp: throughput_work
+    if batch * n >= work:
+        return "throughput"
+    return "mid" if (batch > 1 and "mid=" in plan_text) else "latency"
+
+
+def kernel_tags(plan_list: str, dtype: str = "double"):
+    """'<double, LR, LC, LP,' template-argument prefixes of the pass kernels of a plan -- used to check that a
+    committed PMC profile belongs to the plan that ran."""
     import math
     import re
 
-    part = plan_text.split("latency=")[1] if (latency and "latency=" in plan_text) else plan_text.split("latency=")[0]
     tags = []
-    for rows, cols, pts in re.findall(r"\[(\d+)x(\d+)A? p(\d+)", part):
-        tags.append(f"<double, {int(math.log2(int(rows)))}, {int(math.log2(int(cols)))}, {int(math.log2(int(pts)))},")
+    for rows, cols, pts in re.findall(r"\[(\d+)x(\d+)A? p(\d+)", plan_list):
+        tags.append(f"<{dtype}, {int(math.log2(int(rows)))}, {int(math.log2(int(cols)))}, {int(math.log2(int(pts)))},")
     return tags
+
+
+def roofline_of(pass_ms, alg_bytes, names=None, plan_used=""):
+    dom = max(range(len(pass_ms)), key=lambda i: pass_ms[i])
+    achieved = alg_bytes / (pass_ms[dom] * 1e-3) / 1e9
+    total_ms = sum(pass_ms)
+    label = names[dom] if names else f"tile_fft pass {dom} of {len(pass_ms)}"
+    return {
+        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "traffic": None, "kernel": label + (f" ({plan_used})" if plan_used else ""),
+        "kernel_ms": pass_ms[dom], "pass_ms": pass_ms, "algorithmic_bytes_per_launch": alg_bytes,
+        # the whole transform against the one-pass ideal (every byte once): capped at 1/passes by construction
+        "transform_frac": alg_bytes / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "passes": len(pass_ms),
+    }, dom
 
 
 def hbm_copy_probe(torch, dev, mib: int = 1024, reps: int = 10):
@@ -139,6 +175,164 @@ def hbm_copy_probe(torch, dev, mib: int = 1024, reps: int = 10):
     e1.record()
     torch.cuda.synchronize()
     return 2.0 * src.numel() * 8 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+def event_ms(torch, fn):
+    """HIP events on torch's current stream (the stream the library launches on) around fn()"""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1)
+
+
+# ------------------------------------------------------------------------------------------------
+# the other single-GPU BASELINE configs, on the driver-run line
+# ------------------------------------------------------------------------------------------------
+def config_n2p26(P, torch, dev, steps: int, cpu: bool):
+    """N = 2^26 f64: forward (the second half of BASELINE's metric) and the forward+inverse round trip (configs[2]).
+    Inputs are regenerated on the device before every timed transform (outside the timed interval)."""
+    n = 1 << 26
+    pl = P.PlannerDit64(n)
+    plan_text = pl.describe()
+    re = torch.empty(n, dtype=torch.float64, device=dev)
+    im = torch.empty_like(re)
+    P.fill_uniform(re, im, n, seed=0xCAFE)
+    P.fft_64_dit_with_planner(re, im, P.Direction.Forward, pl)  # warm-up: scratch allocation
+    total = 0.0
+    for i in range(steps):
+        P.fill_uniform(re, im, n, seed=0xCAFE, first_id=i)
+        total += event_ms(torch, lambda: P.fft_64_dit_with_planner(re, im, P.Direction.Forward, pl))
+    ms = total / steps
+    P.fill_uniform(re, im, n, seed=0xCAFE)
+    pass_ms = pl.time_passes(re, im, n, reps=3)
+    used = plan_kind(P, n, 1, plan_text)
+    roof, _ = roofline_of(pass_ms, BYTES_PER_SAMPLE * n, plan_used=f"{used} plan {plan_of(plan_text, used)}")
+    fwd = {"workload": "single f64 forward FFT N=2^26, in place, planar (BASELINE metric, second size)",
+           "value": n / (ms * 1e-3) / 1e9, "unit": "GSamples/s", "steps": steps, "ms_per_step": ms, "dtype": "f64",
+           "plan": plan_text, "roofline": roof}
+    # configs[2]: forward then inverse on the same buffers; the error against the regenerated input is part of it
+    rt_total = 0.0
+    for i in range(steps):
+        P.fill_uniform(re, im, n, seed=0xBEEF, first_id=i)
+
+        def roundtrip():
+            P.fft_64_dit_with_planner(re, im, P.Direction.Forward, pl)
+            P.fft_64_dit_with_planner(re, im, P.Direction.Reverse, pl)
+
+        rt_total += event_ms(torch, roundtrip)
+    ref_re, ref_im = torch.empty_like(re), torch.empty_like(im)
+    P.fill_uniform(ref_re, ref_im, n, seed=0xBEEF, first_id=steps - 1)
+    err = max(float((re - ref_re).abs().max()), float((im - ref_im).abs().max()))
+    del ref_re, ref_im
+    rt_ms = rt_total / steps
+    # one launch of a pass moves 32 B/sample; the round trip is 2 x passes launches
+    rt = {"workload": "single f64 forward+inverse round trip N=2^26 on the same buffers (BASELINE configs[2])",
+          "value": 2 * n / (rt_ms * 1e-3) / 1e9, "unit": "GSamples/s (both directions counted)", "steps": steps,
+          "ms_per_step": rt_ms, "dtype": "f64", "max_abs_err_vs_input": err, "err_ok": bool(err < 1e-10),
+          "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "passes": 2 * len(pass_ms),
+                       "algorithmic_bytes_per_step": 2 * BYTES_PER_SAMPLE * n,
+                       "transform_frac": 2 * BYTES_PER_SAMPLE * n / (rt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "note": "same pass kernels as n2p26_forward (the inverse is the swap trick + 1/N in the last store)"}}
+    del re, im, pl
+    torch.cuda.empty_cache()
+    if cpu:
+        fwd["cpu_baseline"] = cpu_leg("forward", n, 2)
+        rt["cpu_baseline"] = cpu_leg("roundtrip", n, 1)
+    return fwd, rt
+
+
+def config_r2c(P, torch, dev, steps: int, cpu: bool):
+    """configs[3]: r2c_fft_f32 at N = 2^24 (algorithmic bytes 4N in + 8(N/2+1) out)."""
+    n = 1 << 24
+    pl = P.PlannerR2c32(n)
+    x = torch.empty(n, dtype=torch.float32, device=dev)
+    P.fill_uniform(x, None, n, seed=0xCAFE)
+    ore = torch.empty(n // 2 + 1, dtype=torch.float32, device=dev)
+    oim = torch.empty_like(ore)
+    P.r2c_fft_f32_with_planner(x, ore, oim, pl)
+
+    def run():
+        for _ in range(steps):
+            P.r2c_fft_f32_with_planner(x, ore, oim, pl)   # the input is read-only (r2c.rs:535): no refill needed
+
+    run()
+    ms = event_ms(torch, run) / steps
+    pass_ms = pl.time_passes(x, ore, oim, reps=5)
+    r2c_bytes = 4 * n + 8 * (n // 2 + 1)
+    names = [f"tile_fft pass {i} of the inner 2^23-point transform" for i in range(len(pass_ms) - 1)] + ["untangle sweep"]
+    plan_text = pl.describe()
+    # per-kernel algorithmic bytes differ (first pass reads the real input, the untangle re-reads and re-writes the
+    # half spectrum): the kernel fraction is quoted against the bytes THAT kernel must move
+    k_bytes = [8 * (n // 2) + 8 * (n // 2)] * (len(pass_ms) - 1) + [16 * (n // 2 + 1)]
+    fr = [b / (t * 1e-3) / 1e9 / HBM_PEAK_GBS for b, t in zip(k_bytes, pass_ms)]
+    dom = max(range(len(pass_ms)), key=lambda i: pass_ms[i])
+    roof = {"bound": "hbm", "achieved": k_bytes[dom] / (pass_ms[dom] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": fr[dom], "traffic": None, "kernel": names[dom], "kernel_ms": pass_ms[dom], "pass_ms": pass_ms,
+            "algorithmic_bytes_per_launch": k_bytes[dom], "algorithmic_bytes_per_transform": r2c_bytes,
+            "transform_frac": r2c_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "passes": len(pass_ms)}
+    out = {"workload": "r2c_fft_f32 N=2^24, real input -> N/2+1 planar outputs (BASELINE configs[3])",
+           "value": n / (ms * 1e-3) / 1e9, "unit": "GSamples/s (real samples)", "steps": steps, "ms_per_step": ms,
+           "dtype": "f32", "plan": plan_text, "roofline": roof}
+    del x, ore, oim, pl
+    if cpu:
+        out["cpu_baseline"] = cpu_leg("r2c_f32", n, 8)
+    return out
+
+
+def shard_on_one_gpu(P, torch, dev, shard: int, steps: int = 5):
+    """The per-GPU workload of the --gpus N > 1 runs (BASELINE configs[4]: `shard` transforms of 2^20 per GPU,
+    transformed in place per step) timed on this one GPU with HIP events: the denominator for weak-scaling
+    efficiency.  The N = 1 headline is a different workload (ONE transform, configs[1])."""
+    pl = P.PlannerDit64(N)
+    re = torch.empty(shard * N, dtype=torch.float64, device=dev)
+    im = torch.empty_like(re)
+    P.fill_uniform(re, im, N, seed=0xCAFE, first_id=0)
+    P.fft_dit_batched(re, im, N, P.Direction.Forward, pl)  # warm-up (scratch allocation)
+    total = 0.0
+    for i in range(steps):
+        P.fill_uniform(re, im, N, seed=0xCAFE, first_id=0)
+        total += event_ms(torch, lambda: P.fft_dit_batched(re, im, N, P.Direction.Forward, pl))
+    ms = total / steps
+    P.fill_uniform(re, im, N, seed=0xCAFE, first_id=0)
+    pass_ms = pl.time_passes(re, im, N, reps=2)
+    plan_text = pl.describe()
+    used = plan_kind(P, N, shard, plan_text)
+    roof, _ = roofline_of(pass_ms, BYTES_PER_SAMPLE * N * shard, plan_used=f"{used} plan {plan_of(plan_text, used)}")
+    return {"workload": f"{shard} independent f64 forward FFTs N=2^{LOG_N} on 1 GPU, in place (one rank's shard of "
+                        f"BASELINE configs[4])", "value": shard * N / (ms * 1e-3) / 1e9, "unit": "GSamples/s",
+            "steps": steps, "ms_per_step": ms, "roofline": roof}
+
+
+def check_shard(P, torch, re, im, refill, step, first: int, shard: int, samples: int = 8):
+    """After the timed region: one step on fresh inputs, then (i) Parseval on EVERY transform of the shard from the
+    32-byte digests (sum |X|^2 = N sum |x|^2), (ii) `samples` transforms against digests computed from the CPU oracle's
+    output of the same seeded input (first, last and evenly spaced ids)."""
+    import numpy as np
+
+    from oracle import oracle as O
+
+    refill()
+    before = P.digest(re, im, N, probe=1).cpu().numpy()
+    step()
+    after_t = P.digest(re, im, N, probe=1)
+    after = after_t.cpu().numpy()
+    ok = bool(np.all(np.isfinite(after))) and after.shape[0] == shard
+    parseval = float(np.max(np.abs(after[:, 2] / (N * before[:, 2]) - 1.0)))
+    ok = ok and parseval < 1e-12
+    ids = sorted({int(round(i * (shard - 1) / max(1, samples - 1))) for i in range(samples)})
+    worst = 0.0
+    for b in ids:
+        r, m = O.fill(N, np.float64, seed=0xCAFE, transform_id=first + b)
+        O.fft_64_dit(r, m, O.FORWARD)
+        scale = float(np.sqrt(N * before[b, 2]))
+        want = np.array([r.sum(), m.sum(), (r * r + m * m).sum(), r[1]])
+        dev_ = max(abs(after[b, 0] - want[0]) / (scale * np.sqrt(N)), abs(after[b, 1] - want[1]) / (scale * np.sqrt(N)),
+                   abs(after[b, 2] / want[2] - 1.0), abs(after[b, 3] - want[3]) / scale)
+        worst = max(worst, float(dev_))
+    ok = ok and worst < 1e-10
+    return ok, {"parseval_max_rel_dev": parseval, "oracle_digest_max_dev": worst, "oracle_checked_ids": len(ids)}, after_t
 
 
 def main():
@@ -172,13 +366,16 @@ def main():
     if args.plan:
         lrs_s, rest = args.plan.split("@")
         tl_s, p_s = rest.split("p")
-        planner.set_plan(tuple(int(x) for x in lrs_s.split(",")), int(tl_s), {8: 3, 16: 4, 32: 5}[int(p_s)])
+        tls = tuple(int(x) for x in tl_s.split(","))
+        planner.set_plan(tuple(int(x) for x in lrs_s.split(",")), tls if len(tls) > 1 else tls[0],
+                         {8: 3, 16: 4, 32: 5}[int(p_s)])
     plan_text = planner.describe()
+    check_info = None
 
     if n_gpus == 1:
         steps = args.steps if args.steps is not None else 200
         warmup = args.warmup if args.warmup is not None else 20
-        ring = max(steps + warmup, 32)  # >= 512 MiB of distinct transforms; no buffer is transformed twice
+        ring = max(steps + warmup, 40)  # >= 640 MiB of distinct transforms; no buffer is transformed twice
         re = torch.empty(ring * N, dtype=torch.float64, device=dev)
         im = torch.empty_like(re)
         P.fill_uniform(re, im, N, seed=0xCAFE, first_id=0)
@@ -222,7 +419,7 @@ def main():
         samples_per_step = N
         workload = f"single f64 forward FFT N=2^{LOG_N}, in place, planar (BASELINE configs[1])"
         launch = "hipGraph replay of the K steps" if graph is not None else "eager launches from Python"
-        # --- roofline of the dominant pass kernel, HIP events on the launch stream (fresh buffers) ---
+        # --- roofline of the dominant pass kernel, HIP events bound to the dispatches (fresh buffers) ---
         P.fill_uniform(re, im, N, seed=0xCAFE, first_id=0)
         torch.cuda.synchronize()
         acc = None
@@ -232,6 +429,8 @@ def main():
             acc = ms if acc is None else [a + b for a, b in zip(acc, ms)]
         pass_ms = [a / reps for a in acc]
         units = 1
+        del re, im, views
+        torch.cuda.empty_cache()
     else:
         steps = args.steps if args.steps is not None else 10
         warmup = args.warmup if args.warmup is not None else 2
@@ -250,8 +449,10 @@ def main():
         def transform(first_id, count):  # the rank's contiguous shard, in place, no communication
             P.fft_dit_batched(re, im, N, P.Direction.Forward, planner)
 
+        state = {"digest": None}
+
         def digest_fn(first_id, count):
-            return P.digest(re, im, N, probe=1)
+            return state["digest"] if state["digest"] is not None else P.digest(re, im, N, probe=1)
 
         sb = ShardedBatch(total, N, rank, world, transform, digest_fn)
         assert (sb.first, sb.count) == (first, shard)
@@ -269,12 +470,13 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
         elapsed = max_over_ranks(time.perf_counter() - t0, dist, dev)
-        # the trivial gather (RCCL over xGMI): one 32-byte digest per transform -> (total, 4) on every rank.  Taken
-        # from one step on fresh inputs so that it stays finite whatever K was (values grow 2^10-fold per step)
-        refill()
-        sb.step()
+        # after the timed region: every rank checks its shard (Parseval on all, sampled ids against the oracle), then
+        # the trivial gather (RCCL over xGMI): one 32-byte digest per transform -> (total, 4) on every rank
+        ok, check_info, state["digest"] = check_shard(P, torch, re, im, refill, sb.step, first, shard)
         digests = sb.gather_digests(dist)
-        digest_ok = bool(torch.isfinite(digests).all()) and digests.shape[0] == total
+        flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device="cpu" if args.backend == "gloo" else dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        digest_ok = bool(flag.item() == 1.0) and digests.shape[0] == total and bool(torch.isfinite(digests).all())
         samples_per_step = sb.samples_per_step()
         workload = (f"{total} independent f64 forward FFTs N=2^{LOG_N}, {shard} per GPU, in place "
                     f"(BASELINE configs[4])")
@@ -287,46 +489,46 @@ def main():
     ms_per_step = 1e3 * elapsed / steps
     value = samples_per_step * steps / elapsed / 1e9
 
-    out = None
     if rank == 0:
-        dom = max(range(len(pass_ms)), key=lambda i: pass_ms[i])
+        used = plan_kind(P, N, units, plan_text) if not args.plan else "forced"
+        plan_list = plan_of(plan_text, "throughput" if used == "forced" else used)
         alg_bytes = BYTES_PER_SAMPLE * N * units            # what ONE launch of a pass must read + write
-        achieved = alg_bytes / (pass_ms[dom] * 1e-3) / 1e9  # GB/s of the dominant pass kernel
-        total_ms = sum(pass_ms)
-        roofline = {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-            "kernel": f"tile_fft pass {dom} of {len(pass_ms)}",
-            "kernel_ms": pass_ms[dom], "pass_ms": pass_ms, "algorithmic_bytes_per_launch": alg_bytes,
-            # whole transform against the one-pass ideal (32 B/sample once): capped at 1/passes by construction
-            "transform_frac": alg_bytes / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "passes": len(pass_ms),
-        }
+        roofline, dom = roofline_of(pass_ms, alg_bytes, plan_used=f"{used} plan {plan_list}")
+        achieved = roofline["achieved"]
         out = {
-            "metric": "GSamples/s f64 forward FFT N=2^20", "value": value, "unit": "GSamples/s",
+            "metric": "GSamples/s f64 forward FFT N=2^20" + (" (N=2^26, round trip, R2C: see configs)" if n_gpus == 1 else ""),
+            "value": value, "unit": "GSamples/s",
             "n_gpus": n_gpus, "steps": steps, "warmup": warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic (counter-based uniform [-1,1), seed 0xCAFE, generated on device)",
             "config": {"workload": workload, "n": N, "transforms_per_step": samples_per_step // N,
-                       "plan": plan_text, "launch": launch},
+                       "plan": plan_text, "plan_used": used, "launch": launch},
             "roofline": roofline,
         }
         if n_gpus > 1:
             out["config"]["digest_gather"] = f"all_gather of {samples_per_step // N} x 32 B digests over RCCL"
             out["config"]["digest_ok"] = digest_ok
-        traffic = load_profiled_traffic(n_gpus, dom, len(pass_ms), kernel_tags(plan_text, n_gpus == 1))
+            out["config"]["digest_check"] = dict(check_info, what="every rank: Parseval on all transforms of its shard + "
+                                                 "sampled transforms vs digests of the CPU oracle's output; rank 0's numbers")
+        traffic = load_profiled_traffic(n_gpus, dom, len(pass_ms), kernel_tags(plan_list))
         if traffic is not None:
             roofline.update(traffic)
         if n_gpus == 1:
             probe = hbm_copy_probe(torch, dev)
             roofline["copy_probe_GBps"] = probe          # measured d2d copy rate of this box, same run
             roofline["frac_of_copy_probe"] = achieved / probe
+            torch.cuda.empty_cache()
+        cpu = n_gpus == 1 and not args.no_cpu_baseline
+        if cpu:
+            out["cpu_baseline"] = cpu_baseline()
+        if n_gpus == 1 and not args.no_configs:
+            fwd, rt = config_n2p26(P, torch, dev, 5, cpu)
+            out["configs"] = {"n2p26_forward": fwd, "n2p26_roundtrip": rt, "r2c_f32_2p24": config_r2c(P, torch, dev, 20, cpu)}
+            t26 = load_profiled_traffic_key("single_2p26", fwd["roofline"])
+            if t26:
+                fwd["roofline"].update(t26)
         if n_gpus == 1 and not args.no_scaling_reference:
             out["weak_scaling_reference"] = shard_on_one_gpu(P, torch, dev, args.shard)
-        if n_gpus == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
-        if n_gpus == 1 and args.extra:
-            out["extra"] = extra_measurements(P, torch, dev)
         print(json.dumps(out), flush=True)
     if multi:
         import torch.distributed as dist
@@ -335,25 +537,29 @@ def main():
         dist.destroy_process_group()
 
 
-def load_profiled_traffic(n_gpus, dom, n_passes, kernel_tags):
-    """HBM bytes per launch of the dominant pass kernel from the rocprofv3 PMC runs committed under
-    profiles/ (FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md's HBM
-    section prescribes for gfx950).  bench.py cannot collect PMC counters itself; the file records which
-    command produced the numbers.  None when no profile matches this workload."""
+def _traffic_file():
     path = os.path.join(ROOT, "profiles", "traffic_latest.json")
     try:
         with open(path) as f:
-            t = json.load(f)
+            return json.load(f)
     except (OSError, ValueError):
         return None
+
+
+def load_profiled_traffic(n_gpus, dom, n_passes, tags):
+    """HBM bytes per launch of the dominant pass kernel from the rocprofv3 PMC runs committed under
+    profiles/ (FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md's HBM
+    section prescribes for gfx950).  bench.py cannot collect PMC counters itself; the file records which
+    command produced the numbers.  None when no profile matches the plan that ran."""
+    t = _traffic_file()
     key = "single_2p20" if n_gpus == 1 else "batch_2p20"
-    if key not in t:
+    if not t or key not in t:
         return None
     ks = t[key].get("kernels", [])
     # the profile may hold other kernels too: pick, pass by pass, the entries of THIS plan (first / later passes differ
     # in the PRE_TW, TRANSPOSE flags that follow the shape in the kernel's name)
     picked = []
-    for i, tag in enumerate(kernel_tags):
+    for i, tag in enumerate(tags):
         flags = " false, true," if i == 0 else " true, false,"
         hits = [k for k in ks if tag + flags in k["kernel"]]
         if len(hits) != 1:
@@ -365,81 +571,15 @@ def load_profiled_traffic(n_gpus, dom, n_passes, kernel_tags):
             "traffic_kernel": picked[dom]["kernel"]}
 
 
-def extra_measurements(P, torch, dev):
-    """The other BASELINE configs on one GPU, reported beside the headline: N=2^26 forward and the forward+inverse
-    round trip (configs[2]), f32 R2C at N=2^24 (configs[3]), one GPU's 1024-transform shard (configs[4]), and the
-    host-slice (drop-in, PCIe-inclusive) call at N=2^20."""
-    import numpy as np
-
-    res = {}
-
-    def wall(fn, reps):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            fn()
-        torch.cuda.synchronize()
-        return 1e3 * (time.perf_counter() - t0) / reps
-
-    n26 = 1 << 26
-    pl = P.PlannerDit64(n26)
-    re = torch.empty(n26, dtype=torch.float64, device=dev)
-    im = torch.empty_like(re)
-    P.fill_uniform(re, im, n26)
-    P.fft_64_dit_with_planner(re, im, P.Direction.Forward, pl)
-    P.fill_uniform(re, im, n26)
-    ms = pl.time_passes(re, im, n26, reps=3)
-    res["n2p26_single"] = {"plan": pl.describe(), "pass_ms": ms, "gsamples_per_s": n26 / (sum(ms) * 1e-3) / 1e9,
-                           "transform_frac": 32 * n26 / (sum(ms) * 1e-3) / 1e9 / HBM_PEAK_GBS}
-    # configs[2]: forward + inverse round trip on the same buffers, error against the input
-    P.fill_uniform(re, im, n26)
-    ref_re, ref_im = re.clone(), im.clone()
-
-    def roundtrip():
-        P.fft_64_dit_with_planner(re, im, P.Direction.Forward, pl)
-        P.fft_64_dit_with_planner(re, im, P.Direction.Reverse, pl)
-
-    roundtrip()
-    ms_rt = wall(roundtrip, 3)
-    err = max(float((re - ref_re).abs().max()), float((im - ref_im).abs().max()))
-    res["n2p26_roundtrip"] = {"ms": ms_rt, "gsamples_per_s": 2 * n26 / (ms_rt * 1e-3) / 1e9,
-                              "max_abs_err_after_4_roundtrips": err}
-    del re, im, pl, ref_re, ref_im
-    # configs[3]: f32 R2C, N=2^24 (algorithmic bytes 4N + 8(N/2+1), SURVEY.md 8d)
-    n24 = 1 << 24
-    plr = P.PlannerR2c32(n24)
-    x = torch.empty(n24, dtype=torch.float32, device=dev)
-    P.fill_uniform(x, None, n24)
-    ore = torch.empty(n24 // 2 + 1, dtype=torch.float32, device=dev)
-    oim = torch.empty_like(ore)
-    P.r2c_fft_f32_with_planner(x, ore, oim, plr)
-    ms_r2c = wall(lambda: P.r2c_fft_f32_with_planner(x, ore, oim, plr), 20)
-    r2c_bytes = 4 * n24 + 8 * (n24 // 2 + 1)
-    res["r2c_f32_2p24"] = {"ms": ms_r2c, "gsamples_per_s": n24 / (ms_r2c * 1e-3) / 1e9,
-                           "algorithmic_GBps": r2c_bytes / (ms_r2c * 1e-3) / 1e9,
-                           "transform_frac": r2c_bytes / (ms_r2c * 1e-3) / 1e9 / HBM_PEAK_GBS}
-    del x, ore, oim, plr
-    # the drop-in call on host slices: H2D + transform + D2H, blocking (never the headline value)
-    pl = P.PlannerDit64(N)
-    h_re = np.random.default_rng(1).uniform(-1, 1, N)
-    h_im = np.random.default_rng(2).uniform(-1, 1, N)
-    P.fft_64_dit_with_planner(h_re, h_im, P.Direction.Forward, pl)
-    t0 = time.perf_counter()
-    for _ in range(5):
-        P.fft_64_dit_with_planner(h_re, h_im, P.Direction.Forward, pl)
-    ms_host = 1e3 * (time.perf_counter() - t0) / 5
-    res["n2p20_host_slices"] = {"ms": ms_host, "gsamples_per_s": N / (ms_host * 1e-3) / 1e9,
-                                "note": "pageable numpy arrays, PCIe both ways inside the call"}
-    re = torch.empty(SHARD * N, dtype=torch.float64, device=dev)
-    im = torch.empty_like(re)
-    P.fill_uniform(re, im, N)
-    P.fft_dit_batched(re, im, N, P.Direction.Forward, pl)
-    P.fill_uniform(re, im, N)
-    ms = pl.time_passes(re, im, N, reps=2)
-    res["n2p20_batch1024"] = {"plan": pl.describe(), "pass_ms": ms,
-                              "gsamples_per_s": SHARD * N / (sum(ms) * 1e-3) / 1e9,
-                              "transform_frac": 32 * SHARD * N / (sum(ms) * 1e-3) / 1e9 / HBM_PEAK_GBS}
-    return res
+def load_profiled_traffic_key(key, roofline):
+    t = _traffic_file()
+    if not t or key not in t:
+        return None
+    ks = t[key].get("kernels", [])
+    if not ks:
+        return None
+    k = max(ks, key=lambda x: x.get("hbm_bytes_per_launch", 0))
+    return {"traffic": k["hbm_bytes_per_launch"], "traffic_source": t[key]["source"], "traffic_kernel": k["kernel"]}
 
 
 if __name__ == "__main__":

@@ -241,6 +241,19 @@ int phast_planner_dit64_time_passes(const phast_planner_dit64 *p, double *d_real
 int phast_planner_dit32_time_passes(const phast_planner_dit32 *p, float *d_reals, float *d_imags, size_t batch,
                                     size_t dist, int reps, float *pass_ms, int *n_passes, void *stream);
 
+/* the same for a real transform: slots 0..n-2 = the passes of the inner N/2-point complex transform, slot n-1 = the
+ * untangle sweep (r2c.rs:150-242); a transform whose inner N/2 <= 8192 runs as ONE kernel (*n_passes = 1, slot 0 not
+ * timed per kernel -- use stream events around the call).  pass_ms must hold 4 floats. */
+int phast_planner_r2c64_time_passes(const phast_planner_r2c64 *p, const double *d_input, double *d_output_re,
+                                    double *d_output_im, size_t batch, size_t in_dist, size_t out_dist, int reps,
+                                    float *pass_ms, int *n_passes, void *stream);
+int phast_planner_r2c32_time_passes(const phast_planner_r2c32 *p, const float *d_input, float *d_output_re,
+                                    float *d_output_im, size_t batch, size_t in_dist, size_t out_dist, int reps,
+                                    float *pass_ms, int *n_passes, void *stream);
+/* plan of the inner N/2-point complex transform, as phast_planner_dit*_describe */
+int phast_planner_r2c64_describe(const phast_planner_r2c64 *p, char *buf, size_t buf_len);
+int phast_planner_r2c32_describe(const phast_planner_r2c32 *p, char *buf, size_t buf_len);
+
 #ifdef __cplusplus
 }
 #endif

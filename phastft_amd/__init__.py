@@ -256,6 +256,25 @@ class _PlannerR2c:
             pass
 
 
+    def describe(self) -> str:
+        """Plan of the inner N/2-point complex transform."""
+        buf = C.create_string_buffer(1024)
+        _check(getattr(_lib.lib(), f"phast_planner_r2c{self._sfx}_describe")(self._h, buf, C.c_size_t(1024)))
+        return buf.value.decode()
+
+    def time_passes(self, input_re, output_re, output_im, reps: int = 10):
+        """Average HIP-event duration (ms) of every kernel of one R2C transform of the device tensors: the passes of the
+        inner N/2-point transform, then the untangle sweep.  Measurement hook for bench.py."""
+        i, ore, oim = (_Slice(x, self._dtype, w) for x, w in ((input_re, "input_re"), (output_re, "output_re"),
+                                                              (output_im, "output_im")))
+        ms = (C.c_float * 4)()
+        npass = C.c_int()
+        _check(getattr(_lib.lib(), f"phast_planner_r2c{self._sfx}_time_passes")(
+            self._h, i.ptr, ore.ptr, oim.ptr, C.c_size_t(1), C.c_size_t(self.n), C.c_size_t(self.n // 2 + 1),
+            C.c_int(reps), ms, C.byref(npass), _stream()))
+        return [float(ms[k]) for k in range(npass.value)]
+
+
 class PlannerR2c64(_PlannerR2c):
     """planner.rs:164-212 (f64)"""
 

@@ -568,14 +568,16 @@ template <typename T> struct PlannerR2c {
     }
 
     // r2c.rs:535-593 / 607-662 on device pointers
-    int r2c(const T *d_in, T *d_ore, T *d_oim, size_t batch, size_t in_dist, size_t out_dist, hipStream_t s) const {
+    int r2c(const T *d_in, T *d_ore, T *d_oim, size_t batch, size_t in_dist, size_t out_dist, hipStream_t s,
+            PassTimer *timer = nullptr) const {
         const size_t half = n / 2;
         if (in_dist & 1) return PHAST_ERR_INVALID_ARG;  // the input is read as (even, odd) pairs
         std::lock_guard<std::recursive_mutex> call_lock(dit.call_mu);
         if (dit.passes.empty())  // N/2 <= 8192: one kernel, the untangle is its epilogue
             return dit.exec_small_real(1, d_in, nullptr, in_dist / 2, d_ore, d_oim, out_dist, batch, 1.0, d_tw3, tw_bits, s);
-        int rc = dit.exec(d_in, nullptr, in_dist / 2, 1, d_ore, d_oim, out_dist, 0, batch, 1.0, s);
+        int rc = dit.exec(d_in, nullptr, in_dist / 2, 1, d_ore, d_oim, out_dist, 0, batch, 1.0, s, timer);
         if (rc) return rc;
+        const int untangle_slot = (int)dit.plan_for(batch).size();  // timer slot after the inner transform's passes
         for (size_t b0 = 0; b0 < batch; b0 += 65535) {
             UntangleArgs ua{};
             ua.re = d_ore + b0 * out_dist;
@@ -585,7 +587,9 @@ template <typename T> struct PlannerR2c {
             ua.half = (unsigned)half;
             ua.tw_bits = tw_bits;
             ua.batch = (unsigned)(batch - b0 < 65535 ? batch - b0 : 65535);
-            PHAST_HIP(launch_untangle<T>(ua, s));
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (timer) PHAST_HIP(timer->pair(untangle_slot, &e0, &e1));
+            PHAST_HIP(launch_untangle<T>(ua, s, e0, e1));
         }
         return PHAST_OK;
     }
@@ -683,6 +687,31 @@ static int time_passes(const Planner<T> *pl, T *d_re, T *d_im, size_t batch, siz
     for (int r = 0; r < reps; ++r) {
         PassTimer tm;
         int rc = pl->exec(d_re, d_im, dist, 0, d_re, d_im, dist, 0, batch, 1.0, s, &tm);
+        if (rc) return rc;
+        PHAST_HIP(hipStreamSynchronize(s));
+        for (size_t i = 0; i < tm.pass_of.size(); ++i) {
+            float ms = 0;
+            PHAST_HIP(hipEventElapsedTime(&ms, tm.ev[2 * i], tm.ev[2 * i + 1]));
+            acc[tm.pass_of[i]] += ms;
+        }
+    }
+    for (int i = 0; i < np; ++i) pass_ms[i] = (float)(acc[i] / reps);
+    *n_passes = np;
+    return PHAST_OK;
+}
+
+// the same for a real transform: slots 0..np-1 = passes of the inner N/2-point transform, slot np = the untangle sweep
+// (a transform small enough for the one-pass kernel has the untangle fused: one slot)
+template <typename T>
+static int time_passes_r2c(const PlannerR2c<T> *pl, const T *d_in, T *d_ore, T *d_oim, size_t batch, size_t in_dist,
+                           size_t out_dist, int reps, float *pass_ms, int *n_passes, hipStream_t s) {
+    if (!pl || !d_in || !d_ore || !d_oim || !pass_ms || !n_passes || reps < 1) return PHAST_ERR_INVALID_ARG;
+    const int np = pl->dit.passes.empty() ? 1 : (int)pl->dit.plan_for(batch).size() + 1;
+    double acc[4] = {0, 0, 0, 0};
+    for (int r = 0; r < reps; ++r) {
+        PassTimer tm;
+        int rc = pl->dit.passes.empty() ? pl->r2c(d_in, d_ore, d_oim, batch, in_dist, out_dist, s)
+                                        : pl->r2c(d_in, d_ore, d_oim, batch, in_dist, out_dist, s, &tm);
         if (rc) return rc;
         PHAST_HIP(hipStreamSynchronize(s));
         for (size_t i = 0; i < tm.pass_of.size(); ++i) {
@@ -1048,7 +1077,16 @@ int phast_options_guess(size_t input_size, phast_options *out) {
     int phast_planner_r2c##SFX##_new(size_t n, phast_planner_r2c##SFX **out) {                                     \
         return r2c_planner_new(n, out);                                                                            \
     }                                                                                                              \
-    void phast_planner_r2c##SFX##_free(phast_planner_r2c##SFX *p) { delete p; }
+    void phast_planner_r2c##SFX##_free(phast_planner_r2c##SFX *p) { delete p; }                                    \
+    int phast_planner_r2c##SFX##_time_passes(const phast_planner_r2c##SFX *p, const T *d_in, T *d_ore, T *d_oim,    \
+                                             size_t batch, size_t in_dist, size_t out_dist, int reps,              \
+                                             float *pass_ms, int *n_passes, void *stream) {                        \
+        return time_passes_r2c<T>(p, d_in, d_ore, d_oim, batch, in_dist, out_dist, reps, pass_ms, n_passes,        \
+                                  static_cast<hipStream_t>(stream));                                               \
+    }                                                                                                              \
+    int phast_planner_r2c##SFX##_describe(const phast_planner_r2c##SFX *p, char *buf, size_t len) {                \
+        return p ? describe_to<T>(&p->dit, buf, len) : PHAST_ERR_INVALID_ARG;                                      \
+    }
 
 PHAST_PLANNER_API(64, double)
 PHAST_PLANNER_API(32, float)

@@ -43,7 +43,8 @@ struct UntangleArgs {
     unsigned tw_bits;
     unsigned batch;
 };
-template <typename T> hipError_t launch_untangle(const UntangleArgs &a, hipStream_t stream);
+template <typename T>
+hipError_t launch_untangle(const UntangleArgs &a, hipStream_t stream, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 
 struct C2rPreArgs {
     const void *in_re;  // [half + 1]

@@ -11,6 +11,8 @@
 // small-table entries (read through L1/L2: consecutive lanes hit consecutive level-0 entries and one
 // shared entry of the upper levels); unlike planner.rs:120-162 there is no rotation recurrence, so
 // there is no drift to reproduce -- the values are correctly rounded to ~1 ulp.
+#include <hip/hip_ext.h>
+
 #include "kernels.hpp"
 
 namespace phast {
@@ -93,8 +95,11 @@ static inline dim3 grid_for(unsigned work, unsigned batch) {
     return dim3(gx, batch < 65535u ? batch : 65535u);
 }
 
-template <typename T> hipError_t launch_untangle(const UntangleArgs &a, hipStream_t stream) {
-    hipLaunchKernelGGL(untangle_kernel<T>, grid_for(a.half / 2 + 1, a.batch), dim3(256), 0, stream, a);
+template <typename T> hipError_t launch_untangle(const UntangleArgs &a, hipStream_t stream, hipEvent_t e0, hipEvent_t e1) {
+    if (e0 && e1)  // measurement hook: events bound to the dispatch (kernel execution time)
+        hipExtLaunchKernelGGL(untangle_kernel<T>, grid_for(a.half / 2 + 1, a.batch), dim3(256), 0, stream, e0, e1, 0, a);
+    else
+        hipLaunchKernelGGL(untangle_kernel<T>, grid_for(a.half / 2 + 1, a.batch), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 template <typename T> hipError_t launch_c2r_preprocess(const C2rPreArgs &a, hipStream_t stream) {
@@ -102,8 +107,8 @@ template <typename T> hipError_t launch_c2r_preprocess(const C2rPreArgs &a, hipS
     return hipGetLastError();
 }
 
-template hipError_t launch_untangle<float>(const UntangleArgs &, hipStream_t);
-template hipError_t launch_untangle<double>(const UntangleArgs &, hipStream_t);
+template hipError_t launch_untangle<float>(const UntangleArgs &, hipStream_t, hipEvent_t, hipEvent_t);
+template hipError_t launch_untangle<double>(const UntangleArgs &, hipStream_t, hipEvent_t, hipEvent_t);
 template hipError_t launch_c2r_preprocess<float>(const C2rPreArgs &, hipStream_t);
 template hipError_t launch_c2r_preprocess<double>(const C2rPreArgs &, hipStream_t);
 
