@@ -142,7 +142,7 @@ def kernel_tags(plan_list: str, dtype: str = "double"):
     import re
 
     tags = []
-    for rows, cols, pts in re.findall(r"\[(\d+)x(\d+)A? p(\d+)", plan_list):
+    for rows, cols, pts in re.findall(r"\[(\d+)x(\d+)A? [pw](\d+)", plan_list):
         tags.append(f"<{dtype}, {int(math.log2(int(rows)))}, {int(math.log2(int(cols)))}, {int(math.log2(int(pts)))},")
     return tags
 
@@ -367,8 +367,9 @@ def main():
         lrs_s, rest = args.plan.split("@")
         tl_s, p_s = rest.split("p")
         tls = tuple(int(x) for x in tl_s.split(","))
+        wave = 0x10 if p_s.endswith("w") else 0   # "...p8w": 64 x 16 tiles as wave tiles (wave_fft.hpp)
         planner.set_plan(tuple(int(x) for x in lrs_s.split(",")), tls if len(tls) > 1 else tls[0],
-                         {8: 3, 16: 4, 32: 5}[int(p_s)])
+                         {8: 3, 16: 4, 32: 5}[int(p_s.rstrip("w"))] | wave)
     plan_text = planner.describe()
     check_info = None
 

@@ -107,6 +107,11 @@ template <> struct Types<double> {
         return launch_tile_f64_bc(lr, lc, lp, g, s, a, q, b, l, e0, e1);
     }
 };
+template <typename T> static hipError_t launch_wave(bool transpose, hipStream_t s, const TileArgs &a, bool q, int *b, size_t *l,
+                                                    hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
+    if constexpr (sizeof(T) == 8) return launch_wave_f64(transpose, s, a, q, b, l, e0, e1);
+    else return hipErrorInvalidValue;  // wave tiles exist for f64 only (make_passes never asks for them in f32)
+}
 template <> struct Types<float> {
     static hipError_t launch_a(int lr, int lc, int lp, unsigned g, hipStream_t s, const TileArgs &a, bool q, int *b,
                                size_t *l, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
@@ -278,7 +283,8 @@ template <typename T> struct Planner {
             if (rc == PHAST_OK) {
                 TileArgs ta{};
                 ta.tw_bits = ps[i].tw_bits;
-                hipError_t e = ps[i].transpose
+                hipError_t e = ps[i].wave ? launch_wave<T>(ps[i].transpose, nullptr, ta, true, &ps[i].blocks_per_cu, &ps[i].lds)
+                               : ps[i].transpose
                                    ? Types<T>::launch_a(ps[i].lr, ps[i].lc, (int)ps[i].lp, 0, nullptr, ta, true, &ps[i].blocks_per_cu, &ps[i].lds)
                                    : Types<T>::launch_bc(ps[i].lr, ps[i].lc, (int)ps[i].lp, 0, nullptr, ta, true, &ps[i].blocks_per_cu, &ps[i].lds);
                 if (e != hipSuccess) rc = hip_fail(e, "occupancy query");
@@ -392,8 +398,8 @@ template <typename T> struct Planner {
         auto add = [&](const char *tag, const std::vector<PassDesc> &v) {
             s += std::string(" ") + tag + "=" + std::to_string(v.size()) + "p";
             for (auto &p : v) {
-                std::snprintf(buf, sizeof buf, "[%ux%u%s p%u lds=%zu wg/cu=%d]", 1u << p.lr, 1u << p.lc,
-                              p.transpose ? "A" : "", 1u << p.lp, p.lds, p.blocks_per_cu);
+                std::snprintf(buf, sizeof buf, "[%ux%u%s %s%u lds=%zu wg/cu=%d]", 1u << p.lr, 1u << p.lc,
+                              p.transpose ? "A" : "", p.wave ? "w" : "p", 1u << p.lp, p.lds, p.blocks_per_cu);
                 s += buf;
             }
         };
@@ -513,8 +519,9 @@ template <typename T> struct Planner {
                 if (grid >= 8) grid &= ~7u;  // keep tile%8 == workgroup%8 (XCD affinity of the tile order)
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (timer) PHAST_HIP(timer->pair((int)i, &e0, &e1));
-                hipError_t e = p.transpose ? Types<T>::launch_a(p.lr, p.lc, (int)p.lp, grid, stream, ta, false, nullptr, nullptr, e0, e1)
-                                           : Types<T>::launch_bc(p.lr, p.lc, (int)p.lp, grid, stream, ta, false, nullptr, nullptr, e0, e1);
+                hipError_t e = p.wave      ? launch_wave<T>(p.transpose, stream, ta, false, nullptr, nullptr, e0, e1)
+                               : p.transpose ? Types<T>::launch_a(p.lr, p.lc, (int)p.lp, grid, stream, ta, false, nullptr, nullptr, e0, e1)
+                                             : Types<T>::launch_bc(p.lr, p.lc, (int)p.lp, grid, stream, ta, false, nullptr, nullptr, e0, e1);
                 if (e != hipSuccess) return hip_fail(e, "tile_fft launch");
             }
         }
@@ -931,7 +938,7 @@ static int set_plan_c(Planner<T> *p, const unsigned *log_rows, const unsigned *t
         lrs.assign(log_rows, log_rows + n_passes);
         tls.assign(tile_logs, tile_logs + n_passes);
     }
-    if (points_log < 3 || points_log > 5) return PHAST_ERR_INVALID_ARG;
+    if ((points_log & 0xfu) < 3 || (points_log & 0xfu) > 5 || (points_log & ~0x1fu)) return PHAST_ERR_INVALID_ARG;
     return p->set_plan(lrs, tls, 0, points_log);
 }
 

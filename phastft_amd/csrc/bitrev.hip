@@ -128,6 +128,111 @@ __global__ void __launch_bounds__(NTH) bitrev_persistent_kernel(U *data, unsigne
     }
 }
 
+// Second generation of the persistent kernel (round 2):
+//   * 16 bytes per lane on the global side (two adjacent elements: a 64-element f64 row is 32 lanes x 16 B), non-temporal
+//     -- every byte is touched once;
+//   * SPREAD tile order: work item w -> tile t with the bits of w dealt alternately to the LOW and the HIGH end of t.  In
+//     linear order the tiles in flight at one moment are consecutive t, so their partners rev(t) differ only in their
+//     HIGH bits: power-of-two strides of megabytes that pile onto few HBM channels / DRAM pages.  Dealing the bits to
+//     both ends makes both the t side and the rev(t) side "32 neighbours x 32 far apart".
+template <typename U> struct Vec2;  // clang vector types: what the nontemporal builtins accept
+template <> struct Vec2<unsigned long long> { typedef unsigned long long type __attribute__((ext_vector_type(2))); };
+template <> struct Vec2<unsigned> { typedef unsigned type __attribute__((ext_vector_type(2))); };
+
+template <typename U, int BETA, int NTH, bool SPREAD>
+__global__ void __launch_bounds__(NTH) bitrev_persistent2_kernel(U *data, unsigned log_n, size_t dist, unsigned tiles,
+                                                                 unsigned long long total) {
+    using V2 = typename Vec2<U>::type;
+    constexpr int B = 1 << BETA, PER = B * B / (2 * NTH);  // element PAIRS per thread per tile
+    static_assert(PER >= 1, "tile too small for this workgroup");
+    __shared__ U sa[B][B + 1];
+    __shared__ U sb[B][B + 1];
+    const unsigned tile_bits = log_n - 2 * BETA;
+    const unsigned ustride_log = log_n - BETA;
+    auto rev_t = [&](unsigned t) { return tile_bits ? (__brev(t) >> (32u - tile_bits)) : 0u; };
+    auto tile_of = [&](unsigned wl) {  // position in the work order -> tile
+        if (!SPREAD) return wl;
+        unsigned t = 0;
+        for (unsigned i = 0; i < tile_bits; ++i) {
+            const unsigned bit = (wl >> i) & 1u;
+            const unsigned pos = (i & 1u) ? tile_bits - 1u - (i >> 1) : (i >> 1);
+            t |= bit << pos;
+        }
+        return t;
+    };
+    auto advance = [&](unsigned long long w) {  // next work item at or after `w` whose tile is the smaller of its pair
+        while (w < total) {
+            const unsigned t = tile_of((unsigned)(w % tiles));
+            if (t <= rev_t(t)) break;
+            w += gridDim.x;
+        }
+        return w;
+    };
+    V2 ra[PER], rb[PER];
+    auto load = [&](unsigned long long w) {
+        const unsigned t = tile_of((unsigned)(w % tiles)), tr = rev_t(t);
+        const U *x = data + (size_t)(w / tiles) * dist;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = i * NTH + threadIdx.x;
+            const unsigned u = idx >> (BETA - 1), v = (idx & (B / 2 - 1)) * 2;
+            ra[i] = __builtin_nontemporal_load(reinterpret_cast<const V2 *>(x + ((size_t)u << ustride_log) + ((size_t)t << BETA) + v));
+            rb[i] = __builtin_nontemporal_load(reinterpret_cast<const V2 *>(x + ((size_t)u << ustride_log) + ((size_t)tr << BETA) + v));
+        }
+    };
+    unsigned long long w = advance(blockIdx.x);
+    if (w < total) load(w);
+    while (w < total) {
+        const unsigned t = tile_of((unsigned)(w % tiles)), tr = rev_t(t);
+        U *x = data + (size_t)(w / tiles) * dist;
+        __syncthreads();  // the previous pair's readers are done
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = i * NTH + threadIdx.x;
+            const unsigned u = idx >> (BETA - 1), v = (idx & (B / 2 - 1)) * 2;
+            sa[u][v] = ra[i].x;
+            sa[u][v + 1] = ra[i].y;
+            sb[u][v] = rb[i].x;
+            sb[u][v + 1] = rb[i].y;
+        }
+        __syncthreads();
+        V2 oa[PER], ob[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = i * NTH + threadIdx.x;
+            const unsigned u = idx >> (BETA - 1), v = (idx & (B / 2 - 1)) * 2;
+            const unsigned ru = __brev(u) >> (32 - BETA), rv = __brev(v) >> (32 - BETA);  // rev(v + 1) = rv + B/2
+            oa[i].x = sb[rv][ru];
+            oa[i].y = sb[rv + B / 2][ru];
+            ob[i].x = sa[rv][ru];
+            ob[i].y = sa[rv + B / 2][ru];
+        }
+        const unsigned long long wn = advance(w + gridDim.x);
+        if (wn < total) load(wn);  // in flight during the stores below
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = i * NTH + threadIdx.x;
+            const unsigned u = idx >> (BETA - 1), v = (idx & (B / 2 - 1)) * 2;
+            __builtin_nontemporal_store(oa[i], reinterpret_cast<V2 *>(x + ((size_t)u << ustride_log) + ((size_t)t << BETA) + v));
+            if (t != tr)
+                __builtin_nontemporal_store(ob[i], reinterpret_cast<V2 *>(x + ((size_t)u << ustride_log) + ((size_t)tr << BETA) + v));
+        }
+        w = wn;
+    }
+}
+
+template <typename U, int BETA, int NTH, bool SPREAD>
+static hipError_t launch_bitrev_persistent2(U *data, unsigned log_n, size_t batch, size_t dist, hipStream_t stream,
+                                            unsigned wg_per_cu) {
+    const unsigned tiles = 1u << (log_n - 2 * BETA);
+    const unsigned long long total = (unsigned long long)tiles * batch;
+    unsigned long long grid = 256ull * wg_per_cu;
+    if (grid > total) grid = total;
+    hipLaunchKernelGGL((bitrev_persistent2_kernel<U, BETA, NTH, SPREAD>), dim3((unsigned)grid), dim3(NTH), 0, stream, data,
+                       log_n, dist, tiles, total);
+    return hipGetLastError();
+}
+
 template <typename U, int BETA, int NTH>
 static hipError_t launch_bitrev_persistent(U *data, unsigned log_n, size_t batch, size_t dist, hipStream_t stream,
                                            unsigned wg_per_cu) {
@@ -169,7 +274,7 @@ static int bitrev_variant() {  // tuning hook (tools/sweep_bitrev.py): PHAST_BIT
     return e ? atoi(e) : 0;
 }
 
-// Defaults from profiles/r01_sweep_bitrev.log: the persistent kernel with 64 x 64 tiles (512-byte rows for f64,
+// Defaults (first generation) from profiles/r01_sweep_bitrev.log: the persistent kernel with 64 x 64 tiles (512-byte rows for f64,
 // 256-byte for f32), 512 threads, 4 workgroups per CU -- 3.4-3.7 TB/s at 2^26..2^30 f64, 3.4-4.6 f32.  Variant 1
 // is the one-pair-per-workgroup kernel (32 x 32 tiles for f64) the persistent one replaced.
 template <> hipError_t launch_bitrev<double>(double *data, unsigned log_n, size_t batch, size_t dist, hipStream_t s) {
@@ -179,6 +284,18 @@ template <> hipError_t launch_bitrev<double>(double *data, unsigned log_n, size_
     if (v == 2) return launch_bitrev_persistent<unsigned long long, 5, 256>(p, log_n, batch, dist, s, 8);
     if (v == 3) return launch_bitrev_persistent<unsigned long long, 6, 512>(p, log_n, batch, dist, s, 2);
     if (v == 4) return launch_bitrev_persistent<unsigned long long, 6, 1024>(p, log_n, batch, dist, s, 2);
+    const bool even = (dist & 1) == 0 && (reinterpret_cast<size_t>(data) & 15) == 0;  // 16-byte accesses need it
+    if (v == 5 && even) return launch_bitrev_persistent2<unsigned long long, 6, 512, false>(p, log_n, batch, dist, s, 4);
+    if (v == 6 && even) return launch_bitrev_persistent2<unsigned long long, 6, 512, true>(p, log_n, batch, dist, s, 4);
+    if (v == 7 && even) return launch_bitrev_persistent2<unsigned long long, 6, 256, true>(p, log_n, batch, dist, s, 4);
+    if (v == 8 && even) return launch_bitrev_persistent2<unsigned long long, 6, 512, true>(p, log_n, batch, dist, s, 2);
+    // round 2 (profiles/r02_sweep_bitrev.log): once the array is past the 256 MiB Infinity Cache the 16-byte-per-lane,
+    // non-temporal generation is 4-10 % faster (2^26: 3.9 vs 3.6 TB/s with 256 threads, 2^30: 3.8 vs 3.4 with 512);
+    // the spread tile order buys nothing (so HBM channel camping is not what holds this kernel at ~0.75 of the copy
+    // rate), and for 4-byte elements the first generation stays ahead at every size
+    if (v == 0 && even && log_n >= 29) return launch_bitrev_persistent2<unsigned long long, 6, 512, false>(p, log_n, batch, dist, s, 4);
+    if (v == 0 && even && (((size_t)batch << log_n) >= ((size_t)1 << 25)))
+        return launch_bitrev_persistent2<unsigned long long, 6, 256, true>(p, log_n, batch, dist, s, 4);
     return launch_bitrev_persistent<unsigned long long, 6, 512>(p, log_n, batch, dist, s, 4);
 }
 template <> hipError_t launch_bitrev<float>(float *data, unsigned log_n, size_t batch, size_t dist, hipStream_t s) {
@@ -188,6 +305,11 @@ template <> hipError_t launch_bitrev<float>(float *data, unsigned log_n, size_t 
     if (v == 2) return launch_bitrev_persistent<unsigned, 6, 512>(p, log_n, batch, dist, s, 8);
     if (v == 3) return launch_bitrev_persistent<unsigned, 6, 1024>(p, log_n, batch, dist, s, 2);
     if (v == 4 && log_n >= 14) return launch_bitrev_persistent<unsigned, 7, 1024>(p, log_n, batch, dist, s, 2);
+    const bool even = (dist & 3) == 0 && (reinterpret_cast<size_t>(data) & 15) == 0;
+    if (v == 5 && even) return launch_bitrev_persistent2<unsigned, 6, 512, false>(p, log_n, batch, dist, s, 4);
+    if (v == 6 && even) return launch_bitrev_persistent2<unsigned, 6, 512, true>(p, log_n, batch, dist, s, 4);
+    if (v == 7 && even) return launch_bitrev_persistent2<unsigned, 6, 256, true>(p, log_n, batch, dist, s, 4);
+    if (v == 8 && even && log_n >= 14) return launch_bitrev_persistent2<unsigned, 7, 1024, true>(p, log_n, batch, dist, s, 2);
     return launch_bitrev_persistent<unsigned, 6, 512>(p, log_n, batch, dist, s, 4);
 }
 

@@ -112,10 +112,13 @@ inline bool shape_exists(unsigned lr, unsigned lc, unsigned lp, size_t elem_byte
     return false;
 }
 
+constexpr unsigned kWaveTiles = 0x10;  // flag in a plan's points-per-thread code, see make_passes
+
 // ---- geometry of one pass (see TileArgs in common.hpp) ----
 struct PassGeom {
     unsigned lr = 0, lc = 0;
     unsigned lp = 4;  // log2(points per thread): 4 = throughput tiles, 3 = latency tiles (twice the waves)
+    bool wave = false;  // one wave per 64 x 16 tile, exchange by cross-lane swaps (wave_fft.hpp; f64 only)
     bool pre_tw = false, transpose = false;
     unsigned log_s_in = 0, out_lo_bits = 0, tw_bits = 1;
     unsigned long long out_s1 = 0, out_s2 = 0, out_row_stride = 0;
@@ -143,6 +146,14 @@ inline void heuristic_plan(unsigned L, bool latency, std::vector<unsigned> &lrs,
         for (unsigned i = 0; i < np; ++i) lrs.push_back(L / np + (i < L % np ? 1 : 0));  // balanced, larger first
     };
     const bool f64 = sizeof(T) == 8;
+    if (latency && f64 && (L == 20 || L == 18)) {
+        // round 2: the 64-row passes as WAVE tiles (one wave per 64 x 16 tile, swaps instead of LDS exchanges and
+        // barriers: wave_fft.hpp) around the 256-row LDS pass -- profiles/r02_sweep_wave_tiles.log
+        lrs = L == 20 ? std::vector<unsigned>{6, 8, 6} : std::vector<unsigned>{6, 6, 6};
+        tls = L == 20 ? std::vector<unsigned>{10, 12, 10} : std::vector<unsigned>{10, 10, 10};
+        lp = 3 | kWaveTiles;
+        return;
+    }
     if (latency) {
         split(L <= 19 ? 2 : 3);
         // three passes: short outer FFTs (64 x 64 tiles: 512-byte rows) around a longer middle one; measured
@@ -212,12 +223,18 @@ inline bool make_passes(unsigned L, const std::vector<unsigned> &lrs, const std:
     if (tile_logs.size() != 1 && tile_logs.size() != lrs.size()) return false;
     ps.assign(lrs.size(), PassGeom());
     const unsigned a = lrs[0], b = lrs[1], c = lrs.size() == 3 ? lrs[2] : 0;
+    // lp & 0x10 (kWaveTiles): every pass whose tile is 64 rows x 16 columns runs as wave tiles (f64 only);
+    // lp & 0xf = log2(points per thread) of the other passes
+    const bool want_wave = (lp & kWaveTiles) != 0 && elem_bytes == 8;
+    lp &= 0xfu;
     for (size_t i = 0; i < lrs.size(); ++i) {
         const unsigned tl = tile_logs.size() == 1 ? tile_logs[0] : tile_logs[i];
-        if (lrs[i] > tl || !shape_exists(lrs[i], tl - lrs[i], lp, elem_bytes)) return false;
+        if (lrs[i] > tl) return false;
         ps[i].lr = lrs[i];
         ps[i].lc = tl - lrs[i];
-        ps[i].lp = lp;
+        ps[i].wave = want_wave && lrs[i] == 6 && tl == 10;
+        ps[i].lp = ps[i].wave ? 4 : lp;
+        if (!ps[i].wave && !shape_exists(lrs[i], tl - lrs[i], lp, elem_bytes)) return false;
     }
     ps[0].transpose = true;  // FFT over the top `a` index bits; every column leaves as one contiguous run
     ps[0].log_s_in = L - a;

@@ -35,4 +35,8 @@ hipError_t launch_tile_f32_a(int lr, int lc, int lp, unsigned grid, hipStream_t 
 hipError_t launch_tile_f32_bc(int lr, int lc, int lp, unsigned grid, hipStream_t s, const TileArgs &a, bool q, int *b, size_t *l,
                            hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 
+// defined in wave_f64.hip: one wave per 64 x 16 tile (wave_fft.hpp); transpose = first pass, else a pre-twiddle pass
+hipError_t launch_wave_f64(bool transpose, hipStream_t s, const TileArgs &a, bool q, int *b, size_t *l,
+                           hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+
 }  // namespace phast

@@ -1,0 +1,359 @@
+// wave_fft.hpp -- one pass of the multi-pass FFT with ONE WAVE PER TILE and the butterfly exchange done by
+// cross-lane swaps instead of LDS + barriers (f64; BASELINE.json north_star: "cross-lane shuffles via
+// DS_PERMUTE/ds_swizzle wavefront primitives" -- on gfx950 the cheapest member of that family for this pattern is
+// v_permlane16_swap / v_permlane32_swap, one VALU instruction per swapped dword pair, no LDS round trip).
+//
+// Same pass algebra as tile_fft.hpp (see there for the reference citations: kernels/dit.rs, algorithms/dit.rs,
+// algorithms/bravo.rs): a tile is ROWS = 64 rows x COLS = 16 adjacent columns (128-byte rows in f64) = 1024 points,
+// held by the 64 lanes of one wave at P = 16 points per lane:
+//     lane = (col = lane & 15, tau = lane >> 4),   register j holds row n = 4 j + tau        (j = 0..15)
+//   1. radix-16 DIF over j in registers (literal twiddles)            -> register p holds digit k1 = bitrev4(p)
+//   2. inter-digit twiddle W_64^(tau * k1)
+//   3. EXCHANGE: the 4 x 4 transposition between the lane bits (5, 4) = tau and the register bits (p1, p0):
+//         round 1: v_permlane32_swap on the register pairs (p, p | 2)   -- lane bit 5 <-> register bit 1
+//         round 2: v_permlane16_swap on the register pairs (p, p | 1)   -- lane bit 4 <-> register bit 0
+//      afterwards lane tau' = (b5 b4), register (p3 p2 s1 s0) holds the value of tau = (s1 s0), k1 = bitrev4(p3 p2 b5 b4)
+//   4. radix-4 DIF over tau in registers, four independent groups     -> register 4 g + s holds k2 = bitrev2(s)
+//      output row k = k1 + 16 k2
+// No workgroup barrier anywhere in a tile's life (one at kernel start, behind the twiddle-table staging); the four
+// waves of a 256-thread block are four independent tiles.  Pass A's transposition to contiguous output runs goes through
+// a WAVE-PRIVATE LDS buffer (written and read by the same wave: ordered by the LDS queue, no barrier).
+//
+// Phase functions are __host__ __device__ (per lane); tests/emu/emu.hip runs them lane by lane with the swaps emulated.
+#pragma once
+
+#include <vector>
+
+#include "tile_fft.hpp"
+
+namespace phast {
+
+template <typename T, bool PRE_TW, bool TRANSPOSE> struct WaveBody {
+    using cx = cx_t<T>;
+    static constexpr int LR = 6, LC = 4, LP = 4;
+    static constexpr int ROWS = 64, COLS = 16, P = 16, TAUS = 4;
+    static constexpr int WAVES = 4, NT = 64 * WAVES;  // tiles (= waves) per workgroup
+    static constexpr int CS = ROWS + 1;               // column pitch of the transposing buffer: odd => conflict-free
+    static constexpr int XP = TRANSPOSE ? COLS * CS : 0;  // elements per plane per wave
+    static constexpr bool NT_HINT = COLS * sizeof(T) >= 128;
+
+    struct Regs {
+        T re[P], im[P];
+        unsigned xform, g0;
+    };
+
+    static size_t lds_bytes(unsigned tw_bits) {
+        return (PRE_TW ? (size_t)(3u << tw_bits) * sizeof(cx) : 0) + 32 * sizeof(cx) + (size_t)2 * XP * WAVES * sizeof(T);
+    }
+
+    PHAST_HD static int col_of(int lane) { return lane & (COLS - 1); }
+    PHAST_HD static int tau_of(int lane) { return lane >> LC; }
+
+    // tile index -> (transform, first column); XCD-aware: workgroup b (on XCD b % 8) owns 4 adjacent tiles and each XCD
+    // gets one contiguous run of workgroups (cf. TileBody::locate)
+    PHAST_HD static void locate(const TileArgs &a, unsigned block, unsigned blocks_total, unsigned wave, Regs &r) {
+        const unsigned b = ((blocks_total & 7u) == 0u) ? (block & 7u) * (blocks_total >> 3) + (block >> 3) : block;
+        const unsigned tile = b * WAVES + wave;
+        r.xform = tile / a.tiles_per_xform;
+        r.g0 = (tile - r.xform * a.tiles_per_xform) << LC;
+    }
+
+    // rows n = 4 j + tau: one VGPR offset for all 16 loads, the row part is wave-uniform
+    PHAST_HD static void load_raw(const TileArgs &a, int lane, Regs &r) {
+        const int col = col_of(lane), tau = tau_of(lane);
+        const unsigned lo0 = r.g0 & ((1u << a.log_s_in) - 1u);
+        const size_t ubase = (size_t)r.xform * a.in_dist + (((size_t)(r.g0 >> a.log_s_in) << (a.log_s_in + LR)) | lo0);
+        const unsigned voff = ((unsigned)tau << a.log_s_in) + (unsigned)col;
+        if (PRE_TW || !a.in_interleaved) {
+            const T *pr = reinterpret_cast<const T *>(a.in_re) + ubase;
+            const T *pi = reinterpret_cast<const T *>(a.in_im) + ubase;
+            static_for<0, P>([&](auto j) {
+                const size_t urow = (size_t)(decltype(j)::value * TAUS) << a.log_s_in;
+                if constexpr (NT_HINT) {
+                    r.re[j] = __builtin_nontemporal_load(pr + urow + voff);
+                    r.im[j] = __builtin_nontemporal_load(pi + urow + voff);
+                } else {
+                    r.re[j] = (pr + urow)[voff];
+                    r.im[j] = (pi + urow)[voff];
+                }
+            });
+        } else {  // first pass of an interleaved / real transform: (re, im) or (im, re) pairs
+            const cx *pz = reinterpret_cast<const cx *>(a.in_re) + ubase;
+            static_for<0, P>([&](auto j) {
+                const size_t urow = (size_t)(decltype(j)::value * TAUS) << a.log_s_in;
+                cx v = (pz + urow)[voff];
+                r.re[j] = a.in_interleaved == 2 ? v.y : v.x;
+                r.im[j] = a.in_interleaved == 2 ? v.x : v.y;
+            });
+        }
+    }
+
+    // inter-pass twiddle W_{64 S}^{row * lo}: row = tau + 4 j  =>  W^(tau lo) * (W^(4 lo))^j.  Two table look-ups and a
+    // power ladder of depth <= 4 instead of 16 look-ups (48 LDS reads): the ladder's rounding (<= 4 extra complex
+    // products, ~1.3e-16 each) is far inside the 1e-13 budget (measured rel-L2 unchanged, tests/test_gpu_parity.py)
+    PHAST_HD static void pre_twiddle(const TileArgs &a, const cx *tw3, int lane, Regs &r) {
+        if constexpr (PRE_TW) {
+            const unsigned lo = (r.g0 & ((1u << a.log_s_in) - 1u)) + (unsigned)col_of(lane);
+            T br, bi, dr, di;
+            tw3_lookup<T>(tw3, a.tw_bits, (unsigned)tau_of(lane) * lo, br, bi);
+            tw3_lookup<T>(tw3, a.tw_bits, (unsigned)TAUS * lo, dr, di);
+            T pr[P], pi[P];  // D^j: 1, D, D^2 = D D, D^3 = D^2 D, D^4 = D^2 D^2, ... (products of at most 4 factors deep)
+            pr[0] = (T)1;
+            pi[0] = (T)0;
+            pr[1] = dr;
+            pi[1] = di;
+            static_for<2, P>([&](auto j) {
+                constexpr int J = decltype(j)::value, H = J / 2, G = J - H;
+                pr[J] = pr[H] * pr[G] - pi[H] * pi[G];
+                pi[J] = pr[H] * pi[G] + pi[H] * pr[G];
+            });
+            static_for<0, P>([&](auto j) {
+                const T wr = br * pr[j] - bi * pi[j], wi = br * pi[j] + bi * pr[j];
+                cmul(r.re[j], r.im[j], wr, wi);
+            });
+        }
+    }
+
+    // W_64^e, e < 64, from the first 32 entries of host_twr(64): W^(e + 32) = -W^e
+    PHAST_HD static void w64(const cx *twr, unsigned e, T &wr, T &wi) {
+        const cx w = twr[e & 31u];
+        wr = (e & 32u) ? -w.x : w.x;
+        wi = (e & 32u) ? -w.y : w.y;
+    }
+
+    PHAST_HD static void step1(const cx *twr, int lane, Regs &r) {
+        fft_reg_dif<T, 16, 0, P>(r.re, r.im);
+        const unsigned tau = (unsigned)tau_of(lane);
+        static_for<1, P>([&](auto p) {
+            constexpr int K1 = bitrev_c(decltype(p)::value, 4);
+            T wr, wi;
+            w64(twr, tau * K1, wr, wi);
+            cmul(r.re[p], r.im[p], wr, wi);
+        });
+    }
+
+    PHAST_HD static void step2(Regs &r) {
+        static_for<0, 4>([&](auto g) { fft_reg_dif<T, 4, decltype(g)::value * 4, P>(r.re, r.im); });
+    }
+
+    // output row held by register Q = 4 g + s of lane tau' after step2:  k1 + 16 k2,
+    //   k1 = bitrev4(p3 p2 b5 b4) = 8 b4 + 4 b5 + 2 p2 + p3  (g = p3 p2, tau' = b5 b4),  k2 = bitrev2(s)
+    PHAST_HD static unsigned krow_lane(int lane) {
+        const unsigned t = (unsigned)tau_of(lane);
+        return ((t & 1u) << 3) | ((t >> 1) << 2);
+    }
+    template <int Q> PHAST_HD static constexpr unsigned krow_const() {
+        constexpr int G = Q >> 2, S = Q & 3;
+        return (unsigned)(((G & 1) << 1) | (G >> 1)) + 16u * (unsigned)bitrev_c(S, 2);
+    }
+
+    PHAST_HD static size_t out_base(const TileArgs &a, const Regs &r) {
+        return (size_t)(r.g0 & ((1u << a.out_lo_bits) - 1u)) * a.out_s1 + (size_t)(r.g0 >> a.out_lo_bits) * a.out_s2 +
+               (size_t)r.xform * a.out_dist;
+    }
+    PHAST_HD static void put(const TileArgs &a, size_t ubase, unsigned voff, T re, T im) {
+        const T scale = (T)a.scale;
+        if (TRANSPOSE || !a.out_interleaved) {
+            if constexpr (NT_HINT) {
+                __builtin_nontemporal_store(re * scale, reinterpret_cast<T *>(a.out_re) + ubase + voff);
+                __builtin_nontemporal_store(im * scale, reinterpret_cast<T *>(a.out_im) + ubase + voff);
+            } else {
+                (reinterpret_cast<T *>(a.out_re) + ubase)[voff] = re * scale;
+                (reinterpret_cast<T *>(a.out_im) + ubase)[voff] = im * scale;
+            }
+        } else {
+            cx v;
+            v.x = (a.out_interleaved == 2 ? im : re) * scale;
+            v.y = (a.out_interleaved == 2 ? re : im) * scale;
+            (reinterpret_cast<cx *>(a.out_re) + ubase)[voff] = v;
+        }
+    }
+    // later passes: same column-wide pattern out as in
+    PHAST_HD static void store_rows(const TileArgs &a, int lane, const Regs &r) {
+        const size_t base = out_base(a, r);
+        const unsigned voff = (unsigned)col_of(lane) * (unsigned)a.out_s1 + krow_lane(lane) * (unsigned)a.out_row_stride;
+        static_for<0, P>([&](auto Q) {
+            put(a, base + (size_t)krow_const<decltype(Q)::value>() * a.out_row_stride, voff, r.re[Q], r.im[Q]);
+        });
+    }
+    // pass A: through the wave-private buffer [col][k], then register Q holds row k = lane of column Q
+    PHAST_HD static int xp_waddr(int lane, int Q_k) { return col_of(lane) * CS + Q_k; }
+    template <int Q> PHAST_HD static int xp_write_addr(int lane) {
+        return col_of(lane) * CS + (int)krow_lane(lane) + (int)krow_const<Q>();
+    }
+    template <int Q> PHAST_HD static int xp_read_addr(int lane) { return Q * CS + lane; }
+    PHAST_HD static void store_runs(const TileArgs &a, int lane, const Regs &r) {
+        const size_t base = out_base(a, r);
+        const unsigned voff = (unsigned)lane * (unsigned)a.out_row_stride;
+        static_for<0, P>([&](auto Q) { put(a, base + (size_t)decltype(Q)::value * a.out_s1, voff, r.re[Q], r.im[Q]); });
+    }
+};
+
+// ---- the exchange on the GPU: lane bits (5, 4) <-> register bits (1, 0), one VALU swap per dword pair ----
+__device__ __forceinline__ void swap_lane_halves(unsigned &a, unsigned &b) {  // a.lanes[32..63] <-> b.lanes[0..31]
+    auto v = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = v[0];
+    b = v[1];
+}
+__device__ __forceinline__ void swap_lane_rows(unsigned &a, unsigned &b) {  // a.rows{1,3} <-> b.rows{0,2} (16-lane rows)
+    auto v = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    a = v[0];
+    b = v[1];
+}
+template <bool HALVES> __device__ __forceinline__ void swap_pair(double &a, double &b) {
+    unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a);
+    unsigned blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
+    if constexpr (HALVES) {
+        swap_lane_halves(alo, blo);
+        swap_lane_halves(ahi, bhi);
+    } else {
+        swap_lane_rows(alo, blo);
+        swap_lane_rows(ahi, bhi);
+    }
+    a = __hiloint2double((int)ahi, (int)alo);
+    b = __hiloint2double((int)bhi, (int)blo);
+}
+template <bool HALVES> __device__ __forceinline__ void swap_pair(float &a, float &b) {
+    unsigned x = __float_as_uint(a), y = __float_as_uint(b);
+    if constexpr (HALVES) swap_lane_halves(x, y);
+    else swap_lane_rows(x, y);
+    a = __uint_as_float(x);
+    b = __uint_as_float(y);
+}
+template <typename T> __device__ __forceinline__ void wave_exchange(T (&re)[16], T (&im)[16]) {
+    static_for<0, 16>([&](auto p) {  // round 1: lane bit 5 <-> register bit 1
+        constexpr int Pp = decltype(p)::value;
+        if constexpr ((Pp & 2) == 0) {
+            swap_pair<true>(re[Pp], re[Pp | 2]);
+            swap_pair<true>(im[Pp], im[Pp | 2]);
+        }
+    });
+    static_for<0, 16>([&](auto p) {  // round 2: lane bit 4 <-> register bit 0
+        constexpr int Pp = decltype(p)::value;
+        if constexpr ((Pp & 1) == 0) {
+            swap_pair<false>(re[Pp], re[Pp | 1]);
+            swap_pair<false>(im[Pp], im[Pp | 1]);
+        }
+    });
+}
+
+template <typename T, bool PRE_TW, bool TRANSPOSE>
+__global__ void __launch_bounds__(256) wave_fft_kernel(const TileArgs a, unsigned blocks_total) {
+    using Body = WaveBody<T, PRE_TW, TRANSPOSE>;
+    using cx = cx_t<T>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    cx *l_tw3 = reinterpret_cast<cx *>(smem);
+    cx *l_twr = l_tw3 + (PRE_TW ? (3u << a.tw_bits) : 0u);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    T *xp = reinterpret_cast<T *>(l_twr + 32) + (size_t)wave * 2 * Body::XP;
+
+    typename Body::Regs r;
+    Body::locate(a, blockIdx.x, blocks_total, (unsigned)wave, r);
+    const bool active = (blockIdx.x * Body::WAVES + (unsigned)wave) < a.tiles_total;
+    if (active) Body::load_raw(a, lane, r);  // the tile's loads fly while the tables are staged
+    for (int i = tid; i < 32; i += Body::NT) l_twr[i] = reinterpret_cast<const cx *>(a.twr)[i];
+    if constexpr (PRE_TW)
+        for (unsigned i = tid; i < (3u << a.tw_bits); i += Body::NT) l_tw3[i] = reinterpret_cast<const cx *>(a.tw3)[i];
+    __syncthreads();  // the only workgroup barrier: tables visible
+    if (!active) return;
+    Body::pre_twiddle(a, l_tw3, lane, r);
+    Body::step1(l_twr, lane, r);
+    wave_exchange<T>(r.re, r.im);
+    Body::step2(r);
+    if constexpr (TRANSPOSE) {
+        // wave-private transposition: this wave writes and then reads its own buffer; LDS operations of one wave
+        // execute in order, and the compiler's s_waitcnt lgkmcnt covers the data dependency -- no barrier
+        static_for<0, 16>([&](auto Q) {
+            xp[Body::template xp_write_addr<decltype(Q)::value>(lane)] = r.re[Q];
+            xp[Body::XP + Body::template xp_write_addr<decltype(Q)::value>(lane)] = r.im[Q];
+        });
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        static_for<0, 16>([&](auto Q) {
+            r.re[Q] = xp[Body::template xp_read_addr<decltype(Q)::value>(lane)];
+            r.im[Q] = xp[Body::XP + Body::template xp_read_addr<decltype(Q)::value>(lane)];
+        });
+        Body::store_runs(a, lane, r);
+    } else {
+        Body::store_rows(a, lane, r);
+    }
+}
+
+// host-side launcher
+template <typename T, bool PRE_TW, bool TRANSPOSE>
+hipError_t launch_wave_inst(hipStream_t stream, const TileArgs &a, bool query_only, int *blocks_per_cu, size_t *lds_out,
+                            hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
+    using Body = WaveBody<T, PRE_TW, TRANSPOSE>;
+    auto kern = wave_fft_kernel<T, PRE_TW, TRANSPOSE>;
+    const size_t lds = Body::lds_bytes(a.tw_bits);
+    if (lds_out) *lds_out = lds;
+    if (lds > (size_t)160 * 1024) {
+        if (query_only && blocks_per_cu) *blocks_per_cu = 0;
+        return query_only ? hipSuccess : hipErrorInvalidValue;
+    }
+    static size_t lds_limit = 0;
+    if (lds > lds_limit) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        lds_limit = lds;
+    }
+    if (query_only) {
+        if (blocks_per_cu) *blocks_per_cu = (int)((160 * 1024) / lds) < 4 ? (int)((160 * 1024) / lds) : 4;
+        return hipSuccess;
+    }
+    const unsigned blocks = (a.tiles_total + Body::WAVES - 1) / Body::WAVES;
+    if (ev_start && ev_stop)
+        hipExtLaunchKernelGGL(kern, dim3(blocks), dim3(Body::NT), (uint32_t)lds, stream, ev_start, ev_stop, 0, a, blocks);
+    else
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(Body::NT), lds, stream, a, blocks);
+    return hipGetLastError();
+}
+
+// Lane-by-lane host execution of one pass (tests/emu): the same phase functions, the swaps replaced by their definition
+//   new[lane (b5 b4)][register (p3 p2 s1 s0)] = old[lane (s1 s0)][register (p3 p2 b5 b4)]      (same column)
+template <typename T, bool PRE_TW, bool TRANSPOSE> void emulate_wave_pass(const TileArgs &a) {
+    using Body = WaveBody<T, PRE_TW, TRANSPOSE>;
+    using Regs = typename Body::Regs;
+    const unsigned blocks_total = (a.tiles_total + Body::WAVES - 1) / Body::WAVES;
+    std::vector<T> xp((size_t)2 * Body::XP + 1);
+    for (unsigned block = 0; block < blocks_total; ++block)
+        for (unsigned wave = 0; wave < (unsigned)Body::WAVES; ++wave) {
+            if (block * Body::WAVES + wave >= a.tiles_total) continue;
+            Regs regs[64], nxt[64];
+            for (int l = 0; l < 64; ++l) {
+                Body::locate(a, block, blocks_total, wave, regs[l]);
+                Body::load_raw(a, l, regs[l]);
+                Body::pre_twiddle(a, reinterpret_cast<const cx_t<T> *>(a.tw3), l, regs[l]);
+                Body::step1(reinterpret_cast<const cx_t<T> *>(a.twr), l, regs[l]);
+            }
+            for (int l = 0; l < 64; ++l) {
+                nxt[l] = regs[l];
+                const int col = l & 15, b = l >> 4;
+                for (int q = 0; q < 16; ++q) {
+                    const int src_lane = ((q & 3) << 4) | col, src_reg = (q & 12) | b;
+                    nxt[l].re[q] = regs[src_lane].re[src_reg];
+                    nxt[l].im[q] = regs[src_lane].im[src_reg];
+                }
+            }
+            for (int l = 0; l < 64; ++l) Body::step2(nxt[l]);
+            if constexpr (TRANSPOSE) {
+                for (int l = 0; l < 64; ++l)
+                    static_for<0, 16>([&](auto Q) {
+                        xp[Body::template xp_write_addr<decltype(Q)::value>(l)] = nxt[l].re[Q];
+                        xp[Body::XP + Body::template xp_write_addr<decltype(Q)::value>(l)] = nxt[l].im[Q];
+                    });
+                for (int l = 0; l < 64; ++l) {
+                    static_for<0, 16>([&](auto Q) {
+                        nxt[l].re[Q] = xp[Body::template xp_read_addr<decltype(Q)::value>(l)];
+                        nxt[l].im[Q] = xp[Body::XP + Body::template xp_read_addr<decltype(Q)::value>(l)];
+                    });
+                    Body::store_runs(a, l, nxt[l]);
+                }
+            } else {
+                for (int l = 0; l < 64; ++l) Body::store_rows(a, l, nxt[l]);
+            }
+        }
+}
+
+}  // namespace phast

@@ -9,10 +9,16 @@
 #include "plan.hpp"
 #include "row_fft.hpp"
 #include "tile_fft.hpp"
+#include "wave_fft.hpp"
 
 namespace phast {
 
 template <typename T> static bool emu_pass(const PassGeom &p, const TileArgs &a) {
+    if (p.wave) {
+        if (p.transpose) emulate_wave_pass<T, false, true>(a);
+        else emulate_wave_pass<T, true, false>(a);
+        return true;
+    }
 #define PHAST_EMU(LR_, LC_, LP_)                                                                   \
     if (p.lr == LR_ && p.lc == LC_ && p.lp == LP_) {                                                   \
         if (p.transpose)                                                                               \

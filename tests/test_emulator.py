@@ -32,7 +32,8 @@ def run(emu, re, im, direction=1, lrs=(), tile_log=12, points_log=4):
 # (log2 rows, log2 cols, log2 points per thread) -- PHAST_TILE_SHAPES of csrc/plan.hpp
 SHAPES = [(6, 6, 4), (7, 5, 4), (8, 4, 4), (9, 3, 4), (10, 2, 4), (7, 6, 4), (8, 5, 4), (9, 4, 4), (10, 3, 4), (8, 6, 4),
           (9, 5, 4), (10, 4, 4), (6, 6, 3), (7, 5, 3), (8, 4, 3), (9, 3, 3), (10, 2, 3),
-          (10, 4, 5), (9, 5, 5), (8, 6, 5), (10, 3, 5), (9, 4, 5), (8, 5, 5), (10, 2, 5), (11, 3, 5)]
+          (10, 4, 5), (9, 5, 5), (8, 6, 5), (10, 3, 5), (9, 4, 5), (8, 5, 5), (10, 2, 5), (11, 3, 5),
+          (6, 5, 3), (7, 4, 3), (8, 3, 3), (6, 4, 3), (7, 3, 3), (6, 5, 4), (7, 4, 4), (8, 3, 4), (6, 4, 4), (7, 3, 4), (7, 4, 5)]
 SHAPES_F32_ONLY = [(10, 5, 5), (9, 6, 5), (8, 7, 5), (11, 4, 5)]  # PHAST_TILE_SHAPES_F32: 32768-point tiles
 
 
@@ -56,7 +57,11 @@ PLANS = [(12, (6, 6), 12, 4), (13, (7, 6), 12, 4), (15, (8, 7), 12, 4), (16, (8,
          (20, (10, 10), 14, 5), (19, (10, 9), 14, 5), (18, (9, 9), 13, 5), (16, (8, 8), 13, 5), (20, (10, 10), 12, 5),
          (20, (10, 10), 13, 5),
          # a 2048-point tile FFT (32 x 32 x 2) as second or first pass
-         (21, (10, 11), 14, 5), (21, (11, 10), 14, 5)]
+         (21, (10, 11), 14, 5), (21, (11, 10), 14, 5),
+         # round 2: 1024- and 2048-point tiles (several workgroups per CU)
+         (18, (6, 6, 6), 10, 3), (18, (6, 6, 6), 10, 4), (20, (7, 7, 6), 11, 3), (20, (7, 6, 7), 11, 4), (21, (7, 7, 7), 11, 5),
+         # WAVE tiles (points code | 0x10: wave_fft.hpp, the cross-lane swaps emulated): all three passes
+         (18, (6, 6, 6), 10, 4 | 0x10)]
 
 
 @pytest.mark.parametrize("L,lrs,tl,lp", PLANS)
@@ -82,7 +87,9 @@ def test_default_plans_both_types_and_inverse(emu, oracle, L):
             re, im = oracle.fill(n, dtype, transform_id=7 * L + latency)
             a, b = re.copy(), im.copy()
             direction = -1 if latency else 1
-            assert run(emu, a, b, direction, tuple(lrs)[:npass], tl.value, lp.value) == 0
+            # lrs = () lets the emulator take the library's own heuristic plan (incl. per-pass tile sizes and wave
+            # tiles): tile_log 0 selects the latency plan, anything else the throughput plan
+            assert run(emu, a, b, direction, (), 0 if latency else 12, 0) == 0
             ofn(re, im, oracle.REVERSE if latency else oracle.FORWARD)
             err = np.sqrt(np.sum((a.astype(np.float64) - re) ** 2 + (b.astype(np.float64) - im) ** 2) /
                           np.sum(re.astype(np.float64) ** 2 + im.astype(np.float64) ** 2))

@@ -140,7 +140,12 @@ def test_inverse_matches_oracle(gpu, oracle):
 
 @pytest.mark.parametrize("plan", [((10, 10), 13, 4), ((7, 7, 6), 12, 4), ((9, 8, 3), 12, 4), ((10, 10), 14, 5),
                                   ((10, 10), 14, 4), ((10, 10), 13, 5), ((10, 10), 12, 5), ((6, 8, 6), 12, 3),
-                                  ((10, 10), 12, 3)])
+                                  ((10, 10), 12, 3),
+                                  # small tiles (several workgroups per CU) and WAVE tiles (points code | 0x10: every
+                                  # 64 x 16 tile is one wave, v_permlane swaps instead of LDS exchanges -- wave_fft.hpp)
+                                  ((7, 6, 7), (11, 10, 11), 3), ((6, 7, 7), (10, 11, 11), 4),
+                                  ((6, 8, 6), (10, 12, 10), 3 | 0x10), ((6, 8, 6), (10, 12, 10), 4 | 0x10),
+                                  ((7, 6, 7), (11, 10, 11), 3 | 0x10), ((6, 7, 7), (10, 11, 11), 4 | 0x10)])
 def test_forced_plans_agree_2p20(gpu, oracle, plan):
     n = 1 << 20
     lrs, tl, lp = plan
@@ -671,3 +676,39 @@ def test_one_transform_over_two_ranks_sharing_the_gpu(gpu, tmp_path):
     for r in range(2):
         err, back = (float(v) for v in open(tmp_path / f"err{r}.txt").read().split())
         assert err < 1e-14 and back < 1e-12, (r, err, back)
+
+
+def test_wave_tiles_all_passes_batched_inverse_and_interleaved(gpu, oracle):
+    """wave_fft.hpp (one wave per 64 x 16 tile, cross-lane swaps): N = 2^18 as three wave-tile passes -- first pass
+    (transposing through the wave-private buffer), pre-twiddle passes, batched with a ragged tile count per workgroup,
+    the inverse (1/N in the last store), and the interleaved first-pass load / last-pass store."""
+    import torch
+
+    n = 1 << 18
+    planner = gpu.PlannerDit64(n)
+    planner.set_plan((6, 6, 6), 10, 4 | 0x10)
+    assert planner.describe().count(" w16 ") == 3, planner.describe()
+    for batch in (1, 3):
+        re = torch.empty(batch * n, dtype=torch.float64, device="cuda")
+        im = torch.empty_like(re)
+        gpu.fill_uniform(re, im, n, seed=0x77, first_id=9)
+        gpu.fft_dit_batched(re, im, n, gpu.Direction.Forward, planner)
+        for b in range(batch):
+            r, m = oracle.fill(n, np.float64, seed=0x77, transform_id=9 + b)
+            oracle.fft_64_dit(r, m, oracle.FORWARD)
+            assert rel_l2(re[b * n:(b + 1) * n].cpu().numpy(), im[b * n:(b + 1) * n].cpu().numpy(), r, m) <= F64_REL
+        gpu.fft_dit_batched(re, im, n, gpu.Direction.Reverse, planner)
+        ref_re, ref_im = torch.empty_like(re), torch.empty_like(im)
+        gpu.fill_uniform(ref_re, ref_im, n, seed=0x77, first_id=9)
+        assert float((re - ref_re).abs().max()) < 1e-12 and float((im - ref_im).abs().max()) < 1e-12
+    r, m = oracle.fill(n, np.float64, seed=0x78, transform_id=1)
+    z = np.empty(n, np.complex128)
+    z.real, z.imag = r, m
+    d = torch.from_numpy(z.copy()).cuda()
+    gpu.fft_64_interleaved_with_planner(d, gpu.Direction.Forward, planner)
+    oracle.fft_64_dit(r, m, oracle.FORWARD)
+    h = d.cpu().numpy()
+    assert rel_l2(h.real.copy(), h.imag.copy(), r, m) <= F64_REL
+    # the default latency plans of 2^18 and 2^20 ARE wave-tile plans
+    assert " w16 " in gpu.PlannerDit64(1 << 20).describe().split("latency=")[1]
+    assert " w16 " in gpu.PlannerDit64(1 << 18).describe().split("latency=")[1]

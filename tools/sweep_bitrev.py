@@ -9,10 +9,10 @@ import torch  # noqa: E402
 import phastft_amd as P  # noqa: E402
 
 for dt, fn, sz in ((torch.float64, P.bit_rev_bravo_f64, 8), (torch.float32, P.bit_rev_bravo_f32, 4)):
-    for log_n in (20, 24, 26, 28, 30):
+    for log_n in (20, 24, 26, 28, 30) if len(sys.argv) < 2 else [int(a) for a in sys.argv[1:]]:
         n = 1 << log_n
         x = torch.arange(n, dtype=dt, device="cuda")
-        for variant in (0, 1, 2, 3, 4):
+        for variant in (0, 5, 6, 7, 8):
             os.environ["PHAST_BITREV_VARIANT"] = str(variant)
             fn(x, log_n)
             fn(x, log_n)
