@@ -118,6 +118,15 @@ int phast_fft_64_dit_dev(double *d_reals, double *d_imags, size_t n, size_t batc
                          const phast_planner_dit64 *planner, void *stream);
 int phast_fft_32_dit_dev(float *d_reals, float *d_imags, size_t n, size_t batch, size_t dist, int direction,
                          const phast_planner_dit32 *planner, void *stream);
+/* Strided batches (no reference counterpart): transform b occupies elements b*dist + j*stride, j < n.
+ * stride == 1 is the call above.  dist == 1 with stride, batch powers of two, batch <= stride, n >= 64 are the
+ * "column FFTs" of a row-major [n][stride] array (first `batch` columns), in place, natural order in and out -- what
+ * a four-step split (phastft_amd/distributed.py) and multi-dimensional transforms need.  The planner's scratch grows
+ * to n*stride elements per plane.  Anything else returns PHAST_ERR_INVALID_ARG. */
+int phast_fft_64_dit_strided_dev(double *d_reals, double *d_imags, size_t n, size_t batch, size_t dist, size_t stride,
+                                 int direction, const phast_planner_dit64 *planner, void *stream);
+int phast_fft_32_dit_strided_dev(float *d_reals, float *d_imags, size_t n, size_t batch, size_t dist, size_t stride,
+                                 int direction, const phast_planner_dit32 *planner, void *stream);
 
 /* ---- C2C on interleaved Complex<T> signals: lib.rs:41-140 (feature `complex-nums`) ----
  * `signal` holds n complex numbers as (re, im) pairs, transformed in place.  The reference copies into two planar

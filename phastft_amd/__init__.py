@@ -44,7 +44,7 @@ __all__ = [
     "r2c_fft_f64", "r2c_fft_f32", "r2c_fft_f64_with_planner", "r2c_fft_f32_with_planner",
     "c2r_fft_f64", "c2r_fft_f32", "c2r_fft_f64_with_planner", "c2r_fft_f32_with_planner",
     "c2r_fft_f64_with_planner_and_scratch", "c2r_fft_f32_with_planner_and_scratch",
-    "fft_64_interleaved", "fft_32_interleaved", "fft_64_interleaved_with_planner", "fft_32_interleaved_with_planner",
+    "fft_dit_strided", "fft_64_interleaved", "fft_32_interleaved", "fft_64_interleaved_with_planner", "fft_32_interleaved_with_planner",
     "fft_64_interleaved_with_planner_and_opts", "fft_32_interleaved_with_planner_and_opts",
     "bit_rev_bravo_f64", "bit_rev_bravo_f32", "fft_dit_batched", "r2c_fft_batched", "c2r_fft_batched", "fill_uniform", "digest", "device_info",
     "TwiddleGrid64", "TwiddleGrid32",
@@ -426,6 +426,23 @@ def fft_dit_batched(reals, imags, n: int, direction: Direction, planner, dist: i
     _check(getattr(_lib.lib(), f"phast_fft_{sfx}_dit_dev")(re.ptr, im.ptr, C.c_size_t(n), C.c_size_t(batch),
                                                            C.c_size_t(dist), C.c_int(int(direction)), planner._h,
                                                            _stream()))
+
+
+def fft_dit_strided(reals, imags, n: int, direction: Direction, planner, batch: int, stride: int) -> None:
+    """Device-resident "column FFTs": the tensors hold a row-major ``[n][stride]`` array whose first ``batch`` columns
+    are transformed along the rows' axis, in place (transform ``c`` = elements ``c + j*stride``).  ``stride`` and
+    ``batch`` powers of two, ``batch <= stride``, ``n >= 64``.  No reference counterpart."""
+    dtype, sfx = planner._dtype, planner._sfx
+    re, im = _Slice(reals, dtype, "reals"), _Slice(imags, dtype, "imags")
+    if not _same_place(re, im):
+        raise TypeError("fft_dit_strided needs device tensors")
+    if re.len != im.len:
+        _check(2)
+    if re.len < n * stride:
+        raise ValueError("the tensors must hold n*stride elements")
+    _check(getattr(_lib.lib(), f"phast_fft_{sfx}_dit_strided_dev")(re.ptr, im.ptr, C.c_size_t(n), C.c_size_t(batch),
+                                                                   C.c_size_t(1), C.c_size_t(stride),
+                                                                   C.c_int(int(direction)), planner._h, _stream()))
 
 
 def r2c_fft_batched(input_re, output_re, output_im, planner, batch: int) -> None:

@@ -178,6 +178,12 @@ template <typename T> struct Planner {
     // old one, and a hipDeviceSynchronize + hipFree in the middle of a launch sequence is a hidden device-wide sync
     // (and illegal under stream capture).  The predecessors are released with the planner.
     mutable std::vector<void *> retired_dev, retired_pin;
+    // plans of strided batches (column FFTs), built on first use per (log2 stride, log2 batch): see make_strided_passes
+    struct StridedPlan {
+        unsigned s = 0, sb = 0;
+        std::vector<PassDesc> passes;
+    };
+    mutable std::vector<StridedPlan> strided_plans;
 
     ~Planner() { release(); }
     // Host-slice calls up to this many staged bytes go through the pinned mirror (one memcpy each way on the host,
@@ -232,6 +238,8 @@ template <typename T> struct Planner {
         v.clear();
     }
     void release_passes() {
+        for (auto &sp : strided_plans) free_passes(sp.passes);
+        strided_plans.clear();
         free_passes(passes);
         free_passes(passes_lat);
         free_passes(passes_mid);
@@ -273,31 +281,9 @@ template <typename T> struct Planner {
         std::vector<PassDesc> ps(geo.size());
         for (size_t i = 0; i < geo.size(); ++i) static_cast<PassGeom &>(ps[i]) = geo[i];
         size_t tb = 0;
-        for (size_t i = 0; i < ps.size(); ++i) {
-            int rc = upload<T>(host_twr<T>(1u << ps[i].lr), &ps[i].d_twr);
-            if (rc == PHAST_OK && ps[i].pre_tw) {
-                rc = upload<T>(host_tw3<T>(ps[i].log_mod(), ps[i].tw_bits), &ps[i].d_tw3);
-                tb += ((size_t)3 << ps[i].tw_bits) * sizeof(cx_t<T>);
-            }
-            tb += 64 * sizeof(cx_t<T>);
-            if (rc == PHAST_OK) {
-                TileArgs ta{};
-                ta.tw_bits = ps[i].tw_bits;
-                hipError_t e = ps[i].wave ? launch_wave<T>(ps[i].transpose, nullptr, ta, true, &ps[i].blocks_per_cu, &ps[i].lds)
-                               : ps[i].transpose
-                                   ? Types<T>::launch_a(ps[i].lr, ps[i].lc, (int)ps[i].lp, 0, nullptr, ta, true, &ps[i].blocks_per_cu, &ps[i].lds)
-                                   : Types<T>::launch_bc(ps[i].lr, ps[i].lc, (int)ps[i].lp, 0, nullptr, ta, true, &ps[i].blocks_per_cu, &ps[i].lds);
-                if (e != hipSuccess) rc = hip_fail(e, "occupancy query");
-                if (ps[i].blocks_per_cu < 1) ps[i].blocks_per_cu = 1;
-                if (rc == PHAST_OK && ps[i].lds > 160 * 1024) rc = PHAST_ERR_INVALID_ARG;  // tile does not fit one CU's LDS
-            }
-            if (rc != PHAST_OK) {
-                for (auto &p : ps) {
-                    if (p.d_tw3) hipFree(p.d_tw3);
-                    if (p.d_twr) hipFree(p.d_twr);
-                }
-                return rc;
-            }
+        {
+            int rc = prepare_passes(ps, &tb);
+            if (rc) return rc;
         }
         // exec() reads the pass vectors while holding call_mu: take it, so a plan is never swapped under a launch
         // sequence; kernels already enqueued keep reading the old tables, which are therefore retired, not freed
@@ -360,8 +346,8 @@ template <typename T> struct Planner {
     }
 
     // scratch for `want` transforms in flight (capped by the target footprint, at least 1)
-    int ensure_scratch(size_t batch, size_t *cap_out) const {
-        if (passes.empty()) {
+    int ensure_scratch(size_t batch, size_t *cap_out, bool exact = false) const {
+        if (passes.empty() && !exact) {  // whole transforms on chip: no scratch (strided batches of such sizes need one)
             *cap_out = batch;
             return PHAST_OK;
         }
@@ -371,6 +357,7 @@ template <typename T> struct Planner {
         if (want < 1) want = 1;
         if (want < reserve) want = reserve;
         if (want > batch && batch >= reserve) want = batch;
+        if (exact && want < batch) want = batch;  // work that cannot be cut into chunks (strided batches)
         if (scratch_cap < want) {
             if (d_scratch) {
                 retired_dev.push_back(d_scratch);
@@ -387,6 +374,97 @@ template <typename T> struct Planner {
     }
 
     size_t device_bytes() const { return table_bytes + scratch_cap * 2 * n * sizeof(T); }
+
+    // tables + launch parameters of a pass list (shared by set_plan and the strided plans)
+    int prepare_passes(std::vector<PassDesc> &ps, size_t *table_bytes_out) const {
+        size_t tb = 0;
+        for (size_t i = 0; i < ps.size(); ++i) {
+            int rc = upload<T>(host_twr<T>(1u << ps[i].lr), &ps[i].d_twr);
+            if (rc == PHAST_OK && ps[i].pre_tw) {
+                rc = upload<T>(host_tw3<T>(ps[i].log_mod(), ps[i].tw_bits), &ps[i].d_tw3);
+                tb += ((size_t)3 << ps[i].tw_bits) * sizeof(cx_t<T>);
+            }
+            tb += 64 * sizeof(cx_t<T>);
+            if (rc == PHAST_OK) {
+                TileArgs ta{};
+                ta.tw_bits = ps[i].tw_bits;
+                hipError_t e = ps[i].wave ? launch_wave<T>(ps[i].transpose, nullptr, ta, true, &ps[i].blocks_per_cu, &ps[i].lds)
+                               : ps[i].transpose
+                                   ? Types<T>::launch_a(ps[i].lr, ps[i].lc, (int)ps[i].lp, 0, nullptr, ta, true, &ps[i].blocks_per_cu, &ps[i].lds)
+                                   : Types<T>::launch_bc(ps[i].lr, ps[i].lc, (int)ps[i].lp, 0, nullptr, ta, true, &ps[i].blocks_per_cu, &ps[i].lds);
+                if (e != hipSuccess) rc = hip_fail(e, "occupancy query");
+                if (ps[i].blocks_per_cu < 1) ps[i].blocks_per_cu = 1;
+                if (rc == PHAST_OK && ps[i].lds > 160 * 1024) rc = PHAST_ERR_INVALID_ARG;  // tile does not fit one CU's LDS
+            }
+            if (rc != PHAST_OK) {
+                for (auto &p : ps) {
+                    if (p.d_tw3) hipFree(p.d_tw3);
+                    if (p.d_twr) hipFree(p.d_twr);
+                    p.d_tw3 = p.d_twr = nullptr;
+                }
+                return rc;
+            }
+        }
+        if (table_bytes_out) *table_bytes_out = tb;
+        return PHAST_OK;
+    }
+
+    hipError_t launch_pass(const PassDesc &p, const TileArgs &ta, hipStream_t stream, hipEvent_t e0, hipEvent_t e1) const {
+        unsigned grid = (unsigned)(g_wg_per_cu_override > 0 ? g_wg_per_cu_override : p.blocks_per_cu) * (unsigned)g_cus;
+        if (grid > ta.tiles_total) grid = ta.tiles_total;
+        if (grid >= 8) grid &= ~7u;  // keep tile%8 == workgroup%8 (XCD affinity of the tile order)
+        return p.wave      ? launch_wave<T>(p.transpose, stream, ta, false, nullptr, nullptr, e0, e1)
+               : p.transpose ? Types<T>::launch_a(p.lr, p.lc, (int)p.lp, grid, stream, ta, false, nullptr, nullptr, e0, e1)
+                             : Types<T>::launch_bc(p.lr, p.lc, (int)p.lp, grid, stream, ta, false, nullptr, nullptr, e0, e1);
+    }
+
+    // Strided batch ("column FFTs"): 2^sb transforms, transform c at element c, points 2^s elements apart, in place in
+    // the caller's planes (forward arithmetic; `scale` on the last store).  make_strided_passes has the layouts.
+    int exec_strided(T *re, T *im, unsigned s_bits, unsigned sb_bits, double scale, hipStream_t stream) const {
+        std::lock_guard<std::recursive_mutex> call_lock(call_mu);
+        const StridedPlan *plan = nullptr;
+        for (const auto &sp : strided_plans)
+            if (sp.s == s_bits && sp.sb == sb_bits) plan = &sp;
+        if (!plan) {
+            std::vector<PassGeom> geo;
+            if (!make_strided_passes(log_n, s_bits, sb_bits, sizeof(T), geo)) return PHAST_ERR_INVALID_ARG;
+            StridedPlan sp;
+            sp.s = s_bits;
+            sp.sb = sb_bits;
+            sp.passes.resize(geo.size());
+            for (size_t i = 0; i < geo.size(); ++i) static_cast<PassGeom &>(sp.passes[i]) = geo[i];
+            int rc = prepare_passes(sp.passes, nullptr);
+            if (rc) return rc;
+            strided_plans.push_back(std::move(sp));
+            plan = &strided_plans.back();
+        }
+        // the whole [2^log_n][2^s] array is one unit of work: scratch for all of it (2^s "transforms" of n points)
+        const size_t cols = (size_t)1 << s_bits;
+        size_t cap = 0;
+        int rc = ensure_scratch(cols, &cap, true);
+        if (rc) return rc;
+        T *s_re = d_scratch, *s_im = d_scratch + cap * n;
+        const size_t np = plan->passes.size();
+        for (size_t i = 0; i < np; ++i) {
+            const PassDesc &p = plan->passes[i];
+            TileArgs ta{};
+            // x -> scratch -> x (-> x): every pass but the last moves the data (digits change places)
+            const bool from_x = (i % 2) == 0 || i + 1 == np && np == 3;
+            const bool to_x = (i % 2) == 1 || i + 1 == np;
+            ta.in_re = from_x ? re : s_re;
+            ta.in_im = from_x ? im : s_im;
+            ta.out_re = to_x ? re : s_re;
+            ta.out_im = to_x ? im : s_im;
+            ta.in_dist = ta.out_dist = 0;
+            ta.scale = i + 1 == np ? scale : 1.0;
+            ta.tw3 = p.d_tw3;
+            ta.twr = p.d_twr;
+            geom_to_args(p, log_n, 1, ta);
+            hipError_t e = launch_pass(p, ta, stream, nullptr, nullptr);
+            if (e != hipSuccess) return hip_fail(e, "tile_fft launch (strided)");
+        }
+        return PHAST_OK;
+    }
 
     std::string describe() const {
         char buf[512];
@@ -514,14 +592,9 @@ template <typename T> struct Planner {
                 ta.trace = g_trace ? g_trace + (size_t)i * 16 * 4096 : nullptr;
                 if (((unsigned long long)nb << (log_n - p.lr - p.lc)) > 0xffffffffull) return PHAST_ERR_INVALID_ARG;
                 geom_to_args(p, log_n, nb, ta);
-                unsigned grid = (unsigned)(g_wg_per_cu_override > 0 ? g_wg_per_cu_override : p.blocks_per_cu) * (unsigned)g_cus;
-                if (grid > ta.tiles_total) grid = ta.tiles_total;
-                if (grid >= 8) grid &= ~7u;  // keep tile%8 == workgroup%8 (XCD affinity of the tile order)
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (timer) PHAST_HIP(timer->pair((int)i, &e0, &e1));
-                hipError_t e = p.wave      ? launch_wave<T>(p.transpose, stream, ta, false, nullptr, nullptr, e0, e1)
-                               : p.transpose ? Types<T>::launch_a(p.lr, p.lc, (int)p.lp, grid, stream, ta, false, nullptr, nullptr, e0, e1)
-                                             : Types<T>::launch_bc(p.lr, p.lc, (int)p.lp, grid, stream, ta, false, nullptr, nullptr, e0, e1);
+                hipError_t e = launch_pass(p, ta, stream, e0, e1);
                 if (e != hipSuccess) return hip_fail(e, "tile_fft launch");
             }
         }
@@ -682,6 +755,25 @@ static int fft_dev(T *d_re, T *d_im, size_t n, size_t batch, size_t dist, int di
     if (batch > 1 && dist < n) return PHAST_ERR_INVALID_ARG;
     if (direction == PHAST_REVERSE) return pl->exec(d_im, d_re, dist, 0, d_im, d_re, dist, 0, batch, 1.0 / (double)n, s);
     return pl->exec(d_re, d_im, dist, 0, d_re, d_im, dist, 0, batch, 1.0, s);
+}
+
+// Strided batches on device pointers: transform b occupies elements b*dist + j*stride, j < n.
+//   stride == 1: contiguous transforms `dist` apart (the plain batched path above);
+//   dist == 1:   "column FFTs" of a row-major [n][stride] array -- stride and batch powers of two, batch <= stride,
+//                n >= 64 (what a four-step split and any multi-dimensional transform need; no reference counterpart,
+//                SURVEY.md section 8b suggested the signature).
+template <typename T>
+static int fft_strided_dev(T *d_re, T *d_im, size_t n, size_t batch, size_t dist, size_t stride, int direction,
+                           const Planner<T> *pl, hipStream_t s) {
+    if (stride == 1) return fft_dev<T>(d_re, d_im, n, batch, dist, direction, pl, s);
+    if (!pl || !d_re || !d_im) return PHAST_ERR_INVALID_ARG;
+    if (direction != PHAST_FORWARD && direction != PHAST_REVERSE) return PHAST_ERR_INVALID_ARG;
+    if (!is_pow2(n)) return PHAST_ERR_NOT_POW2;
+    if (ilog2(n) != pl->log_n) return PHAST_ERR_PLANNER_SIZE;
+    if (dist != 1 || !is_pow2(stride) || !is_pow2(batch) || batch > stride) return PHAST_ERR_INVALID_ARG;
+    const unsigned sb = ilog2(stride), bb = ilog2(batch);
+    if (direction == PHAST_REVERSE) return pl->exec_strided(d_im, d_re, sb, bb, 1.0 / (double)n, s);
+    return pl->exec_strided(d_re, d_im, sb, bb, 1.0, s);
 }
 
 // average kernel duration of every pass over `reps` forward transforms of the same buffers
@@ -1114,6 +1206,11 @@ PHAST_PLANNER_API(32, float)
     int phast_fft_##SFX##_dit_dev(T *d_re, T *d_im, size_t n, size_t batch, size_t dist, int direction,             \
                                   const phast_planner_dit##SFX *pl, void *stream) {                                 \
         return fft_dev<T>(d_re, d_im, n, batch, dist, direction, pl, static_cast<hipStream_t>(stream));             \
+    }                                                                                                               \
+    int phast_fft_##SFX##_dit_strided_dev(T *d_re, T *d_im, size_t n, size_t batch, size_t dist, size_t stride,     \
+                                          int direction, const phast_planner_dit##SFX *pl, void *stream) {          \
+        return fft_strided_dev<T>(d_re, d_im, n, batch, dist, stride, direction, pl,                                \
+                                  static_cast<hipStream_t>(stream));                                                \
     }                                                                                                               \
     int phast_fft_##SFX##_interleaved(T *signal, size_t n, int direction) {                                         \
         Planner<T> *pl = nullptr;                                                                                   \

@@ -93,6 +93,14 @@ struct TileArgs {
     unsigned in_interleaved;   // 1: input is one array of (re, im) pairs (R2C deinterleave fused into the load); 2: read as (im, re)
     unsigned out_interleaved;  // 1: output is one array of (re, im) pairs (C2R interleave fused into the store);
                                // 2: pairs stored as (im, re) -- the swap-trick inverse (algorithms/dit.rs:297-300)
+    // pre-twiddle exponent multiplier of column g:  lo = (g >> tw_shift) & tw_mask  (contiguous transforms: shift 0,
+    // mask 2^log_s_in - 1; strided batches carry the batch index in the low bits of g, which takes no part)
+    unsigned tw_shift;
+    unsigned tw_mask;
+    // column of tile t (strided batches that fill only 2^cb_bits * COLS of the 2^cs_bits columns of a row; 0 = all):
+    //   g0 = ((t >> cb_bits) << cs_bits) | ((t & (2^cb_bits - 1)) << LC)
+    unsigned cs_bits;
+    unsigned cb_bits;
     double scale;              // 1/N on the last pass of an inverse transform, else 1
     unsigned long long *trace; // tools/trace_tile.py only: [workgroup][16] s_memtime stamps of the first tile's phases
 };

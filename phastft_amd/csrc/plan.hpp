@@ -122,7 +122,10 @@ struct PassGeom {
     bool pre_tw = false, transpose = false;
     unsigned log_s_in = 0, out_lo_bits = 0, tw_bits = 1;
     unsigned long long out_s1 = 0, out_s2 = 0, out_row_stride = 0;
-    unsigned log_mod() const { return lr + log_s_in; }  // the inter-pass twiddle is W_{2^log_mod}^{row*lo}
+    // strided batches (make_strided_passes): see TileArgs; tw_log_mod = log2 of the twiddle modulus when it is not lr + log_s_in
+    unsigned tw_shift = 0, tw_mask_bits = 0, cs_bits = 0, cb_bits = 0, tw_log_mod = 0;
+    bool strided = false;
+    unsigned log_mod() const { return strided ? tw_log_mod : lr + log_s_in; }  // the inter-pass twiddle is W_{2^log_mod}^{row*lo}
 };
 
 // Default factorisations of L = log2 N (L > kSmallMaxLog), from the exhaustive MI355X sweeps in profiles/
@@ -279,8 +282,82 @@ inline void geom_to_args(const PassGeom &p, unsigned log_n, size_t n_xforms, Til
     ta.log_s_in = p.log_s_in;
     ta.out_lo_bits = p.out_lo_bits;
     ta.tw_bits = p.tw_bits;
+    if (p.strided) {  // ONE array of 2^log_n rows x 2^cs_bits columns, of which 2^cb_bits * COLS columns are transforms
+        ta.tw_shift = p.tw_shift;
+        ta.tw_mask = p.tw_mask_bits >= 32 ? 0xffffffffu : ((1u << p.tw_mask_bits) - 1u);
+        ta.cs_bits = p.cs_bits;
+        ta.cb_bits = p.cb_bits;
+        ta.tiles_per_xform = 1u << (log_n - p.lr + p.cb_bits);
+        ta.tiles_total = ta.tiles_per_xform;
+        return;
+    }
+    ta.tw_shift = 0;
+    ta.tw_mask = p.log_s_in >= 32 ? 0xffffffffu : ((1u << p.log_s_in) - 1u);
+    ta.cs_bits = ta.cb_bits = 0;
     ta.tiles_per_xform = 1u << (log_n - p.lr - p.lc);
     ta.tiles_total = (unsigned)((size_t)ta.tiles_per_xform * n_xforms);
+}
+
+// ---- strided batches: 2^sb transforms of 2^L points, transform c at element c, its points 2^s elements apart ----
+// (a matrix [2^L][2^s] whose first 2^sb columns are transformed along the rows' axis: "column FFTs").  The batch
+// index c is the contiguous dimension everywhere, so NO pass needs the transposing store: with the digits of the
+// transform index n = (p, r, u) high to low,
+//     x[p][r][u][c] --0: FFT over p--> T1[r][u][kp][c] --1: x W_{2^(a+b)}^(r kp), FFT over r--> T2[u][kb][kp][c]
+//                   --2: x W_N^(u (kp + 2^a kb)), FFT over u--> X[kc][kb][kp][c]      (natural order, k = kp + 2^a kb + ..)
+// every pass reads rows with the full lower part as its (contiguous) column space and writes rows of >= COLS
+// contiguous elements.  Pass 0 runs through the same pre-twiddle kernels with tw_mask = 0 (multiplier 0: W^0 = 1
+// exactly).  Passes are NOT in place except the last: x -> scratch -> x (-> x).
+inline unsigned pick_lp(unsigned lr, unsigned lc, size_t elem_bytes) {
+    for (unsigned lp : {4u, 5u, 3u})
+        if (lp <= lr && shape_exists(lr, lc, lp, elem_bytes)) return lp;
+    return 0;
+}
+inline bool make_strided_passes(unsigned L, unsigned s, unsigned sb, size_t elem_bytes, std::vector<PassGeom> &ps) {
+    if (L < 6 || sb > s || L + s > 31) return false;  // tile FFTs are 64..1024 points; 32-bit element offsets
+    unsigned np = (L + 9) / 10;                        // rows <= 1024 per pass
+    if (np > 3) return false;
+    unsigned want_lc = elem_bytes == 8 ? 4u : 5u;      // 128-byte rows
+    if (L == 11) {  // 6 + 5 has no 32-point tile FFT: one pass of 2048-point tile FFTs on 8 columns (the (11, 3) shape)
+        np = 1;
+        want_lc = 3;
+    }
+    std::vector<unsigned> lrs;
+    for (unsigned i = 0; i < np; ++i) lrs.push_back(L / np + (i < L % np ? 1 : 0));
+    for (unsigned lr : lrs)
+        if (lr < 6) return false;
+    const unsigned lc = sb < want_lc ? sb : want_lc;
+    ps.assign(np, PassGeom());
+    unsigned done = 0;  // log2 of the digits already transformed (they sit below the remaining ones, above c)
+    for (unsigned i = 0; i < np; ++i) {
+        PassGeom &g = ps[i];
+        g.lr = lrs[i];
+        g.lc = lc;
+        g.lp = pick_lp(g.lr, g.lc, elem_bytes);
+        if (!g.lp) return false;
+        g.strided = true;
+        g.pre_tw = true;  // pass 0 too: multiplier 0
+        g.transpose = false;
+        g.log_s_in = L - lrs[i] + s;  // rows of this pass are the TOP digit of what is left
+        g.cs_bits = sb < s ? s : 0;   // all columns used: plain tile numbering
+        g.cb_bits = sb - lc;
+        const bool last = i + 1 == np;
+        g.out_row_stride = 1ull << (done + s);  // the new digit k_i goes right above the digits already done
+        if (last) {
+            g.out_lo_bits = done + s;  // all columns are low digits already in place
+            g.out_s1 = 1;
+            g.out_s2 = 1ull << (L + s);  // never used: g < 2^out_lo_bits
+        } else {
+            g.out_lo_bits = done + s;          // (done digits, c) stay, the untransformed digits move up by lr bits
+            g.out_s1 = 1;
+            g.out_s2 = 1ull << (done + s + lrs[i]);
+        }
+        g.tw_shift = s;
+        g.tw_mask_bits = i == 0 ? 0 : done;  // lo = the digits already done (kp, kb..), not the untransformed ones
+        g.tw_log_mod = done + lrs[i];        // W_{2^(done + lr)}^(row * lo)
+        g.tw_bits = tw3_bits_for(i == 0 ? 3 : g.tw_log_mod);
+        done += lrs[i];
+    }
+    return true;
 }
 
 }  // namespace phast

@@ -172,7 +172,8 @@ template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool 
     PHAST_HD static void locate(const TileArgs &a, unsigned t, Regs &r) {
         const unsigned tile = ((a.tiles_total & 7u) == 0u) ? (t & 7u) * (a.tiles_total >> 3) + (t >> 3) : t;
         r.xform = tile / a.tiles_per_xform;
-        r.g0 = (tile - r.xform * a.tiles_per_xform) << LC;
+        const unsigned ti = tile - r.xform * a.tiles_per_xform;
+        r.g0 = a.cs_bits ? (((ti >> a.cb_bits) << a.cs_bits) | ((ti & ((1u << a.cb_bits) - 1u)) << LC)) : (ti << LC);
     }
 
     // ---------------- load rows n = j*M + tau, j = 0..P-1 ----------------
@@ -214,8 +215,7 @@ template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool 
     PHAST_HD static void pre_twiddle(const TileArgs &a, const Shared &sh, int tid, Regs &r) {
         if constexpr (PRE_TW) {
             const int col = col_of(tid), tau = tau_of(tid);
-            const unsigned lo0 = r.g0 & ((1u << a.log_s_in) - 1u);
-            const unsigned lo = lo0 + (unsigned)col;
+            const unsigned lo = ((r.g0 + (unsigned)col) >> a.tw_shift) & a.tw_mask;
             const unsigned e0 = (unsigned)tau * lo, de = (unsigned)M * lo;  // exponent of row j*M + tau: e0 + j*de
             static_for<0, P>([&](auto j) {
                 T wr, wi;

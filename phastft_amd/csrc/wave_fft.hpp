@@ -55,7 +55,8 @@ template <typename T, bool PRE_TW, bool TRANSPOSE> struct WaveBody {
         const unsigned b = ((blocks_total & 7u) == 0u) ? (block & 7u) * (blocks_total >> 3) + (block >> 3) : block;
         const unsigned tile = b * WAVES + wave;
         r.xform = tile / a.tiles_per_xform;
-        r.g0 = (tile - r.xform * a.tiles_per_xform) << LC;
+        const unsigned ti = tile - r.xform * a.tiles_per_xform;
+        r.g0 = a.cs_bits ? (((ti >> a.cb_bits) << a.cs_bits) | ((ti & ((1u << a.cb_bits) - 1u)) << LC)) : (ti << LC);
     }
 
     // rows n = 4 j + tau: one VGPR offset for all 16 loads, the row part is wave-uniform
@@ -93,7 +94,7 @@ template <typename T, bool PRE_TW, bool TRANSPOSE> struct WaveBody {
     // products, ~1.3e-16 each) is far inside the 1e-13 budget (measured rel-L2 unchanged, tests/test_gpu_parity.py)
     PHAST_HD static void pre_twiddle(const TileArgs &a, const cx *tw3, int lane, Regs &r) {
         if constexpr (PRE_TW) {
-            const unsigned lo = (r.g0 & ((1u << a.log_s_in) - 1u)) + (unsigned)col_of(lane);
+            const unsigned lo = ((r.g0 + (unsigned)col_of(lane)) >> a.tw_shift) & a.tw_mask;
             T br, bi, dr, di;
             tw3_lookup<T>(tw3, a.tw_bits, (unsigned)tau_of(lane) * lo, br, bi);
             tw3_lookup<T>(tw3, a.tw_bits, (unsigned)TAUS * lo, dr, di);

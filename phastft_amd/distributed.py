@@ -5,13 +5,17 @@ that: a single power-of-two transform of N points whose planar (reals, imags) ar
 slabs, rank r holding ``x[r*N/P : (r+1)*N/P]`` -- natural order in, natural order out, the same contract as
 ``fft_64_dit`` (lib.rs:180), forward unnormalised and reverse scaled by 1/N (algorithms/dit.rs:297-331).
 
-Four-step split ``N = N1*N2`` (``n = n1*N2 + n2``, ``k = k1 + N1*k2``):
+Four-step split ``N = N1*N2`` (``n = n1*N2 + n2``, ``k = k1 + N1*k2``), every array row-major:
 
-    slab [n1 (mine)][n2]  --all-to-all-->  [n1][n2 (mine)]
-        FFT over n1 (local, batched)  ->  [k1][n2 (mine)],  times W_N^(n2*k1)   (TwiddleGrid, twiddle.hip)
-    --all-to-all-->  [k1 (mine)][n2]
-        FFT over n2 (local, batched)  ->  [k1 (mine)][k2]
-    --all-to-all-->  [k2 (mine)][k1]  =  X[k] in natural order, slab of rank ``k2 block``
+    slab [n1 (mine)][n2]  --pack, all-to-all-->  [n1][n2 (mine)]
+        COLUMN FFTs over n1 (strided batch, in place)  ->  [k1][n2 (mine)],  times W_N^(k1*n2)   (TwiddleGrid, twiddle.hip)
+    --all-to-all (row blocks are contiguous: no pack), unpack-->  [n2][k1 (mine)]
+        COLUMN FFTs over n2  ->  [k2][k1 (mine)]
+    --all-to-all (contiguous row blocks), unpack-->  [k2 (mine)][k1]  =  X[k] in natural order, slab of rank ``k2 block``
+
+The local transforms are strided batches ("column FFTs", ``phast_fft_*_dit_strided_dev``): they run on the layout an
+exchange delivers, so each exchange costs ONE local permutation (the pack or the unpack a block-distributed global
+transpose cannot avoid) instead of a pack plus a transpose -- three sweeps per plane where round 1 made six.
 
 Three exchanges because both ends are block-distributed in natural order: the first stage of any Cooley-Tukey
 split combines the HIGH index bits, which are exactly the bits the block distribution spreads over the ranks.
@@ -41,29 +45,26 @@ def split_factors(log_n: int, world: int) -> tuple[int, int]:
 class DistributedFft:
     """`n`-point planar transform over the ranks of a process group; every rank calls :meth:`run` with its slab.
 
-    ``local_fft(re, im, length, count)`` transforms `count` contiguous length-`length` transforms in place
-    (forward); ``twiddle(re, im, rows, cols, row0)`` multiplies the row-major block by W_n^((row0+r)*c).
-    Both act on 1-D tensors of the process group's device type.
+    ``column_fft(re, im, length, count)`` transforms the `count` columns of the row-major ``[length][count]`` array in
+    place (forward); ``twiddle(re, im, rows, cols, col0)`` multiplies element (r, c) of the row-major block by
+    W_n^(r*(col0+c)).  Both act on 1-D tensors of the process group's device type.
     """
 
-    def __init__(self, n: int, rank: int, world: int, local_fft: Callable, twiddle: Callable, dist=None):
+    def __init__(self, n: int, rank: int, world: int, column_fft: Callable, twiddle: Callable, dist=None):
         if n <= 0 or n & (n - 1):
             raise ValueError("assertion failed: num_points > 0 && num_points.is_power_of_two()")  # planner.rs:66
         self.n, self.rank, self.world, self.dist = n, rank, world, dist
         self.n1, self.n2 = split_factors(n.bit_length() - 1, world)
-        self._fft, self._twiddle = local_fft, twiddle
+        self._fft, self._twiddle = column_fft, twiddle
         if world > 1 and dist is None:
             raise ValueError("more than one rank needs a torch.distributed process group")
 
-    # -- one exchange: `x` viewed as [rows_local][world][cols/world]; rank q receives every rank's q-th column
-    #    block; returns [rows_local * world][cols / world] (row index = source rank major) --
-    def _exchange(self, x, rows_local: int, cols: int):
+    def _all_to_all(self, send):
+        """rank q receives every rank's q-th equal chunk of `send`; returns the chunks in source-rank order"""
         import torch
 
-        w = self.world
-        if w == 1:
-            return x
-        send = x.view(rows_local, w, cols // w).permute(1, 0, 2).contiguous().view(-1)
+        if self.world == 1:
+            return send
         recv = torch.empty_like(send)
         if self.dist.get_backend() == "gloo" and send.is_cuda:  # dry run on one GPU: through host memory
             r = torch.empty(send.shape, dtype=send.dtype)
@@ -73,10 +74,6 @@ class DistributedFft:
             self.dist.all_to_all_single(recv, send)
         return recv
 
-    @staticmethod
-    def _transpose(x, rows: int, cols: int):
-        return x.view(rows, cols).t().contiguous().view(-1)
-
     def run(self, reals, imags, reverse: bool = False):
         """In place on the rank's slab (1-D tensors of n/world elements)."""
         w, n1, n2 = self.world, self.n1, self.n2
@@ -84,19 +81,28 @@ class DistributedFft:
             raise ValueError("assertion `left == right` failed: reals.len() == imags.len()")  # dit.rs:284
         re, im = (imags, reals) if reverse else (reals, imags)  # the swap trick, algorithms/dit.rs:297-300
         r1, c2 = n1 // w, n2 // w
-        # [n1 mine][n2] -> [n1][n2 mine] -> [n2 mine][n1]; FFT over n1; twiddle W_N^(n2*k1)
-        a_re = self._transpose(self._exchange(re, r1, n2), n1, c2)
-        a_im = self._transpose(self._exchange(im, r1, n2), n1, c2)
+
+        def pack(x):       # [n1 mine][n2] -> [dest q][n1 mine][n2 in q's block]: the send order of exchange 1
+            return x.view(r1, w, c2).permute(1, 0, 2).contiguous().view(-1) if w > 1 else x
+
+        def unpack2(x):    # received [src s][k1 mine][n2 in s's block] -> [n2][k1 mine]
+            return x.view(w, r1, c2).permute(0, 2, 1).contiguous().view(-1)
+
+        def unpack3(x):    # received [src s][k2 mine][k1 in s's block] -> [k2 mine][k1]
+            return x.view(w, c2, r1).permute(1, 0, 2).contiguous().view(-1) if w > 1 else x
+
+        # exchange 1 -> [n1][n2 mine] (source-major = natural n1 order): column FFTs over n1, then W_N^(k1 * n2)
+        a_re, a_im = self._all_to_all(pack(re)), self._all_to_all(pack(im))
+        if w == 1:
+            a_re, a_im = a_re.clone(), a_im.clone()
         self._fft(a_re, a_im, n1, c2)
-        self._twiddle(a_re, a_im, c2, n1, self.rank * c2)
-        # [n2 mine][k1] -> [n2][k1 mine] -> [k1 mine][n2]; FFT over n2
-        b_re = self._transpose(self._exchange(a_re, c2, n1), n2, r1)
-        b_im = self._transpose(self._exchange(a_im, c2, n1), n2, r1)
+        self._twiddle(a_re, a_im, n1, c2, self.rank * c2)
+        # exchange 2: the block for rank q is the rows k1 of q's range -- contiguous as it stands
+        b_re, b_im = unpack2(self._all_to_all(a_re)), unpack2(self._all_to_all(a_im))
         del a_re, a_im
-        self._fft(b_re, b_im, n2, r1)
-        # [k1 mine][k2] -> [k1][k2 mine] -> [k2 mine][k1] = natural order
-        c_re = self._transpose(self._exchange(b_re, r1, n2), n1, c2)
-        c_im = self._transpose(self._exchange(b_im, r1, n2), n1, c2)
+        self._fft(b_re, b_im, n2, r1)                     # -> [k2][k1 mine]
+        # exchange 3: rows k2 of q's range, contiguous; unpack to natural order
+        c_re, c_im = unpack3(self._all_to_all(b_re)), unpack3(self._all_to_all(b_im))
         del b_re, b_im
         if reverse:
             scale = 1.0 / self.n  # algorithms/dit.rs:325-331
@@ -107,7 +113,7 @@ class DistributedFft:
 
 
 def gpu_transform(n: int, rank: int, world: int, dist=None, dtype: str = "f64") -> DistributedFft:
-    """The GPU instance: local stages = the library's batched kernels and the TwiddleGrid kernel."""
+    """The GPU instance: local stages = the library's strided-batch kernels and the TwiddleGrid kernel."""
     import phastft_amd as P
 
     f64 = dtype == "f64"
@@ -115,12 +121,21 @@ def gpu_transform(n: int, rank: int, world: int, dist=None, dtype: str = "f64") 
     planners = {m: (P.PlannerDit64 if f64 else P.PlannerDit32)(m) for m in {n1, n2}}
     grid = (P.TwiddleGrid64 if f64 else P.TwiddleGrid32)(n)
 
-    def local_fft(re, im, length, count):
-        P.fft_dit_batched(re, im, length, P.Direction.Forward, planners[length])
+    def column_fft(re, im, length, count):
+        try:
+            P.fft_dit_strided(re, im, length, P.Direction.Forward, planners[length], batch=count, stride=count)
+        except P.PhastPanic:
+            # shapes the strided kernels do not cover (fewer than 64 points, or too few columns for a tile row):
+            # transpose, contiguous batch, transpose back
+            t_re = re.view(length, count).t().contiguous().view(-1)
+            t_im = im.view(length, count).t().contiguous().view(-1)
+            P.fft_dit_batched(t_re, t_im, length, P.Direction.Forward, planners[length])
+            re.copy_(t_re.view(count, length).t().contiguous().view(-1))
+            im.copy_(t_im.view(count, length).t().contiguous().view(-1))
 
-    def twiddle(re, im, rows, cols, row0):
-        grid.apply(re, im, rows, cols, row0=row0)
+    def twiddle(re, im, rows, cols, col0):
+        grid.apply(re, im, rows, cols, row0=0, col0=col0)
 
-    t = DistributedFft(n, rank, world, local_fft, twiddle, dist)
+    t = DistributedFft(n, rank, world, column_fft, twiddle, dist)
     t._keep = (planners, grid)
     return t

@@ -286,6 +286,33 @@ int phast_emu_audit_small(int is_f64, unsigned log_n, int *max_read_ways, int *m
 }
 
 // the default plan of the library for (type, log_n): fills lrs[3], returns the number of passes
+// strided batch (column FFTs of a row-major [2^log_n][2^s] array, first 2^sb columns), in place, forward
+int phast_emu_fft_strided_f64(double *re, double *im, unsigned log_n, unsigned s, unsigned sb) {
+    using namespace phast;
+    std::vector<PassGeom> ps;
+    if (!make_strided_passes(log_n, s, sb, sizeof(double), ps)) return 1;
+    const size_t total = (size_t)1 << (log_n + s);
+    std::vector<double> t_re(total), t_im(total);
+    for (size_t i = 0; i < ps.size(); ++i) {
+        const PassGeom &p = ps[i];
+        std::vector<cx_t<double>> twr = host_twr<double>(1u << p.lr), tw3 = host_tw3<double>(p.log_mod(), p.tw_bits);
+        TileArgs ta{};
+        const size_t np = ps.size();
+        const bool from_x = (i % 2) == 0 || (i + 1 == np && np == 3);
+        const bool to_x = (i % 2) == 1 || i + 1 == np;
+        ta.in_re = from_x ? re : t_re.data();
+        ta.in_im = from_x ? im : t_im.data();
+        ta.out_re = to_x ? re : t_re.data();
+        ta.out_im = to_x ? im : t_im.data();
+        ta.scale = 1.0;
+        ta.tw3 = tw3.data();
+        ta.twr = twr.data();
+        geom_to_args(p, log_n, 1, ta);
+        if (!emu_pass<double>(p, ta)) return 2;
+    }
+    return 0;
+}
+
 int phast_emu_default_plan(int is_f64, int latency, unsigned log_n, unsigned *lrs, unsigned *tile_log,
                            unsigned *points_log) {
     std::vector<unsigned> v, tl;

@@ -95,14 +95,16 @@ def _dist_fft_worker(rank, world, port, log_n, reverse, out_dir):
 
     n = 1 << log_n
 
-    def local_fft(re, im, length, count):  # the oracle stands in for the batched HIP kernels
-        r, m = re.numpy(), im.numpy()
-        for b in range(count):
-            O.fft_64_dit(r[b * length:(b + 1) * length], m[b * length:(b + 1) * length], O.FORWARD)
+    def column_fft(re, im, length, count):  # the oracle stands in for the strided-batch HIP kernels
+        r, m = re.numpy().reshape(length, count), im.numpy().reshape(length, count)
+        for c in range(count):
+            x, y = np.ascontiguousarray(r[:, c]), np.ascontiguousarray(m[:, c])
+            O.fft_64_dit(x, y, O.FORWARD)
+            r[:, c], m[:, c] = x, y
 
-    def twiddle(re, im, rows, cols, row0):
-        r = torch.arange(row0, row0 + rows, dtype=torch.int64).view(rows, 1)
-        c = torch.arange(cols, dtype=torch.int64).view(1, cols)
+    def twiddle(re, im, rows, cols, col0):
+        r = torch.arange(rows, dtype=torch.int64).view(rows, 1)
+        c = torch.arange(col0, col0 + cols, dtype=torch.int64).view(1, cols)
         ang = ((r * c) % n).to(torch.float64) * (-2.0 * np.pi / n)
         wr, wi = torch.cos(ang).view(-1), torch.sin(ang).view(-1)
         x, y = re.clone(), im.clone()
@@ -112,7 +114,7 @@ def _dist_fft_worker(rank, world, port, log_n, reverse, out_dir):
     full_re, full_im = O.fill(n, np.float64, seed=0xD157, transform_id=log_n)
     lo, hi = rank * n // world, (rank + 1) * n // world
     re, im = torch.from_numpy(full_re[lo:hi].copy()), torch.from_numpy(full_im[lo:hi].copy())
-    DistributedFft(n, rank, world, local_fft, twiddle, dist).run(re, im, reverse=reverse)
+    DistributedFft(n, rank, world, column_fft, twiddle, dist).run(re, im, reverse=reverse)
     np.save(os.path.join(out_dir, f"re{rank}.npy"), re.numpy())
     np.save(os.path.join(out_dir, f"im{rank}.npy"), im.numpy())
     dist.barrier()

@@ -239,3 +239,22 @@ def test_small_real_transforms_fused_untangle_and_preprocess(emu, oracle, log_ha
         got = np.zeros(n, dtype)
         assert emu.phast_emu_small_real(is_f64, 2, p(rr), p(ri), p(got), None, log_half, 1, half + 1, n) == 0
         assert np.max(np.abs(got - want)) < (1e-12 if is_f64 else 2e-5)
+
+
+@pytest.mark.parametrize("L,s,sb", [(6, 4, 4), (8, 5, 5), (11, 4, 4), (12, 6, 5), (12, 5, 4), (16, 4, 4), (21, 4, 4)])
+def test_strided_batch_geometry_vs_oracle(emu, oracle, L, s, sb):
+    """Strided batches (plan.hpp: make_strided_passes -- column FFTs of a row-major [2^L][2^s] array, first 2^sb
+    columns): one, two and three passes, none of them transposing, the batch index as the contiguous dimension; every
+    transformed column against the oracle, every other column untouched."""
+    n, stride, batch = 1 << L, 1 << s, 1 << sb
+    rng = np.random.default_rng(L * 10 + s)
+    re, im = rng.uniform(-1, 1, n * stride), rng.uniform(-1, 1, n * stride)
+    a, b = re.copy(), im.copy()
+    assert emu.phast_emu_fft_strided_f64(a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), L, s, sb) == 0
+    A, B, R, I = (x.reshape(n, stride) for x in (a, b, re, im))
+    for c in sorted({0, 1, batch // 2, batch - 1}):
+        r, m = np.ascontiguousarray(R[:, c]), np.ascontiguousarray(I[:, c])
+        oracle.fft_64_dit(r, m, oracle.FORWARD)
+        assert np.sqrt(np.sum((A[:, c] - r) ** 2 + (B[:, c] - m) ** 2) / np.sum(r ** 2 + m ** 2)) <= 1e-13, c
+    if batch < stride:
+        assert np.array_equal(A[:, batch:], R[:, batch:]) and np.array_equal(B[:, batch:], I[:, batch:])

@@ -265,3 +265,49 @@ def test_one_transform_over_two_ranks_vs_oracle(gpu, tmp_path):
     for r in range(2):
         err = float(open(tmp_path / f"oerr{r}.txt").read())
         assert err < F64_REL, (r, err)
+
+
+# ---------------------------------------------------------------- strided batches ("column FFTs"), SURVEY 8b
+@pytest.mark.parametrize("k,s,sb,dt", [(6, 4, 4, "f64"), (8, 5, 5, "f64"), (10, 4, 4, "f64"), (11, 4, 4, "f64"),
+                                       (12, 6, 5, "f64"), (16, 4, 4, "f64"), (21, 4, 4, "f64"), (10, 5, 5, "f32"),
+                                       (14, 6, 6, "f32"), (20, 5, 5, "f32")])
+def test_strided_batch_vs_oracle(gpu, oracle, k, s, sb, dt):
+    """phast_fft_*_dit_strided_dev: the first 2^sb columns of a row-major [2^k][2^s] array transformed along the rows'
+    axis, in place; every other column untouched; forward against the oracle column by column, then the inverse."""
+    import torch
+
+    n, stride, batch = 1 << k, 1 << s, 1 << sb
+    ndt, tdt, tol = (np.float64, torch.float64, F64_REL) if dt == "f64" else (np.float32, torch.float32, F32_REL)
+    rng = np.random.default_rng(k * 100 + s)
+    h_re = rng.uniform(-1, 1, n * stride).astype(ndt)
+    h_im = rng.uniform(-1, 1, n * stride).astype(ndt)
+    planner = (gpu.PlannerDit64 if dt == "f64" else gpu.PlannerDit32)(n)
+    d_re, d_im = dev(h_re.copy()), dev(h_im.copy())
+    gpu.fft_dit_strided(d_re, d_im, n, gpu.Direction.Forward, planner, batch=batch, stride=stride)
+    g_re, g_im = d_re.cpu().numpy().reshape(n, stride), d_im.cpu().numpy().reshape(n, stride)
+    r2, i2 = h_re.reshape(n, stride), h_im.reshape(n, stride)
+    ofn = oracle.fft_64_dit if dt == "f64" else oracle.fft_32_dit
+    for c in sorted({0, 1, batch // 2, batch - 1}):
+        r, m = np.ascontiguousarray(r2[:, c]), np.ascontiguousarray(i2[:, c])
+        ofn(r, m, oracle.FORWARD)
+        assert rel_l2(g_re[:, c], g_im[:, c], r, m) <= tol, (k, s, sb, c)
+    if batch < stride:
+        assert np.array_equal(g_re[:, batch:], r2[:, batch:]) and np.array_equal(g_im[:, batch:], i2[:, batch:])
+    gpu.fft_dit_strided(d_re, d_im, n, gpu.Direction.Reverse, planner, batch=batch, stride=stride)
+    lim = 1e-12 if dt == "f64" else 2e-5
+    assert float((d_re - dev(h_re)).abs().max()) < lim and float((d_im - dev(h_im)).abs().max()) < lim
+
+
+def test_strided_batch_rejects_what_it_cannot_do(gpu):
+    import torch
+
+    x = torch.zeros(64 * 16, dtype=torch.float64, device="cuda")
+    y = torch.zeros_like(x)
+    p = gpu.PlannerDit64(32)
+    with pytest.raises(gpu.PhastPanic):    # fewer than 64 points
+        gpu.fft_dit_strided(x, y, 32, gpu.Direction.Forward, p, batch=16, stride=16)
+    p = gpu.PlannerDit64(64)
+    with pytest.raises(gpu.PhastPanic):    # stride not a power of two
+        gpu.fft_dit_strided(x, y, 64, gpu.Direction.Forward, p, batch=4, stride=12)
+    with pytest.raises(gpu.PhastPanic):    # batch larger than the stride
+        gpu.fft_dit_strided(x, y, 64, gpu.Direction.Forward, p, batch=32, stride=16)
