@@ -136,14 +136,20 @@ def plan_kind(P, n: int, batch: int, plan_text: str) -> str:
 
 
 def kernel_tags(plan_list: str, dtype: str = "double"):
-    """'<double, LR, LC, LP,' template-argument prefixes of the pass kernels of a plan -- used to check that a
-    committed PMC profile belongs to the plan that ran."""
+    """Substrings of the pass kernels' names of a plan, in launch order -- used to check that a committed PMC profile
+    belongs to the plan that ran: 'tile_fft_kernel<double, LR, LC, LP, PRE_TW, TRANSPOSE,' for LDS tiles,
+    'wave_fft_kernel<double, PRE_TW, TRANSPOSE>' for wave tiles."""
     import math
     import re
 
     tags = []
-    for rows, cols, pts in re.findall(r"\[(\d+)x(\d+)A? [pw](\d+)", plan_list):
-        tags.append(f"<{dtype}, {int(math.log2(int(rows)))}, {int(math.log2(int(cols)))}, {int(math.log2(int(pts)))},")
+    for i, (rows, cols, kind, pts) in enumerate(re.findall(r"\[(\d+)x(\d+)A? ([pw])(\d+)", plan_list)):
+        flags = "false, true" if i == 0 else "true, false"
+        if kind == "w":
+            tags.append(f"wave_fft_kernel<{dtype}, {flags}>")
+        else:
+            tags.append(f"tile_fft_kernel<{dtype}, {int(math.log2(int(rows)))}, {int(math.log2(int(cols)))}, "
+                        f"{int(math.log2(int(pts)))}, {flags},")
     return tags
 
 
@@ -560,9 +566,8 @@ def load_profiled_traffic(n_gpus, dom, n_passes, tags):
     # the profile may hold other kernels too: pick, pass by pass, the entries of THIS plan (first / later passes differ
     # in the PRE_TW, TRANSPOSE flags that follow the shape in the kernel's name)
     picked = []
-    for i, tag in enumerate(tags):
-        flags = " false, true," if i == 0 else " true, false,"
-        hits = [k for k in ks if tag + flags in k["kernel"]]
+    for tag in tags:
+        hits = [k for k in ks if tag in k["kernel"]]
         if len(hits) != 1:
             return None  # the profile was taken with another plan
         picked.append(hits[0])

@@ -1,24 +1,41 @@
 #!/bin/bash
-# Runs on the GPU box (gpurun): rocprofv3 kernel statistics and HBM-traffic counters of the headline bench,
-# summarised into gpurun_out/profiles_new/ (copy what should be judged into profiles/).
+# Runs on the GPU box (gpurun): rocprofv3 kernel statistics, HBM-traffic counters (FETCH_SIZE / WRITE_SIZE in separate
+# passes) and SQ counters of the bench workloads, summarised into gpurun_out/profiles_new/ (copy what should be
+# judged into profiles/).  Counter passes use --kernel-trace only (never the hip/hsa trace domains).
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/profiles_new
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-TAG=${1:-r01}
-CMD="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-graph --no-scaling-reference"
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python $R/bench.py --no-cpu-baseline --no-scaling-reference > $O/${TAG}_bench_single2p20_under_rocprofv3.json 2> /tmp/prof_stats.err
-python $R/tools/summarize_prof.py stats /tmp/prof_stats $O/${TAG}_bench_single2p20_kernel_stats.csv > /dev/null
-timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/prof_fetch -- $CMD > /dev/null 2> /tmp/prof_fetch.err
-timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/prof_write -- $CMD > /dev/null 2> /tmp/prof_write.err
-python $R/tools/summarize_prof.py pmc /tmp/prof_fetch /tmp/prof_write $O/${TAG}_pmc_hbm_traffic_single2p20.txt $O/traffic_latest.json single_2p20 \
-    "python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-graph --no-scaling-reference" | tail -5
-# the other workloads (batch shard, 2^26, R2C, bit reversal): kernel statistics only
-for w in batch big r2c bitrev; do
+TAG=${1:-r02}
+SQ="SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM"
+# 1. the driver's command under the profiler: per-kernel statistics of everything on the default line
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python $R/bench.py --no-cpu-baseline > $O/${TAG}_bench_default_under_rocprofv3.json 2> /tmp/prof_stats.err
+python $R/tools/summarize_prof.py stats /tmp/prof_stats $O/${TAG}_bench_default_kernel_stats.csv > /dev/null
+# 2. HBM traffic: headline (single 2^20), N = 2^26, R2C f32 2^24
+pmc() {  # key, algorithmic bytes, out name, command...
+    local key=$1 alg=$2 name=$3; shift 3
+    rm -rf /tmp/prof_fetch /tmp/prof_write
+    timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/prof_fetch -- "$@" > /dev/null 2> /tmp/prof_fetch.err
+    timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/prof_write -- "$@" > /dev/null 2> /tmp/prof_write.err
+    python $R/tools/summarize_prof.py pmc /tmp/prof_fetch /tmp/prof_write $O/${TAG}_pmc_hbm_traffic_${name}.txt $O/traffic_latest.json $key "${*/$R\//}" $alg | tail -4
+}
+pmc single_2p20 33554432 single2p20 python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-graph --no-scaling-reference --no-configs
+pmc single_2p26 2147483648 single2p26 python $R/tools/prof_workloads.py big --iters 4
+pmc r2c_f32_2p24 134217728 r2c_f32_2p24 python $R/tools/prof_workloads.py r2c --iters 10
+pmc batch_2p20 8589934592 batch256_2p20 python $R/tools/prof_workloads.py batch --batch 256 --iters 3
+# 3. where the wave cycles go (SQ counters, one pass of 8)
+for w in single big; do
+    rm -rf /tmp/prof_sq
+    timeout 300 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d /tmp/prof_sq -- python $R/tools/prof_workloads.py $w --iters 5 > /dev/null 2> /tmp/prof_sq.err
+    python $R/tools/summarize_sq.py /tmp/prof_sq $O/${TAG}_sq_${w}.txt "python tools/prof_workloads.py $w --iters 5"
+done
+# 4. kernel statistics of the other workloads
+for w in batch bitrev; do
     rm -rf /tmp/prof_wl
     timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_wl -- python $R/tools/prof_workloads.py $w > $O/${TAG}_${w}.log 2> /tmp/prof_wl.err
     python $R/tools/summarize_prof.py stats /tmp/prof_wl $O/${TAG}_${w}_kernel_stats.csv > /dev/null
 done
-cd $R && timeout 300 python bench.py --extra > $O/${TAG}_bench_single2p20_plain_extra.json 2> $O/bench_extra.err
-head -c 600 $O/${TAG}_bench_single2p20_kernel_stats.csv
+# 5. the plain (un-profiled) default line, for comparison with the profiled one
+cd $R && timeout 600 python bench.py > $O/${TAG}_bench_default_plain.json 2> $O/bench_plain.err
+head -c 1500 $O/${TAG}_bench_default_kernel_stats.csv

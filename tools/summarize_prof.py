@@ -29,7 +29,8 @@ def counter(d, name):
     per = OrderedDict()
     with open(find(d, "*counter_collection.csv")) as f:
         for row in csv.DictReader(f):
-            if row.get("Counter_Name") != name or "tile_fft_kernel" not in row.get("Kernel_Name", ""):
+            kn = row.get("Kernel_Name", "")
+            if row.get("Counter_Name") != name or not any(t in kn for t in ("tile_fft_kernel", "wave_fft_kernel", "untangle_kernel")):
                 continue
             per.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
     return per
