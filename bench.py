@@ -143,10 +143,12 @@ def kernel_tags(plan_list: str, dtype: str = "double"):
     import re
 
     tags = []
-    for i, (rows, cols, kind, pts) in enumerate(re.findall(r"\[(\d+)x(\d+)A? ([pw])(\d+)", plan_list)):
+    for i, (rows, cols, kind, pts) in enumerate(re.findall(r"\[(\d+)x(\d+)A? ([pwq])(\d+)", plan_list)):
         flags = "false, true" if i == 0 else "true, false"
         if kind == "w":
             tags.append(f"wave_fft_kernel<{dtype}, {flags}>")
+        elif kind == "q":
+            tags.append(f"quad_fft_kernel<{dtype}>")
         else:
             tags.append(f"tile_fft_kernel<{dtype}, {int(math.log2(int(rows)))}, {int(math.log2(int(cols)))}, "
                         f"{int(math.log2(int(pts)))}, {flags},")

@@ -112,6 +112,11 @@ template <typename T> static hipError_t launch_wave(bool transpose, hipStream_t 
     if constexpr (sizeof(T) == 8) return launch_wave_f64(transpose, s, a, q, b, l, e0, e1);
     else return hipErrorInvalidValue;  // wave tiles exist for f64 only (make_passes never asks for them in f32)
 }
+template <typename T> static hipError_t launch_quad(unsigned grid, hipStream_t s, const TileArgs &a, bool q, int *b, size_t *l,
+                                                    hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
+    if constexpr (sizeof(T) == 8) return launch_quad_f64(grid, s, a, q, b, l, e0, e1);
+    else return hipErrorInvalidValue;
+}
 template <> struct Types<float> {
     static hipError_t launch_a(int lr, int lc, int lp, unsigned g, hipStream_t s, const TileArgs &a, bool q, int *b,
                                size_t *l, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
@@ -379,7 +384,7 @@ template <typename T> struct Planner {
     int prepare_passes(std::vector<PassDesc> &ps, size_t *table_bytes_out) const {
         size_t tb = 0;
         for (size_t i = 0; i < ps.size(); ++i) {
-            int rc = upload<T>(host_twr<T>(1u << ps[i].lr), &ps[i].d_twr);
+            int rc = ps[i].quad ? upload<T>(host_twq<T>(), &ps[i].d_twr) : upload<T>(host_twr<T>(1u << ps[i].lr), &ps[i].d_twr);
             if (rc == PHAST_OK && ps[i].pre_tw) {
                 rc = upload<T>(host_tw3<T>(ps[i].log_mod(), ps[i].tw_bits), &ps[i].d_tw3);
                 tb += ((size_t)3 << ps[i].tw_bits) * sizeof(cx_t<T>);
@@ -389,6 +394,7 @@ template <typename T> struct Planner {
                 TileArgs ta{};
                 ta.tw_bits = ps[i].tw_bits;
                 hipError_t e = ps[i].wave ? launch_wave<T>(ps[i].transpose, nullptr, ta, true, &ps[i].blocks_per_cu, &ps[i].lds)
+                               : ps[i].quad ? launch_quad<T>(0, nullptr, ta, true, &ps[i].blocks_per_cu, &ps[i].lds)
                                : ps[i].transpose
                                    ? Types<T>::launch_a(ps[i].lr, ps[i].lc, (int)ps[i].lp, 0, nullptr, ta, true, &ps[i].blocks_per_cu, &ps[i].lds)
                                    : Types<T>::launch_bc(ps[i].lr, ps[i].lc, (int)ps[i].lp, 0, nullptr, ta, true, &ps[i].blocks_per_cu, &ps[i].lds);
@@ -414,6 +420,7 @@ template <typename T> struct Planner {
         if (grid > ta.tiles_total) grid = ta.tiles_total;
         if (grid >= 8) grid &= ~7u;  // keep tile%8 == workgroup%8 (XCD affinity of the tile order)
         return p.wave      ? launch_wave<T>(p.transpose, stream, ta, false, nullptr, nullptr, e0, e1)
+               : p.quad    ? launch_quad<T>(grid, stream, ta, false, nullptr, nullptr, e0, e1)
                : p.transpose ? Types<T>::launch_a(p.lr, p.lc, (int)p.lp, grid, stream, ta, false, nullptr, nullptr, e0, e1)
                              : Types<T>::launch_bc(p.lr, p.lc, (int)p.lp, grid, stream, ta, false, nullptr, nullptr, e0, e1);
     }
@@ -477,7 +484,7 @@ template <typename T> struct Planner {
             s += std::string(" ") + tag + "=" + std::to_string(v.size()) + "p";
             for (auto &p : v) {
                 std::snprintf(buf, sizeof buf, "[%ux%u%s %s%u lds=%zu wg/cu=%d]", 1u << p.lr, 1u << p.lc,
-                              p.transpose ? "A" : "", p.wave ? "w" : "p", 1u << p.lp, p.lds, p.blocks_per_cu);
+                              p.transpose ? "A" : "", p.wave ? "w" : p.quad ? "q" : "p", 1u << p.lp, p.lds, p.blocks_per_cu);
                 s += buf;
             }
         };

@@ -85,6 +85,16 @@ template <typename T> inline std::vector<cx_t<T>> host_twr(unsigned rows) {
     return h;
 }
 
+// step-twiddle table of the four-wave 256-row kernel (quad_fft.hpp): W_256^j, j < 64, then W_64^j, j < 64
+template <typename T> inline std::vector<cx_t<T>> host_twq() {
+    std::vector<cx_t<T>> h(128);
+    for (unsigned j = 0; j < 64; ++j) {
+        h[j] = twiddle_t<T>(j, 256);
+        h[64 + j] = twiddle_t<T>(j, 64);
+    }
+    return h;
+}
+
 // ---- tile shapes that exist as kernels: log2(rows), log2(cols) ----
 // log2(rows), log2(cols), log2(points per thread).  16 points per thread: 4096-, 8192- and 16384-point tiles
 // (256 / 512 / 1024 threads); 8 points per thread: 4096-point tiles with 512 threads (latency plans); 32 points
@@ -119,6 +129,7 @@ struct PassGeom {
     unsigned lr = 0, lc = 0;
     unsigned lp = 4;  // log2(points per thread): 4 = throughput tiles, 3 = latency tiles (twice the waves)
     bool wave = false;  // one wave per 64 x 16 tile, exchange by cross-lane swaps (wave_fft.hpp; f64 only)
+    bool quad = false;  // four waves per 256 x 16 tile, one LDS + one cross-lane exchange (quad_fft.hpp; f64, later passes)
     bool pre_tw = false, transpose = false;
     unsigned log_s_in = 0, out_lo_bits = 0, tw_bits = 1;
     unsigned long long out_s1 = 0, out_s2 = 0, out_row_stride = 0;
@@ -149,12 +160,18 @@ inline void heuristic_plan(unsigned L, bool latency, std::vector<unsigned> &lrs,
         for (unsigned i = 0; i < np; ++i) lrs.push_back(L / np + (i < L % np ? 1 : 0));  // balanced, larger first
     };
     const bool f64 = sizeof(T) == 8;
-    if (latency && f64 && (L == 20 || L == 18)) {
-        // round 2: the 64-row passes as WAVE tiles (one wave per 64 x 16 tile, swaps instead of LDS exchanges and
-        // barriers: wave_fft.hpp) around the 256-row LDS pass -- profiles/r02_sweep_wave_tiles.log
-        lrs = L == 20 ? std::vector<unsigned>{6, 8, 6} : std::vector<unsigned>{6, 6, 6};
-        tls = L == 20 ? std::vector<unsigned>{10, 12, 10} : std::vector<unsigned>{10, 10, 10};
-        lp = 3 | kWaveTiles;
+    if (latency && f64 && L >= 19 && L <= 23) {
+        // round 2 (profiles/r02_sweep_wave_quad_single.log): one f64 transform of 2^19..2^23 points as three passes built
+        // from WAVE tiles (64 x 16, one wave, cross-lane swaps: wave_fft.hpp) and the four-wave 256 x 16 kernel
+        // (quad_fft.hpp), generic LDS tiles for the 128-row passes and 256-row first passes:
+        //   2^19 22.9 us (two 1024/512-row passes: 27.4), 2^20 26.5 (27.4 .. 29.7), 2^21 42.3 (43.5), 2^22 82.1 (98.7),
+        //   2^23 182.7 (188.4)
+        static const unsigned plans[5][7] = {
+            {6, 7, 6, 10, 11, 10, 3}, {6, 8, 6, 10, 12, 10, 3}, {8, 7, 6, 12, 12, 10, 3}, {8, 8, 6, 13, 12, 10, 4}, {8, 7, 8, 12, 12, 12, 3}};
+        const unsigned *p = plans[L - 19];
+        lrs = {p[0], p[1], p[2]};
+        tls = {p[3], p[4], p[5]};
+        lp = p[6] | kWaveTiles;
         return;
     }
     if (latency) {
@@ -226,7 +243,8 @@ inline bool make_passes(unsigned L, const std::vector<unsigned> &lrs, const std:
     if (tile_logs.size() != 1 && tile_logs.size() != lrs.size()) return false;
     ps.assign(lrs.size(), PassGeom());
     const unsigned a = lrs[0], b = lrs[1], c = lrs.size() == 3 ? lrs[2] : 0;
-    // lp & 0x10 (kWaveTiles): every pass whose tile is 64 rows x 16 columns runs as wave tiles (f64 only);
+    // lp & 0x10 (kWaveTiles): every pass whose tile is 64 rows x 16 columns runs as wave tiles, every later pass with
+    // 256 x 16 tiles as the four-wave kernel (f64 only);
     // lp & 0xf = log2(points per thread) of the other passes
     const bool want_wave = (lp & kWaveTiles) != 0 && elem_bytes == 8;
     lp &= 0xfu;
@@ -236,8 +254,9 @@ inline bool make_passes(unsigned L, const std::vector<unsigned> &lrs, const std:
         ps[i].lr = lrs[i];
         ps[i].lc = tl - lrs[i];
         ps[i].wave = want_wave && lrs[i] == 6 && tl == 10;
-        ps[i].lp = ps[i].wave ? 4 : lp;
-        if (!ps[i].wave && !shape_exists(lrs[i], tl - lrs[i], lp, elem_bytes)) return false;
+        ps[i].quad = want_wave && lrs[i] == 8 && tl == 12 && i > 0;
+        ps[i].lp = (ps[i].wave || ps[i].quad) ? 4 : lp;
+        if (!ps[i].wave && !ps[i].quad && !shape_exists(lrs[i], tl - lrs[i], lp, elem_bytes)) return false;
     }
     ps[0].transpose = true;  // FFT over the top `a` index bits; every column leaves as one contiguous run
     ps[0].log_s_in = L - a;

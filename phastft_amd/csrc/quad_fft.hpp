@@ -1,0 +1,325 @@
+// quad_fft.hpp -- a 256-row pass of the multi-pass FFT on FOUR waves: 256 rows x 16 columns (f64: 128-byte rows) per
+// 256-thread workgroup, 16 points per lane, radix 4 x 4 x 4 x 4 with ONE LDS exchange (between the waves) and one
+// cross-lane exchange (v_permlane32/16_swap, as wave_fft.hpp) -- where the generic tile kernel (tile_fft.hpp, shape
+// 256 x 16 at 8 points per thread) takes three radix steps with two LDS exchanges of four barriers.  This is the middle
+// pass of the single 2^20-point f64 transform (BASELINE configs[1]: plan 64 . 256 . 64), the one kernel of that plan the
+// copy-floor microbenchmark (profiles/r02_pass_floor_686_patterns.log) showed 2 us above its access pattern's floor.
+//
+//   lane = (col = lane & 15, tau = lane >> 4), wave w;   row n = 64 n_hi + 16 jj + 4 w + tau,   register q = 4 n_hi + jj
+//   0. inter-pass twiddle W_{256 S}^(n lo) = W^((4 w + tau) lo) (W^(16 lo))^q        two table look-ups + a power ladder
+//   1. radix-4 over n_hi (registers, stride 4)      -> k_a = bitrev2(s) at register jj + 4 s;   x W_256^(n_lo k_a)
+//   2. radix-4 over jj   (registers, contiguous)    -> k_b = bitrev2(t) at register 4 s + t;    x W_64^((4 w + tau) k_b)
+//   3. LDS exchange [register][wave][lane]: wave w' collects t = w' from all four waves  -> register 4 s + ws
+//      radix-4 over ws = w                          -> k_c = bitrev2(u) at register 4 s + u;    x W_16^(tau k_c)
+//   4. cross-lane exchange: lane bits (5, 4) <-> register bits (3, 2)                    -> register 4 tt + u (tt = tau)
+//      radix-4 over tt (registers, stride 4)        -> k_d = bitrev2(v) at register u + 4 v
+//   output row k = k_a + 4 k_b + 16 k_c + 64 k_d with k_a = bitrev2(tau'), k_b = bitrev2(w') from the lane and wave
+// Phase functions are __host__ __device__ per lane (tests/emu emulates both exchanges).
+#pragma once
+
+#include <vector>
+
+#include "tile_fft.hpp"
+#include "wave_fft.hpp"
+
+namespace phast {
+
+// radix-R DIF on registers OFF, OFF + STRIDE, ...: afterwards position OFF + STRIDE p holds X[bitrev(p)]
+template <typename T, int R, int OFF, int STRIDE, int P> PHAST_HD void fft_reg_dif_s(T (&re)[P], T (&im)[P]) {
+    static_for<0, ilog2_c(R)>([&](auto st) {
+        constexpr int SPAN = R >> (decltype(st)::value + 1);
+        static_for<0, R / 2>([&](auto bi) {
+            constexpr int B = decltype(bi)::value;
+            constexpr int J = B % SPAN;
+            constexpr int I0 = OFF + STRIDE * ((B / SPAN) * 2 * SPAN + J);
+            constexpr int I1 = I0 + STRIDE * SPAN;
+            T ar = re[I0], ai = im[I0], br = re[I1], bi_ = im[I1];
+            re[I0] = ar + br;
+            im[I0] = ai + bi_;
+            T dr = ar - br, di = ai - bi_;
+            mul_w<T, 2 * SPAN, J>(dr, di);
+            re[I1] = dr;
+            im[I1] = di;
+        });
+    });
+}
+
+template <typename T> struct QuadBody {
+    using cx = cx_t<T>;
+    static constexpr int LR = 8, LC = 4, ROWS = 256, COLS = 16, P = 16, WAVES = 4, NT = 256;
+    static constexpr int EXCH = P * NT;  // elements per plane of the exchange buffer [register][wave][lane]
+    static constexpr int TWQ = 128;      // staged entries of the step-twiddle table: W_256^j (j < 64), then W_64^j (j < 64)
+    static constexpr bool NT_HINT = COLS * sizeof(T) >= 128;
+
+    struct Regs {
+        T re[P], im[P];
+        unsigned xform, g0;
+    };
+
+    static size_t lds_bytes(unsigned tw_bits) {
+        return (size_t)(3u << tw_bits) * sizeof(cx) + TWQ * sizeof(cx) + (size_t)2 * EXCH * sizeof(T);
+    }
+
+    PHAST_HD static int col_of(int lane) { return lane & 15; }
+    PHAST_HD static int tau_of(int lane) { return lane >> 4; }
+
+    PHAST_HD static void locate(const TileArgs &a, unsigned t, Regs &r) {  // as TileBody::locate
+        const unsigned tile = ((a.tiles_total & 7u) == 0u) ? (t & 7u) * (a.tiles_total >> 3) + (t >> 3) : t;
+        r.xform = tile / a.tiles_per_xform;
+        const unsigned ti = tile - r.xform * a.tiles_per_xform;
+        r.g0 = a.cs_bits ? (((ti >> a.cb_bits) << a.cs_bits) | ((ti & ((1u << a.cb_bits) - 1u)) << LC)) : (ti << LC);
+    }
+
+    // row of register q: 64 (q >> 2) + 16 (q & 3) + 4 w + tau
+    PHAST_HD static void load_raw(const TileArgs &a, int wave, int lane, Regs &r) {
+        const unsigned lo0 = r.g0 & ((1u << a.log_s_in) - 1u);
+        const size_t ubase = (size_t)r.xform * a.in_dist + (((size_t)(r.g0 >> a.log_s_in) << (a.log_s_in + LR)) | lo0);
+        const unsigned voff = ((unsigned)(4 * wave + tau_of(lane)) << a.log_s_in) + (unsigned)col_of(lane);
+        const T *pr = reinterpret_cast<const T *>(a.in_re) + ubase;
+        const T *pi = reinterpret_cast<const T *>(a.in_im) + ubase;
+        static_for<0, P>([&](auto q) {
+            constexpr int Q = decltype(q)::value;
+            const size_t urow = (size_t)(64 * (Q >> 2) + 16 * (Q & 3)) << a.log_s_in;
+            if constexpr (NT_HINT) {
+                r.re[Q] = __builtin_nontemporal_load(pr + urow + voff);
+                r.im[Q] = __builtin_nontemporal_load(pi + urow + voff);
+            } else {
+                r.re[Q] = (pr + urow)[voff];
+                r.im[Q] = (pi + urow)[voff];
+            }
+        });
+    }
+
+    // W^(n lo), n = (4 w + tau) + 16 (jj + 4 n_hi): base W^((4w+tau) lo) times the power (jj + 4 n_hi) of D = W^(16 lo)
+    PHAST_HD static void pre_twiddle(const TileArgs &a, const cx *tw3, int wave, int lane, Regs &r) {
+        const unsigned lo = ((r.g0 + (unsigned)col_of(lane)) >> a.tw_shift) & a.tw_mask;
+        T br, bi, dr, di;
+        tw3_lookup<T>(tw3, a.tw_bits, (unsigned)(4 * wave + tau_of(lane)) * lo, br, bi);
+        tw3_lookup<T>(tw3, a.tw_bits, 16u * lo, dr, di);
+        T pr[P], pi[P];
+        pr[0] = (T)1;
+        pi[0] = (T)0;
+        pr[1] = dr;
+        pi[1] = di;
+        static_for<2, P>([&](auto j) {
+            constexpr int J = decltype(j)::value, H = J / 2, G = J - H;
+            pr[J] = pr[H] * pr[G] - pi[H] * pi[G];
+            pi[J] = pr[H] * pi[G] + pi[H] * pr[G];
+        });
+        static_for<0, P>([&](auto q) {
+            constexpr int Q = decltype(q)::value, E = (Q & 3) + 4 * (Q >> 2);  // jj + 4 n_hi
+            const T wr = br * pr[E] - bi * pi[E], wi = br * pi[E] + bi * pr[E];
+            cmul(r.re[Q], r.im[Q], wr, wi);
+        });
+    }
+
+    // steps 1 and 2 (both in registers) with their twiddles; twq = [W_256^j | W_64^j], j < 64 each
+    PHAST_HD static void steps12(const cx *twq, int wave, int lane, Regs &r) {
+        const unsigned m = (unsigned)(4 * wave + tau_of(lane));  // the part of n_lo that lives in (wave, lane)
+        static_for<0, 4>([&](auto jj) { fft_reg_dif_s<T, 4, decltype(jj)::value, 4, P>(r.re, r.im); });
+        static_for<1, 4>([&](auto s) {  // k_a = bitrev2(s) != 0: x W_256^((16 jj + m) k_a) = W_16^(jj k_a) W_256^(m k_a)
+            constexpr int KA = bitrev_c(decltype(s)::value, 2);
+            const cx w = twq[m * KA];
+            static_for<0, 4>([&](auto jj) {
+                constexpr int Q = decltype(jj)::value + 4 * decltype(s)::value;
+                cmul(r.re[Q], r.im[Q], w.x, w.y);
+                constexpr int J = decltype(jj)::value * KA;  // W_16^J, J <= 9: W_16^(J) = -W_16^(J - 8) beyond the half turn
+                mul_w<T, 16, J % 8>(r.re[Q], r.im[Q]);
+                if constexpr (J >= 8) {
+                    r.re[Q] = -r.re[Q];
+                    r.im[Q] = -r.im[Q];
+                }
+            });
+        });
+        static_for<0, 4>([&](auto s) { fft_reg_dif<T, 4, 4 * decltype(s)::value, P>(r.re, r.im); });
+        static_for<1, 4>([&](auto t) {  // k_b = bitrev2(t): x W_64^(m k_b)
+            constexpr int KB = bitrev_c(decltype(t)::value, 2);
+            const cx w = twq[64 + m * KB];
+            static_for<0, 4>([&](auto s) {
+                constexpr int Q = 4 * decltype(s)::value + decltype(t)::value;
+                cmul(r.re[Q], r.im[Q], w.x, w.y);
+            });
+        });
+    }
+    // exchange addresses: writer (register Q, wave, lane); reader wave w' takes t = w', slot 4 s + ws <- (Q = 4 s + w', ws)
+    template <int Q> PHAST_HD static int waddr(int wave, int lane) { return (Q * WAVES + wave) * 64 + lane; }
+    template <int Q> PHAST_HD static int raddr(int wave, int lane) {
+        constexpr int S = Q >> 2, WS = Q & 3;
+        return ((4 * S + wave) * WAVES + WS) * 64 + lane;
+    }
+    // step 3 (radix-4 over the source wave) and its twiddle W_16^(tau k_c) = W_64^(4 tau k_c)
+    PHAST_HD static void step3(const cx *twq, int lane, Regs &r) {
+        static_for<0, 4>([&](auto s) { fft_reg_dif<T, 4, 4 * decltype(s)::value, P>(r.re, r.im); });
+        const unsigned tau = (unsigned)tau_of(lane);
+        static_for<1, 4>([&](auto u) {
+            constexpr int KC = bitrev_c(decltype(u)::value, 2);
+            const cx w = twq[64 + 4 * tau * KC];
+            static_for<0, 4>([&](auto s) {
+                constexpr int Q = 4 * decltype(s)::value + decltype(u)::value;
+                cmul(r.re[Q], r.im[Q], w.x, w.y);
+            });
+        });
+    }
+    PHAST_HD static void step4(Regs &r) {
+        static_for<0, 4>([&](auto u) { fft_reg_dif_s<T, 4, decltype(u)::value, 4, P>(r.re, r.im); });
+    }
+
+    PHAST_HD static unsigned krow_lane(int wave, int lane) {
+        constexpr unsigned br2[4] = {0u, 2u, 1u, 3u};
+        return br2[tau_of(lane)] + 4u * br2[wave];
+    }
+    template <int Q> PHAST_HD static constexpr unsigned krow_const() {  // register Q = u + 4 v
+        return 16u * (unsigned)bitrev_c(Q & 3, 2) + 64u * (unsigned)bitrev_c(Q >> 2, 2);
+    }
+    PHAST_HD static void store(const TileArgs &a, int wave, int lane, const Regs &r) {
+        const size_t base = (size_t)(r.g0 & ((1u << a.out_lo_bits) - 1u)) * a.out_s1 + (size_t)(r.g0 >> a.out_lo_bits) * a.out_s2 +
+                            (size_t)r.xform * a.out_dist;
+        const unsigned voff = (unsigned)col_of(lane) * (unsigned)a.out_s1 + krow_lane(wave, lane) * (unsigned)a.out_row_stride;
+        const T scale = (T)a.scale;
+        static_for<0, P>([&](auto Q) {
+            const size_t at = base + (size_t)krow_const<decltype(Q)::value>() * a.out_row_stride + voff;
+            if (!a.out_interleaved) {
+                if constexpr (NT_HINT) {
+                    __builtin_nontemporal_store(r.re[Q] * scale, reinterpret_cast<T *>(a.out_re) + at);
+                    __builtin_nontemporal_store(r.im[Q] * scale, reinterpret_cast<T *>(a.out_im) + at);
+                } else {
+                    reinterpret_cast<T *>(a.out_re)[at] = r.re[Q] * scale;
+                    reinterpret_cast<T *>(a.out_im)[at] = r.im[Q] * scale;
+                }
+            } else {
+                cx v;
+                v.x = (a.out_interleaved == 2 ? r.im[Q] : r.re[Q]) * scale;
+                v.y = (a.out_interleaved == 2 ? r.re[Q] : r.im[Q]) * scale;
+                reinterpret_cast<cx *>(a.out_re)[at] = v;
+            }
+        });
+    }
+};
+
+// lane bits (5, 4) <-> register bits (3, 2)
+template <typename T> __device__ __forceinline__ void quad_lane_exchange(T (&re)[16], T (&im)[16]) {
+    static_for<0, 16>([&](auto p) {
+        constexpr int Pp = decltype(p)::value;
+        if constexpr ((Pp & 8) == 0) {
+            swap_pair<true>(re[Pp], re[Pp | 8]);
+            swap_pair<true>(im[Pp], im[Pp | 8]);
+        }
+    });
+    static_for<0, 16>([&](auto p) {
+        constexpr int Pp = decltype(p)::value;
+        if constexpr ((Pp & 4) == 0) {
+            swap_pair<false>(re[Pp], re[Pp | 4]);
+            swap_pair<false>(im[Pp], im[Pp | 4]);
+        }
+    });
+}
+
+template <typename T> __global__ void __launch_bounds__(256) quad_fft_kernel(const TileArgs a) {
+    using Body = QuadBody<T>;
+    using cx = cx_t<T>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T *ex_re = reinterpret_cast<T *>(smem);
+    T *ex_im = ex_re + Body::EXCH;
+    cx *l_tw3 = reinterpret_cast<cx *>(ex_im + Body::EXCH);
+    cx *l_twq = l_tw3 + (3u << a.tw_bits);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    typename Body::Regs r;
+    for (unsigned t = blockIdx.x; t < a.tiles_total; t += gridDim.x) {
+        Body::locate(a, t, r);
+        Body::load_raw(a, wave, lane, r);
+        if (t == blockIdx.x) {  // tables once per workgroup, behind the first tile's loads
+            for (int i = tid; i < Body::TWQ; i += Body::NT) l_twq[i] = reinterpret_cast<const cx *>(a.twr)[i];
+            for (unsigned i = tid; i < (3u << a.tw_bits); i += Body::NT) l_tw3[i] = reinterpret_cast<const cx *>(a.tw3)[i];
+        }
+        __syncthreads();  // tables visible / the previous tile's exchange reads done
+        Body::pre_twiddle(a, l_tw3, wave, lane, r);
+        Body::steps12(l_twq, wave, lane, r);
+        static_for<0, 16>([&](auto Q) {
+            ex_re[Body::template waddr<decltype(Q)::value>(wave, lane)] = r.re[Q];
+            ex_im[Body::template waddr<decltype(Q)::value>(wave, lane)] = r.im[Q];
+        });
+        __syncthreads();
+        static_for<0, 16>([&](auto Q) {
+            r.re[Q] = ex_re[Body::template raddr<decltype(Q)::value>(wave, lane)];
+            r.im[Q] = ex_im[Body::template raddr<decltype(Q)::value>(wave, lane)];
+        });
+        Body::step3(l_twq, lane, r);
+        quad_lane_exchange<T>(r.re, r.im);
+        Body::step4(r);
+        Body::store(a, wave, lane, r);
+    }
+}
+
+template <typename T>
+hipError_t launch_quad_inst(unsigned grid, hipStream_t stream, const TileArgs &a, bool query_only, int *blocks_per_cu,
+                            size_t *lds_out, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
+    using Body = QuadBody<T>;
+    auto kern = quad_fft_kernel<T>;
+    const size_t lds = Body::lds_bytes(a.tw_bits);
+    if (lds_out) *lds_out = lds;
+    if (lds > (size_t)160 * 1024) {
+        if (query_only && blocks_per_cu) *blocks_per_cu = 0;
+        return query_only ? hipSuccess : hipErrorInvalidValue;
+    }
+    static size_t lds_limit = 0;
+    if (lds > lds_limit) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        lds_limit = lds;
+    }
+    if (query_only) {
+        if (blocks_per_cu) *blocks_per_cu = (int)((160 * 1024) / lds) < 2 ? (int)((160 * 1024) / lds) : 2;
+        return hipSuccess;
+    }
+    if (ev_start && ev_stop)
+        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(Body::NT), (uint32_t)lds, stream, ev_start, ev_stop, 0, a);
+    else
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(Body::NT), lds, stream, a);
+    return hipGetLastError();
+}
+
+// host emulation of one pass: the same phase functions, both exchanges by their definitions
+template <typename T> void emulate_quad_pass(const TileArgs &a) {
+    using Body = QuadBody<T>;
+    using Regs = typename Body::Regs;
+    std::vector<T> ex_re(Body::EXCH), ex_im(Body::EXCH);
+    std::vector<Regs> regs(Body::NT), nxt(Body::NT);
+    const cx_t<T> *tw3 = reinterpret_cast<const cx_t<T> *>(a.tw3), *twq = reinterpret_cast<const cx_t<T> *>(a.twr);
+    for (unsigned t = 0; t < a.tiles_total; ++t) {
+        for (int tid = 0; tid < Body::NT; ++tid) {
+            const int lane = tid & 63, wave = tid >> 6;
+            Body::locate(a, t, regs[tid]);
+            Body::load_raw(a, wave, lane, regs[tid]);
+            Body::pre_twiddle(a, tw3, wave, lane, regs[tid]);
+            Body::steps12(twq, wave, lane, regs[tid]);
+            static_for<0, 16>([&](auto Q) {
+                ex_re[Body::template waddr<decltype(Q)::value>(wave, lane)] = regs[tid].re[Q];
+                ex_im[Body::template waddr<decltype(Q)::value>(wave, lane)] = regs[tid].im[Q];
+            });
+        }
+        for (int tid = 0; tid < Body::NT; ++tid) {
+            const int lane = tid & 63, wave = tid >> 6;
+            static_for<0, 16>([&](auto Q) {
+                regs[tid].re[Q] = ex_re[Body::template raddr<decltype(Q)::value>(wave, lane)];
+                regs[tid].im[Q] = ex_im[Body::template raddr<decltype(Q)::value>(wave, lane)];
+            });
+            Body::step3(twq, lane, regs[tid]);
+        }
+        // lane bits (5, 4) <-> register bits (3, 2): new[lane (b5 b4)][reg (s1 s0 | u)] = old[lane (s1 s0)][reg (b5 b4 | u)]
+        for (int tid = 0; tid < Body::NT; ++tid) {
+            const int lane = tid & 63, wave = tid >> 6, col = lane & 15, b = lane >> 4;
+            nxt[tid] = regs[tid];
+            for (int q = 0; q < 16; ++q) {
+                const int src = wave * 64 + (((q >> 2) << 4) | col), src_reg = (b << 2) | (q & 3);
+                nxt[tid].re[q] = regs[src].re[src_reg];
+                nxt[tid].im[q] = regs[src].im[src_reg];
+            }
+        }
+        for (int tid = 0; tid < Body::NT; ++tid) {
+            Body::step4(nxt[tid]);
+            Body::store(a, tid >> 6, tid & 63, nxt[tid]);
+        }
+    }
+}
+
+}  // namespace phast

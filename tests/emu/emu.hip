@@ -10,10 +10,15 @@
 #include "row_fft.hpp"
 #include "tile_fft.hpp"
 #include "wave_fft.hpp"
+#include "quad_fft.hpp"
 
 namespace phast {
 
 template <typename T> static bool emu_pass(const PassGeom &p, const TileArgs &a) {
+    if (p.quad) {
+        emulate_quad_pass<T>(a);
+        return true;
+    }
     if (p.wave) {
         if (p.transpose) emulate_wave_pass<T, false, true>(a);
         else emulate_wave_pass<T, true, false>(a);
@@ -50,7 +55,7 @@ static int emu_exec(const void *in_re, const void *in_im, unsigned in_mode, void
     std::vector<T> s_re(n * batch), s_im(n * batch);
     for (size_t i = 0; i < ps.size(); ++i) {
         const PassGeom &p = ps[i];
-        std::vector<cx_t<T>> twr = host_twr<T>(1u << p.lr), tw3;
+        std::vector<cx_t<T>> twr = p.quad ? host_twq<T>() : host_twr<T>(1u << p.lr), tw3;
         if (p.pre_tw) tw3 = host_tw3<T>(p.log_mod(), p.tw_bits);
         TileArgs ta{};
         const bool first = i == 0, last = i + 1 == ps.size();
