@@ -188,6 +188,7 @@ template <typename T, int LR, int LC, int LP> static int audit_small_shape(int *
 
 }  // namespace phast
 
+#if !defined(EMU_PART) || EMU_PART == 3
 extern "C" int phast_emu_audit_lds(int is_f64, unsigned lr, unsigned lc, unsigned lp, int transpose, int *max_read_ways,
                                    int *max_write_ways) {
 #define PHAST_AUD(LR_, LC_, LP_)                                                                                       \
@@ -208,15 +209,19 @@ extern "C" int phast_emu_audit_lds(int is_f64, unsigned lr, unsigned lc, unsigne
 #undef PHAST_AUD32
     return -1;
 }
+#endif
 
 extern "C" {
 // planar in-place forward / inverse (swap trick + 1/N as algorithms/dit.rs:297-300,325-331)
+#if !defined(EMU_PART) || EMU_PART == 1
 int phast_emu_fft_f64(double *re, double *im, unsigned log_n, size_t batch, int direction, const unsigned *lrs,
                       size_t np, unsigned tile_log) {
     const size_t n = (size_t)1 << log_n;
     if (direction < 0) return phast::emu_exec<double>(im, re, 0, im, re, 0, log_n, batch, n, n, 1.0 / (double)n, lrs, np, tile_log);
     return phast::emu_exec<double>(re, im, 0, re, im, 0, log_n, batch, n, n, 1.0, lrs, np, tile_log);
 }
+#endif
+#if !defined(EMU_PART) || EMU_PART == 2
 int phast_emu_fft_f32(float *re, float *im, unsigned log_n, size_t batch, int direction, const unsigned *lrs,
                       size_t np, unsigned tile_log) {
     const size_t n = (size_t)1 << log_n;
@@ -230,6 +235,8 @@ int phast_emu_fft_f32_modes(const float *in_re, const float *in_im, unsigned in_
     const size_t n = (size_t)1 << log_n;
     return phast::emu_exec<float>(in_re, in_im, in_mode, out_re, out_im, out_mode, log_n, 1, n, n, scale, lrs, np, tile_log);
 }
+#endif
+#if !defined(EMU_PART) || EMU_PART == 4
 // batches of small transforms (N = 2..2048) through the one-pass kernel's body (row_fft.hpp); modes as above
 static int emu_small(int is_f64, const void *in_re, const void *in_im, unsigned in_mode, void *out_re, void *out_im,
                      unsigned out_mode, unsigned log_n, size_t batch, size_t in_dist, size_t out_dist, double scale,
@@ -290,7 +297,8 @@ int phast_emu_audit_small(int is_f64, unsigned log_n, int *max_read_ways, int *m
     return -1;
 }
 
-// the default plan of the library for (type, log_n): fills lrs[3], returns the number of passes
+#endif
+#if !defined(EMU_PART) || EMU_PART == 1
 // strided batch (column FFTs of a row-major [2^log_n][2^s] array, first 2^sb columns), in place, forward
 int phast_emu_fft_strided_f64(double *re, double *im, unsigned log_n, unsigned s, unsigned sb) {
     using namespace phast;
@@ -318,6 +326,7 @@ int phast_emu_fft_strided_f64(double *re, double *im, unsigned log_n, unsigned s
     return 0;
 }
 
+// the default plan of the library for (type, log_n): fills lrs[3], returns the number of passes
 int phast_emu_default_plan(int is_f64, int latency, unsigned log_n, unsigned *lrs, unsigned *tile_log,
                            unsigned *points_log) {
     std::vector<unsigned> v, tl;
@@ -327,4 +336,5 @@ int phast_emu_default_plan(int is_f64, int latency, unsigned log_n, unsigned *lr
     for (size_t i = 0; i < v.size(); ++i) lrs[i] = v[i];
     return (int)v.size();
 }
+#endif
 }
