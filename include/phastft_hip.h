@@ -127,6 +127,16 @@ int phast_fft_64_dit_strided_dev(double *d_reals, double *d_imags, size_t n, siz
                                  int direction, const phast_planner_dit64 *planner, void *stream);
 int phast_fft_32_dit_strided_dev(float *d_reals, float *d_imags, size_t n, size_t batch, size_t dist, size_t stride,
                                  int direction, const phast_planner_dit32 *planner, void *stream);
+/* The same column FFTs with an INPUT twiddle fused into the first pass's load: element j of transform b is multiplied by
+ * W_{tw_n}^(j * (tw_col0 + b)) before it is transformed -- the inter-factor twiddle of a four-step split (N = N1 N2 = tw_n,
+ * this call = the second factor's transforms on rank-local columns tw_col0 ...), which otherwise is a sweep of its own
+ * (phast_twiddle_grid*_apply_dev).  tw_n a power of two, n <= tw_n <= 2^32; dist == 1 only. */
+int phast_fft_64_dit_strided_tw_dev(double *d_reals, double *d_imags, size_t n, size_t batch, size_t dist, size_t stride,
+                                    int direction, const phast_planner_dit64 *planner, size_t tw_n, size_t tw_col0,
+                                    void *stream);
+int phast_fft_32_dit_strided_tw_dev(float *d_reals, float *d_imags, size_t n, size_t batch, size_t dist, size_t stride,
+                                    int direction, const phast_planner_dit32 *planner, size_t tw_n, size_t tw_col0,
+                                    void *stream);
 
 /* ---- C2C on interleaved Complex<T> signals: lib.rs:41-140 (feature `complex-nums`) ----
  * `signal` holds n complex numbers as (re, im) pairs, transformed in place.  The reference copies into two planar

@@ -428,10 +428,13 @@ def fft_dit_batched(reals, imags, n: int, direction: Direction, planner, dist: i
                                                            _stream()))
 
 
-def fft_dit_strided(reals, imags, n: int, direction: Direction, planner, batch: int, stride: int) -> None:
+def fft_dit_strided(reals, imags, n: int, direction: Direction, planner, batch: int, stride: int,
+                    twiddle_n: int = 0, twiddle_col0: int = 0) -> None:
     """Device-resident "column FFTs": the tensors hold a row-major ``[n][stride]`` array whose first ``batch`` columns
     are transformed along the rows' axis, in place (transform ``c`` = elements ``c + j*stride``).  ``stride`` and
-    ``batch`` powers of two, ``batch <= stride``, ``n >= 64``.  No reference counterpart."""
+    ``batch`` powers of two, ``batch <= stride``, ``n >= 64``.  With ``twiddle_n`` the first pass multiplies element
+    ``j`` of column ``c`` by ``W_twiddle_n^(j*(twiddle_col0 + c))`` on load (the inter-factor twiddle of a four-step
+    split).  No reference counterpart."""
     dtype, sfx = planner._dtype, planner._sfx
     re, im = _Slice(reals, dtype, "reals"), _Slice(imags, dtype, "imags")
     if not _same_place(re, im):
@@ -440,6 +443,11 @@ def fft_dit_strided(reals, imags, n: int, direction: Direction, planner, batch: 
         _check(2)
     if re.len < n * stride:
         raise ValueError("the tensors must hold n*stride elements")
+    if twiddle_n:
+        _check(getattr(_lib.lib(), f"phast_fft_{sfx}_dit_strided_tw_dev")(
+            re.ptr, im.ptr, C.c_size_t(n), C.c_size_t(batch), C.c_size_t(1), C.c_size_t(stride), C.c_int(int(direction)),
+            planner._h, C.c_size_t(twiddle_n), C.c_size_t(twiddle_col0), _stream()))
+        return
     _check(getattr(_lib.lib(), f"phast_fft_{sfx}_dit_strided_dev")(re.ptr, im.ptr, C.c_size_t(n), C.c_size_t(batch),
                                                                    C.c_size_t(1), C.c_size_t(stride),
                                                                    C.c_int(int(direction)), planner._h, _stream()))

@@ -185,7 +185,7 @@ template <typename T> struct Planner {
     mutable std::vector<void *> retired_dev, retired_pin;
     // plans of strided batches (column FFTs), built on first use per (log2 stride, log2 batch): see make_strided_passes
     struct StridedPlan {
-        unsigned s = 0, sb = 0;
+        unsigned s = 0, sb = 0, grid_log_n = 0;
         std::vector<PassDesc> passes;
     };
     mutable std::vector<StridedPlan> strided_plans;
@@ -427,17 +427,19 @@ template <typename T> struct Planner {
 
     // Strided batch ("column FFTs"): 2^sb transforms, transform c at element c, points 2^s elements apart, in place in
     // the caller's planes (forward arithmetic; `scale` on the last store).  make_strided_passes has the layouts.
-    int exec_strided(T *re, T *im, unsigned s_bits, unsigned sb_bits, double scale, hipStream_t stream) const {
+    int exec_strided(T *re, T *im, unsigned s_bits, unsigned sb_bits, double scale, hipStream_t stream,
+                     unsigned grid_log_n = 0, unsigned grid_col0 = 0) const {
         std::lock_guard<std::recursive_mutex> call_lock(call_mu);
         const StridedPlan *plan = nullptr;
         for (const auto &sp : strided_plans)
-            if (sp.s == s_bits && sp.sb == sb_bits) plan = &sp;
+            if (sp.s == s_bits && sp.sb == sb_bits && sp.grid_log_n == grid_log_n) plan = &sp;
         if (!plan) {
             std::vector<PassGeom> geo;
-            if (!make_strided_passes(log_n, s_bits, sb_bits, sizeof(T), geo)) return PHAST_ERR_INVALID_ARG;
+            if (!make_strided_passes(log_n, s_bits, sb_bits, sizeof(T), geo, grid_log_n)) return PHAST_ERR_INVALID_ARG;
             StridedPlan sp;
             sp.s = s_bits;
             sp.sb = sb_bits;
+            sp.grid_log_n = grid_log_n;
             sp.passes.resize(geo.size());
             for (size_t i = 0; i < geo.size(); ++i) static_cast<PassGeom &>(sp.passes[i]) = geo[i];
             int rc = prepare_passes(sp.passes, nullptr);
@@ -467,6 +469,7 @@ template <typename T> struct Planner {
             ta.tw3 = p.d_tw3;
             ta.twr = p.d_twr;
             geom_to_args(p, log_n, 1, ta);
+            ta.grid_col0 = grid_col0;
             hipError_t e = launch_pass(p, ta, stream, nullptr, nullptr);
             if (e != hipSuccess) return hip_fail(e, "tile_fft launch (strided)");
         }
@@ -771,7 +774,9 @@ static int fft_dev(T *d_re, T *d_im, size_t n, size_t batch, size_t dist, int di
 //                SURVEY.md section 8b suggested the signature).
 template <typename T>
 static int fft_strided_dev(T *d_re, T *d_im, size_t n, size_t batch, size_t dist, size_t stride, int direction,
-                           const Planner<T> *pl, hipStream_t s) {
+                           const Planner<T> *pl, hipStream_t s, size_t tw_n = 0, size_t tw_col0 = 0) {
+    if (tw_n && (stride == 1 || !is_pow2(tw_n) || tw_n < n || ilog2(tw_n) > 32 || tw_col0 + batch > tw_n))
+        return PHAST_ERR_INVALID_ARG;
     if (stride == 1) return fft_dev<T>(d_re, d_im, n, batch, dist, direction, pl, s);
     if (!pl || !d_re || !d_im) return PHAST_ERR_INVALID_ARG;
     if (direction != PHAST_FORWARD && direction != PHAST_REVERSE) return PHAST_ERR_INVALID_ARG;
@@ -779,8 +784,9 @@ static int fft_strided_dev(T *d_re, T *d_im, size_t n, size_t batch, size_t dist
     if (ilog2(n) != pl->log_n) return PHAST_ERR_PLANNER_SIZE;
     if (dist != 1 || !is_pow2(stride) || !is_pow2(batch) || batch > stride) return PHAST_ERR_INVALID_ARG;
     const unsigned sb = ilog2(stride), bb = ilog2(batch);
-    if (direction == PHAST_REVERSE) return pl->exec_strided(d_im, d_re, sb, bb, 1.0 / (double)n, s);
-    return pl->exec_strided(d_re, d_im, sb, bb, 1.0, s);
+    const unsigned gl = tw_n ? ilog2(tw_n) : 0u;
+    if (direction == PHAST_REVERSE) return pl->exec_strided(d_im, d_re, sb, bb, 1.0 / (double)n, s, gl, (unsigned)tw_col0);
+    return pl->exec_strided(d_re, d_im, sb, bb, 1.0, s, gl, (unsigned)tw_col0);
 }
 
 // average kernel duration of every pass over `reps` forward transforms of the same buffers
@@ -1218,6 +1224,13 @@ PHAST_PLANNER_API(32, float)
                                           int direction, const phast_planner_dit##SFX *pl, void *stream) {          \
         return fft_strided_dev<T>(d_re, d_im, n, batch, dist, stride, direction, pl,                                \
                                   static_cast<hipStream_t>(stream));                                                \
+    }                                                                                                               \
+    int phast_fft_##SFX##_dit_strided_tw_dev(T *d_re, T *d_im, size_t n, size_t batch, size_t dist, size_t stride,  \
+                                             int direction, const phast_planner_dit##SFX *pl, size_t tw_n,          \
+                                             size_t tw_col0, void *stream) {                                        \
+        if (tw_n == 0) return PHAST_ERR_INVALID_ARG;                                                                \
+        return fft_strided_dev<T>(d_re, d_im, n, batch, dist, stride, direction, pl,                                \
+                                  static_cast<hipStream_t>(stream), tw_n, tw_col0);                                 \
     }                                                                                                               \
     int phast_fft_##SFX##_interleaved(T *signal, size_t n, int direction) {                                         \
         Planner<T> *pl = nullptr;                                                                                   \

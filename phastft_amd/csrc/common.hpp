@@ -101,6 +101,12 @@ struct TileArgs {
     //   g0 = ((t >> cb_bits) << cs_bits) | ((t & (2^cb_bits - 1)) << LC)
     unsigned cs_bits;
     unsigned cb_bits;
+    // first pass of a strided batch with an INPUT twiddle (four-step split: x[j][c] *= W_{2^grid_log_n}^(j (col0 + c)) on
+    // load; j = row << grid_row_shift | the column's upper digits): exponent of row p = p K + glo k, K = k << grid_row_shift
+    unsigned grid_mode;
+    unsigned grid_col0;
+    unsigned grid_row_shift;
+    unsigned grid_col_mask;
     double scale;              // 1/N on the last pass of an inverse transform, else 1
     unsigned long long *trace; // tools/trace_tile.py only: [workgroup][16] s_memtime stamps of the first tile's phases
 };

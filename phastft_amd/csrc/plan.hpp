@@ -135,6 +135,7 @@ struct PassGeom {
     unsigned long long out_s1 = 0, out_s2 = 0, out_row_stride = 0;
     // strided batches (make_strided_passes): see TileArgs; tw_log_mod = log2 of the twiddle modulus when it is not lr + log_s_in
     unsigned tw_shift = 0, tw_mask_bits = 0, cs_bits = 0, cb_bits = 0, tw_log_mod = 0;
+    unsigned grid_log_n = 0, grid_row_shift = 0;  // first pass with the input twiddle of a four-step split (TileArgs::grid_*)
     bool strided = false;
     unsigned log_mod() const { return strided ? tw_log_mod : lr + log_s_in; }  // the inter-pass twiddle is W_{2^log_mod}^{row*lo}
 };
@@ -306,6 +307,9 @@ inline void geom_to_args(const PassGeom &p, unsigned log_n, size_t n_xforms, Til
         ta.tw_mask = p.tw_mask_bits >= 32 ? 0xffffffffu : ((1u << p.tw_mask_bits) - 1u);
         ta.cs_bits = p.cs_bits;
         ta.cb_bits = p.cb_bits;
+        ta.grid_mode = p.grid_log_n ? 1u : 0u;
+        ta.grid_row_shift = p.grid_row_shift;
+        ta.grid_col_mask = (1u << p.tw_shift) - 1u;
         ta.tiles_per_xform = 1u << (log_n - p.lr + p.cb_bits);
         ta.tiles_total = ta.tiles_per_xform;
         return;
@@ -331,8 +335,11 @@ inline unsigned pick_lp(unsigned lr, unsigned lc, size_t elem_bytes) {
         if (lp <= lr && shape_exists(lr, lc, lp, elem_bytes)) return lp;
     return 0;
 }
-inline bool make_strided_passes(unsigned L, unsigned s, unsigned sb, size_t elem_bytes, std::vector<PassGeom> &ps) {
+// grid_log_n != 0: the first pass multiplies x[j][c] by W_{2^grid_log_n}^(j (col0 + c)) on load (col0 per call).
+inline bool make_strided_passes(unsigned L, unsigned s, unsigned sb, size_t elem_bytes, std::vector<PassGeom> &ps,
+                                unsigned grid_log_n = 0) {
     if (L < 6 || sb > s || L + s > 31) return false;  // tile FFTs are 64..1024 points; 32-bit element offsets
+    if (grid_log_n > 32 || (grid_log_n && grid_log_n < L)) return false;
     unsigned np = (L + 9) / 10;                        // rows <= 1024 per pass
     if (np > 3) return false;
     unsigned want_lc = elem_bytes == 8 ? 4u : 5u;      // 128-byte rows
@@ -374,6 +381,12 @@ inline bool make_strided_passes(unsigned L, unsigned s, unsigned sb, size_t elem
         g.tw_mask_bits = i == 0 ? 0 : done;  // lo = the digits already done (kp, kb..), not the untransformed ones
         g.tw_log_mod = done + lrs[i];        // W_{2^(done + lr)}^(row * lo)
         g.tw_bits = tw3_bits_for(i == 0 ? 3 : g.tw_log_mod);
+        if (i == 0 && grid_log_n) {
+            g.grid_log_n = grid_log_n;
+            g.grid_row_shift = L - lrs[0];  // weight of this pass's row digit in the transform index j
+            g.tw_log_mod = grid_log_n;
+            g.tw_bits = tw3_bits_for(grid_log_n);
+        }
         done += lrs[i];
     }
     return true;

@@ -215,8 +215,17 @@ template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool 
     PHAST_HD static void pre_twiddle(const TileArgs &a, const Shared &sh, int tid, Regs &r) {
         if constexpr (PRE_TW) {
             const int col = col_of(tid), tau = tau_of(tid);
-            const unsigned lo = ((r.g0 + (unsigned)col) >> a.tw_shift) & a.tw_mask;
-            const unsigned e0 = (unsigned)tau * lo, de = (unsigned)M * lo;  // exponent of row j*M + tau: e0 + j*de
+            unsigned e0, de;  // exponent of row j*M + tau: e0 + j*de (mod 2^32, a multiple of every table modulus)
+            if (a.grid_mode) {  // input twiddle of a four-step split: (row << shift | glo) * (col0 + c)
+                const unsigned g = r.g0 + (unsigned)col, k = a.grid_col0 + (g & a.grid_col_mask), glo = g >> a.tw_shift;
+                const unsigned big = k << a.grid_row_shift;
+                e0 = (unsigned)tau * big + glo * k;
+                de = (unsigned)M * big;
+            } else {
+                const unsigned lo = ((r.g0 + (unsigned)col) >> a.tw_shift) & a.tw_mask;
+                e0 = (unsigned)tau * lo;
+                de = (unsigned)M * lo;
+            }
             if constexpr (sizeof(T) == 8 && LR >= 10 && LP == 5) {
                 // W^(e0 + j de) = W^e0 (W^de)^j: two look-ups and a power ladder (depth log2 P) instead of P look-ups --
                 // the same number of complex products, 6 LDS reads per thread instead of 3 P, none of them conflicting

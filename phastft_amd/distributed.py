@@ -8,9 +8,10 @@ slabs, rank r holding ``x[r*N/P : (r+1)*N/P]`` -- natural order in, natural orde
 Four-step split ``N = N1*N2`` (``n = n1*N2 + n2``, ``k = k1 + N1*k2``), every array row-major:
 
     slab [n1 (mine)][n2]  --pack, all-to-all-->  [n1][n2 (mine)]
-        COLUMN FFTs over n1 (strided batch, in place)  ->  [k1][n2 (mine)],  times W_N^(k1*n2)   (TwiddleGrid, twiddle.hip)
+        COLUMN FFTs over n1 (strided batch, in place)  ->  [k1][n2 (mine)]
     --all-to-all (row blocks are contiguous: no pack), unpack-->  [n2][k1 (mine)]
-        COLUMN FFTs over n2  ->  [k2][k1 (mine)]
+        times W_N^(n2*k1), fused into the first load of the COLUMN FFTs over n2  ->  [k2][k1 (mine)]
+        (phast_fft_*_dit_strided_tw_dev; shapes it declines: TwiddleGrid sweep, twiddle.hip)
     --all-to-all (contiguous row blocks), unpack-->  [k2 (mine)][k1]  =  X[k] in natural order, slab of rank ``k2 block``
 
 The local transforms are strided batches ("column FFTs", ``phast_fft_*_dit_strided_dev``): they run on the layout an
@@ -24,7 +25,7 @@ per GPU against ~5 TB/s of HBM): the local stages are the library's batched kern
 
 The exchanges are ``torch.distributed.all_to_all_single`` (backend "nccl" = RCCL on GPUs; "gloo" moves the blocks
 through host memory and serves the CPU tests of this logic and single-GPU dry runs).  The local stages are injected
-(`local_fft`, `twiddle`) so that the host logic is testable without a GPU (tests/test_distributed_cpu.py).
+(`column_fft`, `twiddle`, optionally `column_fft_tw`) so that the host logic is testable without a GPU (tests/test_distributed_cpu.py).
 """
 from __future__ import annotations
 
@@ -47,17 +48,24 @@ class DistributedFft:
 
     ``column_fft(re, im, length, count)`` transforms the `count` columns of the row-major ``[length][count]`` array in
     place (forward); ``twiddle(re, im, rows, cols, col0)`` multiplies element (r, c) of the row-major block by
-    W_n^(r*(col0+c)).  Both act on 1-D tensors of the process group's device type.
+    W_n^(r*(col0+c)).  Both act on 1-D tensors of the process group's device type.  Optional
+    ``column_fft_tw(re, im, length, count, col0)``: the same transform with the multiplication by W_n^(j*(col0+c)) fused
+    into its first load and returning True -- or False when it cannot, in which case `twiddle` + `column_fft` run.
     """
 
-    def __init__(self, n: int, rank: int, world: int, column_fft: Callable, twiddle: Callable, dist=None):
+    def __init__(self, n: int, rank: int, world: int, column_fft: Callable, twiddle: Callable, dist=None,
+                 column_fft_tw: Callable | None = None):
         if n <= 0 or n & (n - 1):
             raise ValueError("assertion failed: num_points > 0 && num_points.is_power_of_two()")  # planner.rs:66
         self.n, self.rank, self.world, self.dist = n, rank, world, dist
         self.n1, self.n2 = split_factors(n.bit_length() - 1, world)
-        self._fft, self._twiddle = column_fft, twiddle
+        self._fft, self._twiddle, self._fft_tw = column_fft, twiddle, column_fft_tw
         if world > 1 and dist is None:
             raise ValueError("more than one rank needs a torch.distributed process group")
+
+    def _twiddle_t(self, re, im, rows, cols, col0):
+        """W_n^(r * (col0 + c)) on a row-major [rows][cols] block: the same call as `twiddle` (its roles are symmetric)"""
+        self._twiddle(re, im, rows, cols, col0)
 
     def _all_to_all(self, send):
         """rank q receives every rank's q-th equal chunk of `send`; returns the chunks in source-rank order"""
@@ -91,16 +99,24 @@ class DistributedFft:
         def unpack3(x):    # received [src s][k2 mine][k1 in s's block] -> [k2 mine][k1]
             return x.view(w, c2, r1).permute(1, 0, 2).contiguous().view(-1) if w > 1 else x
 
-        # exchange 1 -> [n1][n2 mine] (source-major = natural n1 order): column FFTs over n1, then W_N^(k1 * n2)
+        # exchange 1 -> [n1][n2 mine] (source-major = natural n1 order): column FFTs over n1
         a_re, a_im = self._all_to_all(pack(re)), self._all_to_all(pack(im))
         if w == 1:
             a_re, a_im = a_re.clone(), a_im.clone()
         self._fft(a_re, a_im, n1, c2)
-        self._twiddle(a_re, a_im, n1, c2, self.rank * c2)
+        # The inter-factor twiddle W_N^(k1 * n2) commutes with the exchange (it is element-wise): it is applied on the
+        # other side, fused into the first load of the column FFTs over n2 (rows n2, columns k1 = rank*r1 + c) where
+        # the kernels can do that, else as its own sweep over [k1][n2 mine] before the exchange.
+        fused = self._fft_tw is not None
+        if not fused:
+            self._twiddle(a_re, a_im, n1, c2, self.rank * c2)
         # exchange 2: the block for rank q is the rows k1 of q's range -- contiguous as it stands
         b_re, b_im = unpack2(self._all_to_all(a_re)), unpack2(self._all_to_all(a_im))
         del a_re, a_im
-        self._fft(b_re, b_im, n2, r1)                     # -> [k2][k1 mine]
+        if not fused or not self._fft_tw(b_re, b_im, n2, r1, self.rank * r1):   # -> [k2][k1 mine]
+            if fused:  # the fused form declined this shape: W_N^(n2 * k1) on [n2][k1 mine], then the plain transform
+                self._twiddle_t(b_re, b_im, n2, r1, self.rank * r1)
+            self._fft(b_re, b_im, n2, r1)
         # exchange 3: rows k2 of q's range, contiguous; unpack to natural order
         c_re, c_im = unpack3(self._all_to_all(b_re)), unpack3(self._all_to_all(b_im))
         del b_re, b_im
@@ -136,6 +152,14 @@ def gpu_transform(n: int, rank: int, world: int, dist=None, dtype: str = "f64") 
     def twiddle(re, im, rows, cols, col0):
         grid.apply(re, im, rows, cols, row0=0, col0=col0)
 
-    t = DistributedFft(n, rank, world, column_fft, twiddle, dist)
+    def column_fft_tw(re, im, length, count, col0):
+        try:
+            P.fft_dit_strided(re, im, length, P.Direction.Forward, planners[length], batch=count, stride=count,
+                              twiddle_n=n, twiddle_col0=col0)
+            return True
+        except P.PhastPanic:
+            return False
+
+    t = DistributedFft(n, rank, world, column_fft, twiddle, dist, column_fft_tw)
     t._keep = (planners, grid)
     return t

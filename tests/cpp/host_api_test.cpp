@@ -63,6 +63,11 @@ int main(int argc, char **argv) {
     {
         std::vector<double> d(10);
         EXPECT(panic_message([&] { bit_rev_bravo_f64(d, 3); }) == "Data length must be 2^n");
+        // n is validated before it is used as a shift count (a shift by >= 64 is undefined behaviour)
+        EXPECT(panic_message([&] { bit_rev_bravo_f64(d, 64); }) == "Data length must be 2^n");
+        EXPECT(panic_message([&] { bit_rev_bravo_f64(d, 4000000000u); }) == "Data length must be 2^n");
+        std::vector<float> f(10);
+        EXPECT(panic_message([&] { bit_rev_bravo_f32(f, 77); }) == "Data length must be 2^n");
     }
     const Options o = Options::guess_options(size_t(1) << 20);  // options.rs:38-43
     EXPECT(o.multithreaded_bit_reversal && o.smallest_parallel_chunk_size == 16384);
@@ -134,6 +139,22 @@ int main(int argc, char **argv) {
         fft_64_interleaved(sig, Direction::Forward);
         fft_64_dit(re, im, Direction::Forward);
         for (size_t i = 0; i < n; ++i) EXPECT(std::fabs(sig[i].real() - re[i]) < 1e-10 * 1e6 && std::fabs(sig[i].imag() - im[i]) < 1e-10 * 1e6);
+        // the _with_planner_and_opts forms (lib.rs:50): forward then reverse gives the signal back
+        PlannerDit64 planner(n);
+        const Options opts = Options::guess_options(n);
+        std::vector<std::complex<double>> sig2(n);
+        for (size_t i = 0; i < n; ++i) sig2[i] = {double(i + 1), -0.5 * double(i)};
+        std::vector<std::complex<double>> orig = sig2;
+        fft_64_interleaved_with_planner_and_opts(sig2, Direction::Forward, planner, opts);
+        fft_64_interleaved_with_planner_and_opts(sig2, Direction::Reverse, planner, opts);
+        for (size_t i = 0; i < n; ++i) EXPECT(std::abs(sig2[i] - orig[i]) < 1e-9);
+        PlannerDit32 planner32(n);
+        std::vector<std::complex<float>> sig3(n), orig3;
+        for (size_t i = 0; i < n; ++i) sig3[i] = {float(i % 7) - 3.0f, float(i % 5)};
+        orig3 = sig3;
+        fft_32_interleaved_with_planner_and_opts(sig3, Direction::Forward, planner32, opts);
+        fft_32_interleaved_with_planner_and_opts(sig3, Direction::Reverse, planner32, opts);
+        for (size_t i = 0; i < n; ++i) EXPECT(std::abs(sig3[i] - orig3[i]) < 1e-3f);
     }
     // ---- R2C known answers and panics (r2c.rs:1235-1540), R2C -> C2R round trip (r2c.rs:958-976) ----
     {

@@ -300,10 +300,17 @@ int phast_emu_audit_small(int is_f64, unsigned log_n, int *max_read_ways, int *m
 #endif
 #if !defined(EMU_PART) || EMU_PART == 1
 // strided batch (column FFTs of a row-major [2^log_n][2^s] array, first 2^sb columns), in place, forward
+int phast_emu_fft_strided_tw_f64(double *re, double *im, unsigned log_n, unsigned s, unsigned sb, unsigned grid_log_n,
+                                 unsigned col0);
 int phast_emu_fft_strided_f64(double *re, double *im, unsigned log_n, unsigned s, unsigned sb) {
+    return phast_emu_fft_strided_tw_f64(re, im, log_n, s, sb, 0, 0);
+}
+// ... with the input twiddle W_{2^grid_log_n}^(j (col0 + c)) fused into the first pass (grid_log_n = 0: none)
+int phast_emu_fft_strided_tw_f64(double *re, double *im, unsigned log_n, unsigned s, unsigned sb, unsigned grid_log_n,
+                                 unsigned col0) {
     using namespace phast;
     std::vector<PassGeom> ps;
-    if (!make_strided_passes(log_n, s, sb, sizeof(double), ps)) return 1;
+    if (!make_strided_passes(log_n, s, sb, sizeof(double), ps, grid_log_n)) return 1;
     const size_t total = (size_t)1 << (log_n + s);
     std::vector<double> t_re(total), t_im(total);
     for (size_t i = 0; i < ps.size(); ++i) {
@@ -321,6 +328,7 @@ int phast_emu_fft_strided_f64(double *re, double *im, unsigned log_n, unsigned s
         ta.tw3 = tw3.data();
         ta.twr = twr.data();
         geom_to_args(p, log_n, 1, ta);
+        ta.grid_col0 = col0;
         if (!emu_pass<double>(p, ta)) return 2;
     }
     return 0;

@@ -85,7 +85,7 @@ def test_two_rank_sharded_batch_gloo(tmp_path):
 
 
 # ---------------------------------------------------------------- one transform over several ranks (f-3)
-def _dist_fft_worker(rank, world, port, log_n, reverse, out_dir):
+def _dist_fft_worker(rank, world, port, log_n, reverse, out_dir, fused=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
 
@@ -114,20 +114,28 @@ def _dist_fft_worker(rank, world, port, log_n, reverse, out_dir):
     full_re, full_im = O.fill(n, np.float64, seed=0xD157, transform_id=log_n)
     lo, hi = rank * n // world, (rank + 1) * n // world
     re, im = torch.from_numpy(full_re[lo:hi].copy()), torch.from_numpy(full_im[lo:hi].copy())
-    DistributedFft(n, rank, world, column_fft, twiddle, dist).run(re, im, reverse=reverse)
+    def column_fft_tw(re, im, length, count, col0):  # fused form: declines odd-numbered problem sizes (fallback path)
+        if log_n % 2:
+            return False
+        twiddle(re, im, length, count, col0)
+        column_fft(re, im, length, count)
+        return True
+
+    DistributedFft(n, rank, world, column_fft, twiddle, dist, column_fft_tw if fused else None).run(re, im, reverse=reverse)
     np.save(os.path.join(out_dir, f"re{rank}.npy"), re.numpy())
     np.save(os.path.join(out_dir, f"im{rank}.npy"), im.numpy())
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,log_n,reverse", [(2, 10, False), (4, 11, False), (2, 13, True), (4, 8, True)])
-def test_one_transform_over_ranks_gloo(tmp_path, world, log_n, reverse):
+@pytest.mark.parametrize("world,log_n,reverse,fused", [(2, 10, False, False), (4, 11, False, True), (2, 13, True, False),
+                                                       (4, 8, True, True), (2, 12, False, True)])
+def test_one_transform_over_ranks_gloo(tmp_path, world, log_n, reverse, fused):
     """Block-distributed natural order in, natural order out, three all-to-alls: the concatenated slabs must be the
     transform of the concatenated input (the oracle run on one rank), forward and reverse."""
     from oracle import oracle as O
 
-    mp.spawn(_dist_fft_worker, args=(world, _free_port(), log_n, reverse, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_dist_fft_worker, args=(world, _free_port(), log_n, reverse, str(tmp_path), fused), nprocs=world, join=True)
     n = 1 << log_n
     got_re = np.concatenate([np.load(tmp_path / f"re{r}.npy") for r in range(world)])
     got_im = np.concatenate([np.load(tmp_path / f"im{r}.npy") for r in range(world)])

@@ -311,3 +311,30 @@ def test_strided_batch_rejects_what_it_cannot_do(gpu):
         gpu.fft_dit_strided(x, y, 64, gpu.Direction.Forward, p, batch=4, stride=12)
     with pytest.raises(gpu.PhastPanic):    # batch larger than the stride
         gpu.fft_dit_strided(x, y, 64, gpu.Direction.Forward, p, batch=32, stride=16)
+
+
+@pytest.mark.parametrize("k,s,total_log,col0,dt", [(6, 4, 12, 16, "f64"), (10, 5, 20, 96, "f64"), (11, 4, 15, 0, "f64"),
+                                                   (12, 5, 22, 64, "f64"), (16, 4, 24, 48, "f64"), (14, 6, 20, 0, "f32")])
+def test_strided_batch_with_fused_input_twiddle(gpu, oracle, k, s, total_log, col0, dt):
+    """phast_fft_*_dit_strided_tw_dev: x[j][c] *= W_{2^total_log}^(j (col0 + c)) fused into the first pass's load, then the
+    column FFTs -- against the oracle's transform of the explicitly twiddled columns (exact numpy twiddles)."""
+    import torch
+
+    n, stride, big = 1 << k, 1 << s, 1 << total_log
+    ndt, tol = (np.float64, F64_REL) if dt == "f64" else (np.float32, F32_REL)
+    rng = np.random.default_rng(k * 7 + s)
+    h_re = rng.uniform(-1, 1, n * stride).astype(ndt)
+    h_im = rng.uniform(-1, 1, n * stride).astype(ndt)
+    planner = (gpu.PlannerDit64 if dt == "f64" else gpu.PlannerDit32)(n)
+    d_re, d_im = dev(h_re.copy()), dev(h_im.copy())
+    gpu.fft_dit_strided(d_re, d_im, n, gpu.Direction.Forward, planner, batch=stride, stride=stride, twiddle_n=big,
+                        twiddle_col0=col0)
+    g_re, g_im = d_re.cpu().numpy().reshape(n, stride), d_im.cpu().numpy().reshape(n, stride)
+    r2, i2 = h_re.reshape(n, stride).astype(np.float64), h_im.reshape(n, stride).astype(np.float64)
+    j = np.arange(n)
+    for c in sorted({0, 1, stride // 2, stride - 1}):
+        w = np.exp(-2j * np.pi * ((j * (col0 + c)) % big) / big)
+        z = (r2[:, c] + 1j * i2[:, c]) * w
+        r, m = np.ascontiguousarray(z.real), np.ascontiguousarray(z.imag)
+        oracle.fft_64_dit(r, m, oracle.FORWARD)   # the twiddled column in f64 on both sides of the comparison
+        assert rel_l2(g_re[:, c], g_im[:, c], r, m) <= tol, (k, s, c)
