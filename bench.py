@@ -199,20 +199,28 @@ def event_ms(torch, fn):
 # the other single-GPU BASELINE configs, on the driver-run line
 # ------------------------------------------------------------------------------------------------
 def config_n2p26(P, torch, dev, steps: int, cpu: bool):
-    """N = 2^26 f64: forward (the second half of BASELINE's metric) and the forward+inverse round trip (configs[2]).
-    Inputs are regenerated on the device before every timed transform (outside the timed interval)."""
+    """N = 2^26 f64: forward (the second half of BASELINE's metric) and the forward+inverse round trip (configs[2]), each
+    timed step on its own pre-filled buffer of a ring (the headline's protocol)."""
     n = 1 << 26
     pl = P.PlannerDit64(n)
     plan_text = pl.describe()
-    re = torch.empty(n, dtype=torch.float64, device=dev)
-    im = torch.empty_like(re)
+    # the same protocol as the headline: a pre-filled ring of distinct transforms (1 GiB each, so every one is HBM-cold
+    # by construction), one timed in-place transform per buffer -- no fill kernel's write-back tail inside a timed step
+    ring = steps
+    ring_re = torch.empty(ring * n, dtype=torch.float64, device=dev)
+    ring_im = torch.empty_like(ring_re)
+    re, im = ring_re[:n], ring_im[:n]
     P.fill_uniform(re, im, n, seed=0xCAFE)
-    P.fft_64_dit_with_planner(re, im, P.Direction.Forward, pl)  # warm-up: scratch allocation
-    total = 0.0
-    for i in range(steps):
-        P.fill_uniform(re, im, n, seed=0xCAFE, first_id=i)
-        total += event_ms(torch, lambda: P.fft_64_dit_with_planner(re, im, P.Direction.Forward, pl))
-    ms = total / steps
+    for _ in range(3):  # untimed warm-up: scratch allocation, clocks (the CPU legs above left the GPU idle for seconds)
+        P.fft_64_dit_with_planner(re, im, P.Direction.Forward, pl)
+    P.fill_uniform(ring_re, ring_im, n, seed=0xCAFE, first_id=0)
+    torch.cuda.synchronize()
+
+    def forward_all():  # the K timed steps back to back, one event pair around them (as the headline's K-step region)
+        for i in range(steps):
+            P.fft_64_dit_with_planner(ring_re[i * n:(i + 1) * n], ring_im[i * n:(i + 1) * n], P.Direction.Forward, pl)
+
+    ms = event_ms(torch, forward_all) / steps
     P.fill_uniform(re, im, n, seed=0xCAFE)
     pass_ms = pl.time_passes(re, im, n, reps=3)
     used = plan_kind(P, n, 1, plan_text)
@@ -221,18 +229,19 @@ def config_n2p26(P, torch, dev, steps: int, cpu: bool):
            "value": n / (ms * 1e-3) / 1e9, "unit": "GSamples/s", "steps": steps, "ms_per_step": ms, "dtype": "f64",
            "plan": plan_text, "roofline": roof}
     # configs[2]: forward then inverse on the same buffers; the error against the regenerated input is part of it
-    rt_total = 0.0
-    for i in range(steps):
-        P.fill_uniform(re, im, n, seed=0xBEEF, first_id=i)
+    P.fill_uniform(ring_re, ring_im, n, seed=0xBEEF, first_id=0)
+    torch.cuda.synchronize()
+    def roundtrip_all():
+        for i in range(steps):
+            r_i, m_i = ring_re[i * n:(i + 1) * n], ring_im[i * n:(i + 1) * n]
+            P.fft_64_dit_with_planner(r_i, m_i, P.Direction.Forward, pl)
+            P.fft_64_dit_with_planner(r_i, m_i, P.Direction.Reverse, pl)
 
-        def roundtrip():
-            P.fft_64_dit_with_planner(re, im, P.Direction.Forward, pl)
-            P.fft_64_dit_with_planner(re, im, P.Direction.Reverse, pl)
-
-        rt_total += event_ms(torch, roundtrip)
+    rt_total = event_ms(torch, roundtrip_all)
     ref_re, ref_im = torch.empty_like(re), torch.empty_like(im)
     P.fill_uniform(ref_re, ref_im, n, seed=0xBEEF, first_id=steps - 1)
-    err = max(float((re - ref_re).abs().max()), float((im - ref_im).abs().max()))
+    last_re, last_im = ring_re[(steps - 1) * n:steps * n], ring_im[(steps - 1) * n:steps * n]
+    err = max(float((last_re - ref_re).abs().max()), float((last_im - ref_im).abs().max()))
     del ref_re, ref_im
     rt_ms = rt_total / steps
     # one launch of a pass moves 32 B/sample; the round trip is 2 x passes launches
@@ -243,7 +252,7 @@ def config_n2p26(P, torch, dev, steps: int, cpu: bool):
                        "algorithmic_bytes_per_step": 2 * BYTES_PER_SAMPLE * n,
                        "transform_frac": 2 * BYTES_PER_SAMPLE * n / (rt_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                        "note": "same pass kernels as n2p26_forward (the inverse is the swap trick + 1/N in the last store)"}}
-    del re, im, pl
+    del re, im, ring_re, ring_im, last_re, last_im, pl
     torch.cuda.empty_cache()
     if cpu:
         fwd["cpu_baseline"] = cpu_leg("forward", n, 2)
@@ -298,11 +307,14 @@ def shard_on_one_gpu(P, torch, dev, shard: int, steps: int = 5):
     im = torch.empty_like(re)
     P.fill_uniform(re, im, N, seed=0xCAFE, first_id=0)
     P.fft_dit_batched(re, im, N, P.Direction.Forward, pl)  # warm-up (scratch allocation)
-    total = 0.0
-    for i in range(steps):
-        P.fill_uniform(re, im, N, seed=0xCAFE, first_id=0)
-        total += event_ms(torch, lambda: P.fft_dit_batched(re, im, N, P.Direction.Forward, pl))
-    ms = total / steps
+    P.fill_uniform(re, im, N, seed=0xCAFE, first_id=0)
+    torch.cuda.synchronize()
+
+    def all_steps():  # in place step after step, as the --gpus N run does (values grow 2^10-fold per step: 5 steps are safe)
+        for _ in range(steps):
+            P.fft_dit_batched(re, im, N, P.Direction.Forward, pl)
+
+    ms = event_ms(torch, all_steps) / steps
     P.fill_uniform(re, im, N, seed=0xCAFE, first_id=0)
     pass_ms = pl.time_passes(re, im, N, reps=2)
     plan_text = pl.describe()
