@@ -292,6 +292,10 @@ def config_r2c(P, torch, dev, steps: int, cpu: bool):
     out = {"workload": "r2c_fft_f32 N=2^24, real input -> N/2+1 planar outputs (BASELINE configs[3])",
            "value": n / (ms * 1e-3) / 1e9, "unit": "GSamples/s (real samples)", "steps": steps, "ms_per_step": ms,
            "dtype": "f32", "plan": plan_text, "roofline": roof}
+    tags = kernel_tags(plan_of(plan_text, plan_kind(P, n // 2, 1, plan_text)), "float")
+    tr = traffic_for("r2c_f32_2p24", ["untangle_kernel"] if dom == len(pass_ms) - 1 else [tags[dom]]) if dom < len(tags) + 1 else None
+    if tr:
+        roof.update(tr)
     del x, ore, oim, pl
     if cpu:
         out["cpu_baseline"] = cpu_leg("r2c_f32", n, 8)
@@ -319,7 +323,12 @@ def shard_on_one_gpu(P, torch, dev, shard: int, steps: int = 5):
     pass_ms = pl.time_passes(re, im, N, reps=2)
     plan_text = pl.describe()
     used = plan_kind(P, N, shard, plan_text)
-    roof, _ = roofline_of(pass_ms, BYTES_PER_SAMPLE * N * shard, plan_used=f"{used} plan {plan_of(plan_text, used)}")
+    roof, dom = roofline_of(pass_ms, BYTES_PER_SAMPLE * N * shard, plan_used=f"{used} plan {plan_of(plan_text, used)}")
+    tags = kernel_tags(plan_of(plan_text, used))
+    tr = traffic_for("batch_2p20", [tags[dom]], scale=shard / 256.0) if dom < len(tags) else None  # profiled per 256-transform launch
+    if tr:
+        roof.update(tr)
+        roof["traffic_note"] = "PMC bytes of one 256-transform launch scaled to the shard (the shard runs as chunks of 256)"
     return {"workload": f"{shard} independent f64 forward FFTs N=2^{LOG_N} on 1 GPU, in place (one rank's shard of "
                         f"BASELINE configs[4])", "value": shard * N / (ms * 1e-3) / 1e9, "unit": "GSamples/s",
             "steps": steps, "ms_per_step": ms, "roofline": roof}
@@ -589,6 +598,18 @@ def load_profiled_traffic(n_gpus, dom, n_passes, tags):
         return None
     return {"traffic": picked[dom]["hbm_bytes_per_launch"], "traffic_source": t[key]["source"],
             "traffic_kernel": picked[dom]["kernel"]}
+
+
+def traffic_for(key, substrings, scale=1.0):
+    """traffic of the profiled kernel whose name contains every one of `substrings` (None if absent / ambiguous)"""
+    t = _traffic_file()
+    if not t or key not in t:
+        return None
+    hits = [k for k in t[key].get("kernels", []) if all(x in k["kernel"] for x in substrings)]
+    if len(hits) != 1:
+        return None
+    return {"traffic": hits[0]["hbm_bytes_per_launch"] * scale, "traffic_source": t[key]["source"],
+            "traffic_kernel": hits[0]["kernel"]}
 
 
 def load_profiled_traffic_key(key, roofline):
