@@ -191,6 +191,21 @@ template <typename T, bool PRE_TW, bool TRANSPOSE> struct WaveBody {
 };
 
 // ---- the exchange on the GPU: lane bits (5, 4) <-> register bits (1, 0), one VALU swap per dword pair ----
+// -DPHAST_WAVE_XCHG_BPERMUTE builds the same exchange from ds_bpermute_b32 (the LDS crossbar without the memory: two
+// selects + one DS instruction + an lgkmcnt wait per dword pair) for comparison -- tools/ and profiles/r02_wave_xchg.log:
+// the swap instructions are what the product uses.
+#ifdef PHAST_WAVE_XCHG_BPERMUTE
+template <int BIT> __device__ __forceinline__ void swap_via_bpermute(unsigned &a, unsigned &b) {
+    const unsigned lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const bool up = (lane & BIT) != 0;
+    const unsigned send = up ? a : b;  // the upper lane gives its `a`, the lower lane its `b`
+    const unsigned recv = (unsigned)__builtin_amdgcn_ds_bpermute((int)((lane ^ BIT) << 2), (int)send);
+    if (up) a = recv;
+    else b = recv;
+}
+__device__ __forceinline__ void swap_lane_halves(unsigned &a, unsigned &b) { swap_via_bpermute<32>(a, b); }
+__device__ __forceinline__ void swap_lane_rows(unsigned &a, unsigned &b) { swap_via_bpermute<16>(a, b); }
+#else
 __device__ __forceinline__ void swap_lane_halves(unsigned &a, unsigned &b) {  // a.lanes[32..63] <-> b.lanes[0..31]
     auto v = __builtin_amdgcn_permlane32_swap(a, b, false, false);
     a = v[0];
@@ -201,6 +216,7 @@ __device__ __forceinline__ void swap_lane_rows(unsigned &a, unsigned &b) {  // a
     a = v[0];
     b = v[1];
 }
+#endif
 template <bool HALVES> __device__ __forceinline__ void swap_pair(double &a, double &b) {
     unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a);
     unsigned blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
