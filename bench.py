@@ -121,7 +121,7 @@ def plan_of(plan_text: str, kind: str) -> str:
     return m.group(1) if m else plan_text
 
 
-def plan_kind(P, n: int, batch: int, plan_text: str) -> str:
+def plan_kind(P, n: int, batch: int, plan_text: str, dtype: str = "f64") -> str:
     """which of the planner's plans a call with `batch` transforms runs (api.hip: Planner::plan_for)"""
     if "latency=" not in plan_text:
         return "throughput" if "throughput=" in plan_text else "one-pass"
@@ -130,6 +130,8 @@ def plan_kind(P, n: int, batch: int, plan_text: str) -> str:
     tiles = [int(r) * int(c) for r, c in re.findall(r"\[(\d+)x(\d+)", plan_of(plan_text, "throughput"))]
     tl = max(t.bit_length() - 1 for t in tiles)
     work = 1 << (25 if tl >= 15 else 24 if tl >= 13 else 22)   # plan.hpp: throughput_work
+    if "f32" in dtype and tl < 15:
+        work *= 2                                                # api.hip: plan_for
     if batch * n >= work:
         return "throughput"
     return "mid" if (batch > 1 and "mid=" in plan_text) else "latency"
@@ -292,7 +294,7 @@ def config_r2c(P, torch, dev, steps: int, cpu: bool):
     out = {"workload": "r2c_fft_f32 N=2^24, real input -> N/2+1 planar outputs (BASELINE configs[3])",
            "value": n / (ms * 1e-3) / 1e9, "unit": "GSamples/s (real samples)", "steps": steps, "ms_per_step": ms,
            "dtype": "f32", "plan": plan_text, "roofline": roof}
-    tags = kernel_tags(plan_of(plan_text, plan_kind(P, n // 2, 1, plan_text)), "float")
+    tags = kernel_tags(plan_of(plan_text, plan_kind(P, n // 2, 1, plan_text, "f32")), "float")
     tr = traffic_for("r2c_f32_2p24", ["untangle_kernel"] if dom == len(pass_ms) - 1 else [tags[dom]]) if dom < len(tags) + 1 else None
     if tr:
         roof.update(tr)

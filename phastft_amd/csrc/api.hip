@@ -273,7 +273,9 @@ template <typename T> struct Planner {
         if (passes_lat.empty() || passes.empty()) return passes;
         unsigned tl = 0;
         for (const PassDesc &p : passes) tl = std::max(tl, p.lr + p.lc);
-        if (batch * n >= throughput_work(tl)) return passes;
+        // 4-byte elements: the same tile holds half the bytes, and the measured crossover sits one octave higher (one f32
+        // transform of 2^24 points: 149.7 us on the latency tiles, 180.0 on the throughput tiles)
+        if (batch * n >= throughput_work(tl) * (sizeof(T) == 4 && tl < 15 ? 2 : 1)) return passes;
         if (batch > 1 && !passes_mid.empty()) return passes_mid;
         return passes_lat;
     }

@@ -175,6 +175,15 @@ inline void heuristic_plan(unsigned L, bool latency, std::vector<unsigned> &lrs,
         lp = p[6] | kWaveTiles;
         return;
     }
+    if (latency && !f64 && (L == 22 || L == 23)) {
+        // round 2, one f32 transform (profiles/r02_sweep_f32_single.log): 2^22 43.7 us with 128x64 / 256x32 / 128x64 tiles at
+        // 16 points per thread (54.0 with the 4096-point tiles), 2^23 80.6 (85.3); 2^24 runs the 4096-point latency tiles
+        // instead of the throughput plan (149.7 vs 180.0 us, see plan_for)
+        lrs = L == 22 ? std::vector<unsigned>{7, 8, 7} : std::vector<unsigned>{8, 8, 7};
+        tls.assign(1, L == 22 ? 13 : 12);
+        lp = 4;
+        return;
+    }
     if (latency) {
         split(L <= 19 ? 2 : 3);
         // three passes: short outer FFTs (64 x 64 tiles: 512-byte rows) around a longer middle one; measured
