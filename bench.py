@@ -544,6 +544,9 @@ def main():
                                                  "sampled transforms vs digests of the CPU oracle's output; rank 0's numbers")
         traffic = load_profiled_traffic(n_gpus, dom, len(pass_ms), kernel_tags(plan_list))
         if traffic is not None:
+            if n_gpus > 1:  # profiled per 256-transform launch; kernel_ms / algorithmic bytes here are per pass over the shard
+                traffic["traffic"] *= units / 256.0
+                traffic["traffic_note"] = "PMC bytes of one 256-transform launch scaled to the shard"
             roofline.update(traffic)
         if n_gpus == 1:
             probe = hbm_copy_probe(torch, dev)
