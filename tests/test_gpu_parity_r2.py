@@ -338,3 +338,29 @@ def test_strided_batch_with_fused_input_twiddle(gpu, oracle, k, s, total_log, co
         r, m = np.ascontiguousarray(z.real), np.ascontiguousarray(z.imag)
         oracle.fft_64_dit(r, m, oracle.FORWARD)   # the twiddled column in f64 on both sides of the comparison
         assert rel_l2(g_re[:, c], g_im[:, c], r, m) <= tol, (k, s, c)
+
+
+@pytest.mark.parametrize("k", [21, 22, 23, 24])
+def test_real_transforms_f64_through_wave_and_quad_plans(gpu, oracle, k):
+    """One f64 real transform whose inner N/2-point complex transform runs a wave-/quad-tile latency plan (2^20 … 2^23):
+    the first pass reads the real signal as (even, odd) pairs (wave tiles or generic), the last pass of C2R stores (im, re)
+    pairs scaled by 1/(N/2) (wave tiles / the four-wave kernel).  R2C against an independent rfft (1e-13) and the oracle
+    (1e-9: its twiddle drift), C2R against the oracle and the independent model."""
+    n = 1 << k
+    x, _ = oracle.fill(n, np.float64, seed=0xFACE, transform_id=k)
+    planner = gpu.PlannerR2c64(n)
+    lat = planner.describe().split("latency=")[1]
+    assert " w16 " in lat or " q16 " in lat, lat
+    ore, oim = np.zeros(n // 2 + 1), np.zeros(n // 2 + 1)
+    gpu.r2c_fft_f64_with_planner(x, ore, oim, planner)
+    ref = np.fft.rfft(x)
+    assert rel_l2(ore, oim, ref.real, ref.imag) <= F64_REL, k
+    w_re, w_im = np.zeros(n // 2 + 1), np.zeros(n // 2 + 1)
+    oracle.r2c_fft_f64(x.copy(), w_re, w_im)
+    assert rel_l2(ore, oim, w_re, w_im) <= 1e-9, k
+    s_re, s_im = _spectrum(n, np.float64, 4000 + k)
+    got, want = np.zeros(n), np.zeros(n)
+    gpu.c2r_fft_f64_with_planner(s_re, s_im, got, planner)
+    oracle.c2r_fft_f64(s_re.copy(), s_im.copy(), want)
+    assert rel_l2_real(got, want) <= 1e-9, k
+    assert rel_l2_real(got, c2r_model(s_re, s_im, n)) <= F64_REL, k
