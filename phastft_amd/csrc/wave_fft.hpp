@@ -178,7 +178,6 @@ template <typename T, bool PRE_TW, bool TRANSPOSE> struct WaveBody {
         });
     }
     // pass A: through the wave-private buffer [col][k], then register Q holds row k = lane of column Q
-    PHAST_HD static int xp_waddr(int lane, int Q_k) { return col_of(lane) * CS + Q_k; }
     template <int Q> PHAST_HD static int xp_write_addr(int lane) {
         return col_of(lane) * CS + (int)krow_lane(lane) + (int)krow_const<Q>();
     }
