@@ -32,7 +32,10 @@ template <typename T, bool PRE_TW, bool TRANSPOSE> struct WaveBody {
     using cx = cx_t<T>;
     static constexpr int LR = 6, LC = 4, LP = 4;
     static constexpr int ROWS = 64, COLS = 16, P = 16, TAUS = 4;
-    static constexpr int WAVES = 4, NT = 64 * WAVES;  // tiles (= waves) per workgroup
+#ifndef PHAST_WAVE_TILES_PER_BLOCK
+#define PHAST_WAVE_TILES_PER_BLOCK 4
+#endif
+    static constexpr int WAVES = PHAST_WAVE_TILES_PER_BLOCK, NT = 64 * WAVES;  // tiles (= waves) per workgroup
     static constexpr int CS = ROWS + 1;               // column pitch of the transposing buffer: odd => conflict-free
     static constexpr int XP = TRANSPOSE ? COLS * CS : 0;  // elements per plane per wave
     static constexpr bool NT_HINT = COLS * sizeof(T) >= 128;
@@ -254,7 +257,7 @@ template <typename T> __device__ __forceinline__ void wave_exchange(T (&re)[16],
 }
 
 template <typename T, bool PRE_TW, bool TRANSPOSE>
-__global__ void __launch_bounds__(256) wave_fft_kernel(const TileArgs a, unsigned blocks_total) {
+__global__ void __launch_bounds__(64 * PHAST_WAVE_TILES_PER_BLOCK) wave_fft_kernel(const TileArgs a, unsigned blocks_total) {
     using Body = WaveBody<T, PRE_TW, TRANSPOSE>;
     using cx = cx_t<T>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
