@@ -134,6 +134,8 @@ def plan_kind(P, n: int, batch: int, plan_text: str, dtype: str = "f64") -> str:
         work *= 2                                                # api.hip: plan_for
     if batch * n >= work:
         return "throughput"
+    if batch <= 2 and "single=" in plan_text:
+        return "single"
     return "mid" if (batch > 1 and "mid=" in plan_text) else "latency"
 
 

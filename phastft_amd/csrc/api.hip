@@ -165,6 +165,7 @@ template <typename T> struct Planner {
     std::vector<PassDesc> passes;      // throughput plan; empty => small path
     std::vector<PassDesc> passes_lat;  // latency plan (one small transform); may equal `passes`
     std::vector<PassDesc> passes_mid;  // a few transforms in flight, where that wants a plan of its own (plan.hpp)
+    std::vector<PassDesc> passes_one;  // ONE (or two) transforms: wave / quad tiles etc. (plan.hpp: single_plan)
     void *d_small_tw = nullptr;
     mutable T *d_scratch = nullptr;  // [cap][2][n]: re plane then im plane per transform
     mutable size_t scratch_cap = 0;
@@ -248,6 +249,7 @@ template <typename T> struct Planner {
         free_passes(passes);
         free_passes(passes_lat);
         free_passes(passes_mid);
+        free_passes(passes_one);
     }
     void release() {
         release_passes();
@@ -276,11 +278,13 @@ template <typename T> struct Planner {
         // 4-byte elements: the same tile holds half the bytes, and the measured crossover sits one octave higher (one f32
         // transform of 2^24 points: 149.7 us on the latency tiles, 180.0 on the throughput tiles)
         if (batch * n >= throughput_work(tl) * (sizeof(T) == 4 && tl < 15 ? 2 : 1)) return passes;
+        if (batch <= 2 && !passes_one.empty()) return passes_one;
         if (batch > 1 && !passes_mid.empty()) return passes_mid;
         return passes_lat;
     }
 
-    // which: 0 = one plan for every batch size, 1 = throughput plan only, 2 = latency plan only, 3 = mid plan only;
+    // which: 0 = one plan for every batch size, 1 = throughput plan only, 2 = latency plan only, 3 = mid plan only,
+    // 4 = the plan for one transform;
     // lp = log2(points per thread)
     int set_plan(const std::vector<unsigned> &lrs, const std::vector<unsigned> &tls, int which = 0, unsigned lp = 4) {
         std::vector<PassGeom> geo;
@@ -302,12 +306,16 @@ template <typename T> struct Planner {
         } else if (which == 3) {
             retire_passes(passes_mid);
             passes_mid = std::move(ps);
+        } else if (which == 4) {
+            retire_passes(passes_one);
+            passes_one = std::move(ps);
         } else {
             retire_passes(passes);
             passes = std::move(ps);
             if (which == 0) {  // one plan for every batch size
                 retire_passes(passes_lat);
                 retire_passes(passes_mid);
+                retire_passes(passes_one);
             }
         }
         table_bytes = tb;
@@ -347,6 +355,10 @@ template <typename T> struct Planner {
         if (rc != PHAST_OK && rc != PHAST_ERR_INVALID_ARG) return rc;
         if (mid_plan<T>(log_n, lrs, tls, lp)) {
             rc = set_plan(lrs, tls, 3, lp);
+            if (rc != PHAST_OK && rc != PHAST_ERR_INVALID_ARG) return rc;
+        }
+        if (single_plan<T>(log_n, lrs, tls, lp)) {
+            rc = set_plan(lrs, tls, 4, lp);
             if (rc != PHAST_OK && rc != PHAST_ERR_INVALID_ARG) return rc;
         }
         return PHAST_OK;
@@ -496,6 +508,7 @@ template <typename T> struct Planner {
         add("throughput", passes);
         if (!passes_mid.empty()) add("mid", passes_mid);
         if (!passes_lat.empty()) add("latency", passes_lat);
+        if (!passes_one.empty()) add("single", passes_one);
         return s;
     }
 

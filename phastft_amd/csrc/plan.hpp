@@ -161,29 +161,6 @@ inline void heuristic_plan(unsigned L, bool latency, std::vector<unsigned> &lrs,
         for (unsigned i = 0; i < np; ++i) lrs.push_back(L / np + (i < L % np ? 1 : 0));  // balanced, larger first
     };
     const bool f64 = sizeof(T) == 8;
-    if (latency && f64 && L >= 19 && L <= 23) {
-        // round 2 (profiles/r02_sweep_wave_quad_single.log): one f64 transform of 2^19..2^23 points as three passes built
-        // from WAVE tiles (64 x 16, one wave, cross-lane swaps: wave_fft.hpp) and the four-wave 256 x 16 kernel
-        // (quad_fft.hpp), generic LDS tiles for the 128-row passes and 256-row first passes:
-        //   2^19 22.9 us (two 1024/512-row passes: 27.4), 2^20 26.5 (27.4 .. 29.7), 2^21 42.3 (43.5), 2^22 82.1 (98.7),
-        //   2^23 182.7 (188.4)
-        static const unsigned plans[5][7] = {
-            {6, 7, 6, 10, 11, 10, 3}, {6, 8, 6, 10, 12, 10, 3}, {8, 7, 6, 12, 12, 10, 3}, {8, 8, 6, 13, 12, 10, 4}, {8, 7, 8, 12, 12, 12, 3}};
-        const unsigned *p = plans[L - 19];
-        lrs = {p[0], p[1], p[2]};
-        tls = {p[3], p[4], p[5]};
-        lp = p[6] | kWaveTiles;
-        return;
-    }
-    if (latency && !f64 && (L == 22 || L == 23)) {
-        // round 2, one f32 transform (profiles/r02_sweep_f32_single.log): 2^22 43.7 us with 128x64 / 256x32 / 128x64 tiles at
-        // 16 points per thread (54.0 with the 4096-point tiles), 2^23 80.6 (85.3); 2^24 runs the 4096-point latency tiles
-        // instead of the throughput plan (149.7 vs 180.0 us, see plan_for)
-        lrs = L == 22 ? std::vector<unsigned>{7, 8, 7} : std::vector<unsigned>{8, 8, 7};
-        tls.assign(1, L == 22 ? 13 : 12);
-        lp = 4;
-        return;
-    }
     if (latency) {
         split(L <= 19 ? 2 : 3);
         // three passes: short outer FFTs (64 x 64 tiles: 512-byte rows) around a longer middle one; measured
@@ -219,6 +196,39 @@ inline void heuristic_plan(unsigned L, bool latency, std::vector<unsigned> &lrs,
         tls.assign(1, 13);
         lp = 5;
     }
+}
+
+// The plan for ONE transform (and two): round 2.  Measured with one transform in flight only -- with four or more the
+// older latency / mid plans win again (2^19 x 8: 48 GSamples/s on these against 69 on the two-pass latency plan,
+// profiles/r02_sweep_batch_wave_quad.log), so Planner::plan_for uses it for batch <= 2.  Returns false where the latency
+// plan already is the right one.
+template <typename T>
+inline bool single_plan(unsigned L, std::vector<unsigned> &lrs, std::vector<unsigned> &tls, unsigned &lp) {
+    const bool f64 = sizeof(T) == 8;
+    if (f64 && L >= 19 && L <= 23) {
+        // one f64 transform of 2^19..2^23 points as three passes built from WAVE tiles (64 x 16, one wave, cross-lane
+        // swaps: wave_fft.hpp) and the four-wave 256 x 16 kernel (quad_fft.hpp), generic LDS tiles for the 128-row passes
+        // and 256-row first passes (profiles/r02_sweep_wave_quad_single.log):
+        //   2^19 22.9 us (two 1024/512-row passes: 27.4), 2^20 26.5 (27.4 .. 29.7), 2^21 42.3 (43.5), 2^22 82.1 (98.7),
+        //   2^23 182.7 (188.4)
+        static const unsigned plans[5][7] = {
+            {6, 7, 6, 10, 11, 10, 3}, {6, 8, 6, 10, 12, 10, 3}, {8, 7, 6, 12, 12, 10, 3}, {8, 8, 6, 13, 12, 10, 4}, {8, 7, 8, 12, 12, 12, 3}};
+        const unsigned *p = plans[L - 19];
+        lrs = {p[0], p[1], p[2]};
+        tls = {p[3], p[4], p[5]};
+        lp = p[6] | kWaveTiles;
+        return true;
+    }
+    if (!f64 && (L == 22 || L == 23)) {
+        // one f32 transform (profiles/r02_sweep_f32_single.log): 2^22 43.7 us with 128x64 / 256x32 / 128x64 tiles at
+        // 16 points per thread (54.0 with the 4096-point tiles), 2^23 80.6 (85.3); 2^24 runs the 4096-point latency tiles
+        // instead of the throughput plan (149.7 vs 180.0 us, see plan_for)
+        lrs = L == 22 ? std::vector<unsigned>{7, 8, 7} : std::vector<unsigned>{8, 8, 7};
+        tls.assign(1, L == 22 ? 13 : 12);
+        lp = 4;
+        return true;
+    }
+    return false;
 }
 
 // A third plan for "a few transforms in flight" where neither of the two above fits: N = 2^20, whose latency plan

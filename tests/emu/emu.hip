@@ -49,7 +49,9 @@ static int emu_exec(const void *in_re, const void *in_im, unsigned in_mode, void
     const unsigned tile_log = tile_log_and_lp & 0xff;
     unsigned lp = (tile_log_and_lp >> 8) ? (tile_log_and_lp >> 8) : 4;
     std::vector<unsigned> lrs(lrs_in, lrs_in + np_in), tls(1, tile_log);
-    if (lrs.empty()) heuristic_plan<T>(log_n, tile_log == 0, lrs, tls, lp);  // tile_log 0 = latency plan
+    if (lrs.empty()) {  // the library's own plans: tile_log 0 = latency plan, 1 = the plan for one transform, else throughput
+        if (tile_log != 1 || !single_plan<T>(log_n, lrs, tls, lp)) heuristic_plan<T>(log_n, tile_log <= 1, lrs, tls, lp);
+    }
     std::vector<PassGeom> ps;
     if (!make_passes(log_n, lrs, tls, ps, lp, sizeof(T))) return 1;
     std::vector<T> s_re(n * batch), s_im(n * batch);

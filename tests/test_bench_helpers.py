@@ -11,33 +11,37 @@ import bench  # noqa: E402
 
 PLAN_20 = ("n=2^20 throughput=2p[1024x16A p32 lds=136192 wg/cu=1][1024x16 p32 lds=142336 wg/cu=1] "
            "mid=2p[1024x8A p16 lds=70656 wg/cu=2][1024x8 p16 lds=76800 wg/cu=2] "
-           "latency=3p[64x16A w16 lds=67072 wg/cu=2][256x16 q16 lds=69120 wg/cu=2][64x16 w16 lds=6656 wg/cu=4]")
+           "latency=3p[64x64A p8 lds=67584 wg/cu=2][256x16 p8 lds=76288 wg/cu=2][64x64 p8 lds=72704 wg/cu=2] "
+           "single=3p[64x16A w16 lds=67072 wg/cu=2][256x16 q16 lds=69120 wg/cu=2][64x16 w16 lds=6656 wg/cu=4]")
 PLAN_R2C = ("n=2^23 throughput=3p[256x32A p16 lds=66304 wg/cu=2][256x32 p16 lds=67584 wg/cu=2][128x64 p16 lds=72192 wg/cu=2] "
-            "latency=3p[256x16A p16 lds=35328 wg/cu=4][256x16 p16 lds=36864 wg/cu=4][128x32 p16 lds=39936 wg/cu=4]")
+            "latency=3p[256x16A p8 lds=37376 wg/cu=4][256x16 p8 lds=38912 wg/cu=4][128x32 p8 lds=39424 wg/cu=4] "
+            "single=3p[256x16A p16 lds=35328 wg/cu=4][256x16 p16 lds=36864 wg/cu=4][128x32 p16 lds=39936 wg/cu=4]")
 
 
 def test_plan_kind_follows_the_library():
     n = 1 << 20
-    assert bench.plan_kind(None, n, 1, PLAN_20) == "latency"
-    assert bench.plan_kind(None, n, 2, PLAN_20) == "mid"
+    assert bench.plan_kind(None, n, 1, PLAN_20) == "single"
+    assert bench.plan_kind(None, n, 2, PLAN_20) == "single"
+    assert bench.plan_kind(None, n, 3, PLAN_20) == "mid"
     assert bench.plan_kind(None, n, 15, PLAN_20) == "mid"
+    assert bench.plan_kind(None, n, 1, PLAN_20.split(" single=")[0]) == "latency"
     assert bench.plan_kind(None, n, 16, PLAN_20) == "throughput"      # 2^24 points in flight, 16384-point tiles
     assert bench.plan_kind(None, n, 1024, PLAN_20) == "throughput"
-    assert bench.plan_kind(None, 1 << 23, 1, PLAN_R2C, "f32") == "latency"
-    assert bench.plan_kind(None, 1 << 23, 2, PLAN_R2C, "f32") == "latency"   # f32: the crossover sits one octave higher
+    assert bench.plan_kind(None, 1 << 23, 1, PLAN_R2C, "f32") == "single"
+    assert bench.plan_kind(None, 1 << 23, 3, PLAN_R2C, "f32") == "latency"   # f32: the crossover sits one octave higher
     assert bench.plan_kind(None, 1 << 23, 4, PLAN_R2C, "f32") == "throughput"
     assert bench.plan_kind(None, 1 << 10, 64, "n=2^10 one pass (whole transforms on chip)") == "one-pass"
 
 
 def test_plan_lists_and_kernel_names():
-    lat = bench.plan_of(PLAN_20, "latency")
+    lat = bench.plan_of(PLAN_20, "single")
     assert lat.startswith("[64x16A w16") and lat.count("[") == 3
     assert bench.kernel_tags(lat) == ["wave_fft_kernel<double, false, true>", "quad_fft_kernel<double>",
                                       "wave_fft_kernel<double, true, false>"]
     thr = bench.plan_of(PLAN_20, "throughput")
     assert bench.kernel_tags(thr) == ["tile_fft_kernel<double, 10, 4, 5, false, true,",
                                       "tile_fft_kernel<double, 10, 4, 5, true, false,"]
-    assert bench.kernel_tags(bench.plan_of(PLAN_R2C, "latency"), "float")[2] == "tile_fft_kernel<float, 7, 5, 4, true, false,"
+    assert bench.kernel_tags(bench.plan_of(PLAN_R2C, "single"), "float")[2] == "tile_fft_kernel<float, 7, 5, 4, true, false,"
 
 
 def test_committed_traffic_profile_matches_the_default_plans():
@@ -45,7 +49,7 @@ def test_committed_traffic_profile_matches_the_default_plans():
     t = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
     for key in ("single_2p20", "single_2p26", "r2c_f32_2p24", "batch_2p20"):
         assert key in t and t[key]["kernels"], key
-    tr = bench.load_profiled_traffic(1, 1, 3, bench.kernel_tags(bench.plan_of(PLAN_20, "latency")))
+    tr = bench.load_profiled_traffic(1, 1, 3, bench.kernel_tags(bench.plan_of(PLAN_20, "single")))
     assert tr is not None and "quad_fft_kernel" in tr["traffic_kernel"]
     assert 1.0 <= tr["traffic"] / 33554432 < 1.02       # HBM bytes ~ algorithmic bytes
     tb = bench.load_profiled_traffic(8, 0, 2, bench.kernel_tags(bench.plan_of(PLAN_20, "throughput")))

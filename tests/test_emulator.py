@@ -79,7 +79,7 @@ def test_forced_plans_vs_oracle_f64(emu, oracle, L, lrs, tl, lp):
 def test_default_plans_both_types_and_inverse(emu, oracle, L):
     n = 1 << L
     for is_f64, dtype, tol, ofn in ((1, np.float64, 1e-13, oracle.fft_64_dit), (0, np.float32, 1e-5, oracle.fft_32_dit)):
-        for latency in (0, 1):
+        for latency in (0, 1, 2):  # throughput plan, latency plan, the plan for ONE transform (wave / quad tiles; 2^19..2^23)
             lrs = (C.c_uint * 3)()
             tl, lp = C.c_uint(), C.c_uint()
             npass = emu.phast_emu_default_plan(is_f64, latency, L, lrs, C.byref(tl), C.byref(lp))
@@ -89,7 +89,7 @@ def test_default_plans_both_types_and_inverse(emu, oracle, L):
             direction = -1 if latency else 1
             # lrs = () lets the emulator take the library's own heuristic plan (incl. per-pass tile sizes and wave
             # tiles): tile_log 0 selects the latency plan, anything else the throughput plan
-            assert run(emu, a, b, direction, (), 0 if latency else 12, 0) == 0
+            assert run(emu, a, b, direction, (), (12, 0, 1)[latency], 0) == 0
             ofn(re, im, oracle.REVERSE if latency else oracle.FORWARD)
             err = np.sqrt(np.sum((a.astype(np.float64) - re) ** 2 + (b.astype(np.float64) - im) ** 2) /
                           np.sum(re.astype(np.float64) ** 2 + im.astype(np.float64) ** 2))

@@ -711,6 +711,6 @@ def test_wave_tiles_all_passes_batched_inverse_and_interleaved(gpu, oracle):
     assert rel_l2(h.real.copy(), h.imag.copy(), r, m) <= F64_REL
     # the default latency plans of 2^18 and 2^20 ARE wave-tile plans
     for k in (19, 20, 21, 22, 23):
-        lat = gpu.PlannerDit64(1 << k).describe().split("latency=")[1]
+        lat = gpu.PlannerDit64(1 << k).describe().split("single=")[1]
         assert " w16 " in lat or " q16 " in lat, (k, lat)
-    assert " q16 " in gpu.PlannerDit64(1 << 20).describe().split("latency=")[1]
+    assert " q16 " in gpu.PlannerDit64(1 << 20).describe().split("single=")[1]

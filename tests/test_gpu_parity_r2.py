@@ -349,7 +349,7 @@ def test_real_transforms_f64_through_wave_and_quad_plans(gpu, oracle, k):
     n = 1 << k
     x, _ = oracle.fill(n, np.float64, seed=0xFACE, transform_id=k)
     planner = gpu.PlannerR2c64(n)
-    lat = planner.describe().split("latency=")[1]
+    lat = planner.describe().split("single=")[1]
     assert " w16 " in lat or " q16 " in lat, lat
     ore, oim = np.zeros(n // 2 + 1), np.zeros(n // 2 + 1)
     gpu.r2c_fft_f64_with_planner(x, ore, oim, planner)
