@@ -49,7 +49,14 @@ template <typename T> struct QuadBody {
     static constexpr int LR = 8, LC = 4, ROWS = 256, COLS = 16, P = 16, WAVES = 4, NT = 256;
     static constexpr int EXCH = P * NT;  // elements per plane of the exchange buffer [register][wave][lane]
     static constexpr int TWQ = 128;      // staged entries of the step-twiddle table: W_256^j (j < 64), then W_64^j (j < 64)
-    static constexpr bool NT_HINT = COLS * sizeof(T) >= 128;
+#ifndef PHAST_WQ_NT_LOADS
+#define PHAST_WQ_NT_LOADS 1
+#endif
+#ifndef PHAST_WQ_NT_STORES
+#define PHAST_WQ_NT_STORES 1
+#endif
+    static constexpr bool NT_LOAD = PHAST_WQ_NT_LOADS && COLS * sizeof(T) >= 128;
+    static constexpr bool NT_STORE = PHAST_WQ_NT_STORES && COLS * sizeof(T) >= 128;
 
     struct Regs {
         T re[P], im[P];
@@ -80,7 +87,7 @@ template <typename T> struct QuadBody {
         static_for<0, P>([&](auto q) {
             constexpr int Q = decltype(q)::value;
             const size_t urow = (size_t)(64 * (Q >> 2) + 16 * (Q & 3)) << a.log_s_in;
-            if constexpr (NT_HINT) {
+            if constexpr (NT_LOAD) {
                 r.re[Q] = __builtin_nontemporal_load(pr + urow + voff);
                 r.im[Q] = __builtin_nontemporal_load(pi + urow + voff);
             } else {
@@ -179,7 +186,7 @@ template <typename T> struct QuadBody {
         static_for<0, P>([&](auto Q) {
             const size_t at = base + (size_t)krow_const<decltype(Q)::value>() * a.out_row_stride + voff;
             if (!a.out_interleaved) {
-                if constexpr (NT_HINT) {
+                if constexpr (NT_STORE) {
                     __builtin_nontemporal_store(r.re[Q] * scale, reinterpret_cast<T *>(a.out_re) + at);
                     __builtin_nontemporal_store(r.im[Q] * scale, reinterpret_cast<T *>(a.out_im) + at);
                 } else {

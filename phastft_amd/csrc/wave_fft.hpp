@@ -39,7 +39,14 @@ template <typename T, bool PRE_TW, bool TRANSPOSE> struct WaveBody {
     static constexpr int WAVES = PHAST_WAVE_TILES_PER_BLOCK, NT = 64 * WAVES;  // tiles (= waves) per workgroup
     static constexpr int CS = ROWS + 1;               // column pitch of the transposing buffer: odd => conflict-free
     static constexpr int XP = TRANSPOSE ? COLS * CS : 0;  // elements per plane per wave
-    static constexpr bool NT_HINT = COLS * sizeof(T) >= 128;
+#ifndef PHAST_WQ_NT_LOADS
+#define PHAST_WQ_NT_LOADS 1
+#endif
+#ifndef PHAST_WQ_NT_STORES
+#define PHAST_WQ_NT_STORES 1
+#endif
+    static constexpr bool NT_LOAD = PHAST_WQ_NT_LOADS && COLS * sizeof(T) >= 128;
+    static constexpr bool NT_STORE = PHAST_WQ_NT_STORES && COLS * sizeof(T) >= 128;
 
     struct Regs {
         T re[P], im[P];
@@ -74,7 +81,7 @@ template <typename T, bool PRE_TW, bool TRANSPOSE> struct WaveBody {
             const T *pi = reinterpret_cast<const T *>(a.in_im) + ubase;
             static_for<0, P>([&](auto j) {
                 const size_t urow = (size_t)(decltype(j)::value * TAUS) << a.log_s_in;
-                if constexpr (NT_HINT) {
+                if constexpr (NT_LOAD) {
                     r.re[j] = __builtin_nontemporal_load(pr + urow + voff);
                     r.im[j] = __builtin_nontemporal_load(pi + urow + voff);
                 } else {
@@ -159,7 +166,7 @@ template <typename T, bool PRE_TW, bool TRANSPOSE> struct WaveBody {
     PHAST_HD static void put(const TileArgs &a, size_t ubase, unsigned voff, T re, T im) {
         const T scale = (T)a.scale;
         if (TRANSPOSE || !a.out_interleaved) {
-            if constexpr (NT_HINT) {
+            if constexpr (NT_STORE) {
                 __builtin_nontemporal_store(re * scale, reinterpret_cast<T *>(a.out_re) + ubase + voff);
                 __builtin_nontemporal_store(im * scale, reinterpret_cast<T *>(a.out_im) + ubase + voff);
             } else {
