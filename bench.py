@@ -332,7 +332,7 @@ def shard_on_one_gpu(P, torch, dev, shard: int, steps: int = 5):
     tr = traffic_for("batch_2p20", [tags[dom]], scale=shard / 256.0) if dom < len(tags) else None  # profiled per 256-transform launch
     if tr:
         roof.update(tr)
-        roof["traffic_note"] = "PMC bytes of one 256-transform launch scaled to the shard (the shard runs as chunks of 256)"
+        roof["traffic_note"] = "PMC bytes of one 256-transform launch of the same kernel, scaled to the shard"
     return {"workload": f"{shard} independent f64 forward FFTs N=2^{LOG_N} on 1 GPU, in place (one rank's shard of "
                         f"BASELINE configs[4])", "value": shard * N / (ms * 1e-3) / 1e9, "unit": "GSamples/s",
             "steps": steps, "ms_per_step": ms, "roofline": roof}

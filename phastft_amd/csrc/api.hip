@@ -135,8 +135,10 @@ static size_t scratch_target_bytes() {
         if (v > 0) return (size_t)v << 20;
     }
     // measured (profiles/r01_sweep_scratch_chunk.log): chunks sized to the 256 MiB Infinity Cache buy nothing, while
-    // launches of >= 256 transforms run the 1024 x 8 passes ~25 % faster than 16-transform launches
-    return (size_t)4096 << 20;
+    // launches of >= 256 transforms run the 1024 x 8 passes ~25 % faster than 16-transform launches; round 2: the whole
+    // 1024-transform shard of BASELINE configs[4] in one chunk is another 1 % (76.4 vs 75.6 GSamples/s; 2 GiB chunks:
+    // 71.6) -- 16 GiB of a 288 GB device, allocated only when a batch that large arrives
+    return (size_t)16384 << 20;
 }
 
 // measurement hook: hipEvents recorded on the launch stream around every pass kernel (bench.py "roofline")
