@@ -231,12 +231,28 @@ template <typename T> __global__ void __launch_bounds__(256) quad_fft_kernel(con
     cx *l_twq = l_tw3 + (3u << a.tw_bits);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     typename Body::Regs r;
+    // tables: global loads first, the first tile's loads right behind them (loads return in order: see wave_fft.hpp)
+    constexpr int TWK = 4;
+    const unsigned n_tw3 = 3u << a.tw_bits;
+    cx tw_stage[TWK];
+    cx twq_stage;
+    if (tid < Body::TWQ) twq_stage = reinterpret_cast<const cx *>(a.twr)[tid];
+#pragma unroll
+    for (int k = 0; k < TWK; ++k) {
+        const unsigned i = (unsigned)tid + (unsigned)k * Body::NT;
+        if (i < n_tw3) tw_stage[k] = reinterpret_cast<const cx *>(a.tw3)[i];
+    }
     for (unsigned t = blockIdx.x; t < a.tiles_total; t += gridDim.x) {
         Body::locate(a, t, r);
         Body::load_raw(a, wave, lane, r);
-        if (t == blockIdx.x) {  // tables once per workgroup, behind the first tile's loads
-            for (int i = tid; i < Body::TWQ; i += Body::NT) l_twq[i] = reinterpret_cast<const cx *>(a.twr)[i];
-            for (unsigned i = tid; i < (3u << a.tw_bits); i += Body::NT) l_tw3[i] = reinterpret_cast<const cx *>(a.tw3)[i];
+        if (t == blockIdx.x) {
+            if (tid < Body::TWQ) l_twq[tid] = twq_stage;
+#pragma unroll
+            for (int k = 0; k < TWK; ++k) {
+                const unsigned i = (unsigned)tid + (unsigned)k * Body::NT;
+                if (i < n_tw3) l_tw3[i] = tw_stage[k];
+            }
+            for (unsigned i = (unsigned)tid + TWK * Body::NT; i < n_tw3; i += Body::NT) l_tw3[i] = reinterpret_cast<const cx *>(a.tw3)[i];
         }
         __syncthreads();  // tables visible / the previous tile's exchange reads done
         Body::pre_twiddle(a, l_tw3, wave, lane, r);

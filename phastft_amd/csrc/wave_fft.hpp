@@ -274,19 +274,47 @@ __global__ void __launch_bounds__(64 * PHAST_WAVE_TILES_PER_BLOCK) wave_fft_kern
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     T *xp = reinterpret_cast<T *>(l_twr + 32) + (size_t)wave * 2 * Body::XP;
 
+    // Twiddle tables: their global loads go out FIRST and the tile's loads right behind them.  Loads return in order
+    // (one vmcnt counter), so the other way round the table values -- and with them the workgroup barrier below -- would
+    // sit behind all 32 tile loads of the slowest wave; this way the barrier is passed while the tile is still in flight.
+    constexpr int TWK = 4;  // table entries per thread held in registers (covers 3 * 2^tw_bits <= 1024: N <= 2^24)
+    const unsigned n_tw3 = PRE_TW ? (3u << a.tw_bits) : 0u;
+    cx tw_stage[TWK];
+    cx twr_stage;
+    if (tid < 32) twr_stage = reinterpret_cast<const cx *>(a.twr)[tid];
+    if constexpr (PRE_TW) {
+#pragma unroll
+        for (int k = 0; k < TWK; ++k) {
+            const unsigned i = (unsigned)tid + (unsigned)k * Body::NT;
+            if (i < n_tw3) tw_stage[k] = reinterpret_cast<const cx *>(a.tw3)[i];
+        }
+    }
     typename Body::Regs r;
     Body::locate(a, blockIdx.x, blocks_total, (unsigned)wave, r);
     const bool active = (blockIdx.x * Body::WAVES + (unsigned)wave) < a.tiles_total;
-    if (active) Body::load_raw(a, lane, r);  // the tile's loads fly while the tables are staged
-    for (int i = tid; i < 32; i += Body::NT) l_twr[i] = reinterpret_cast<const cx *>(a.twr)[i];
-    if constexpr (PRE_TW)
-        for (unsigned i = tid; i < (3u << a.tw_bits); i += Body::NT) l_tw3[i] = reinterpret_cast<const cx *>(a.tw3)[i];
+    if (active) Body::load_raw(a, lane, r);
+    if (tid < 32) l_twr[tid] = twr_stage;
+    if constexpr (PRE_TW) {
+#pragma unroll
+        for (int k = 0; k < TWK; ++k) {
+            const unsigned i = (unsigned)tid + (unsigned)k * Body::NT;
+            if (i < n_tw3) l_tw3[i] = tw_stage[k];
+        }
+        for (unsigned i = (unsigned)tid + TWK * Body::NT; i < n_tw3; i += Body::NT)  // larger tables (N > 2^24): the plain way
+            l_tw3[i] = reinterpret_cast<const cx *>(a.tw3)[i];
+    }
     __syncthreads();  // the only workgroup barrier: tables visible
     if (!active) return;
+#if !defined(PHAST_WAVE_DEBUG_SKIP) || PHAST_WAVE_DEBUG_SKIP < 3   // tools only: 1 = no pre-twiddle, 2 = + no exchange, 3 = no arithmetic at all
+#if !defined(PHAST_WAVE_DEBUG_SKIP) || PHAST_WAVE_DEBUG_SKIP < 1
     Body::pre_twiddle(a, l_tw3, lane, r);
+#endif
     Body::step1(l_twr, lane, r);
+#if !defined(PHAST_WAVE_DEBUG_SKIP) || PHAST_WAVE_DEBUG_SKIP < 2
     wave_exchange<T>(r.re, r.im);
+#endif
     Body::step2(r);
+#endif
     if constexpr (TRANSPOSE) {
         // wave-private transposition: this wave writes and then reads its own buffer; LDS operations of one wave
         // execute in order, and the compiler's s_waitcnt lgkmcnt covers the data dependency -- no barrier
