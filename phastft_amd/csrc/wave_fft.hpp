@@ -293,6 +293,11 @@ __global__ void __launch_bounds__(64 * PHAST_WAVE_TILES_PER_BLOCK) wave_fft_kern
     Body::locate(a, blockIdx.x, blocks_total, (unsigned)wave, r);
     const bool active = (blockIdx.x * Body::WAVES + (unsigned)wave) < a.tiles_total;
     if (active) Body::load_raw(a, lane, r);
+#if defined(PHAST_WAVE_DEBUG_SKIP) && PHAST_WAVE_DEBUG_SKIP >= 4  // tools only: no table staging, no barrier
+    if (a.tiles_total == 0xffffffffu) { l_twr[tid & 31] = twr_stage; l_tw3[tid] = tw_stage[0]; }
+    if (!active) return;
+    if constexpr (TRANSPOSE) { } else { Body::store_rows(a, lane, r); return; }
+#endif
     if (tid < 32) l_twr[tid] = twr_stage;
     if constexpr (PRE_TW) {
 #pragma unroll
