@@ -9,7 +9,9 @@ from __future__ import annotations
 
 import argparse
 import concurrent.futures as cf
+import json
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -23,7 +25,8 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
 UNITS = ["api", "tile_f64_a", "tile_f64_bc", "tile_f32_a", "tile_f32_bc", "wave_f64", "quad_f64", "small_fft", "bitrev", "r2c", "fill", "twiddle"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
-         "-ffp-contract=fast"]
+         "-ffp-contract=fast", "-Rpass-analysis=kernel-resource-usage"]
+RESOURCES = os.path.join(LIB_DIR, "kernel_resources.json")  # per kernel: VGPRs, scratch bytes per lane, occupancy, spills
 
 
 def hipcc() -> str:
@@ -53,7 +56,28 @@ def _compile(unit: str, force: bool, trace: bool = False, extra: tuple = (), tag
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {unit}:\n{r.stdout}\n{r.stderr}")
+        with open(obj + ".res.json", "w") as f:
+            json.dump(_resource_usage(r.stderr), f)
     return obj
+
+
+def _resource_usage(remarks: str) -> dict:
+    """{mangled kernel name: {"vgprs", "agprs", "scratch", "occupancy", "vgpr_spill", "sgpr_spill"}} out of the compiler's
+    kernel-resource-usage remarks: a kernel that starts to use scratch memory (a register array the optimiser could
+    not keep in registers, or spills) pays for it in HBM traffic -- tests/test_kernel_resources.py watches this."""
+    keys = {"VGPRs": "vgprs", "AGPRs": "agprs", "ScratchSize [bytes/lane]": "scratch", "Occupancy [waves/SIMD]": "occupancy",
+            "VGPRs Spill": "vgpr_spill", "SGPRs Spill": "sgpr_spill"}
+    out, cur = {}, None
+    for line in remarks.splitlines():
+        m = re.search(r"remark:\s+(.*?):\s+(\S+)\s+\[-Rpass-analysis", line)
+        if not m:
+            continue
+        k, v = m.group(1).strip(), m.group(2)
+        if k == "Function Name":
+            cur = out.setdefault(v, {})
+        elif cur is not None and k in keys:
+            cur[keys[k]] = int(v)
+    return out
 
 
 def build(force: bool = False, jobs: int | None = None, verbose: bool = False, trace: bool = False,
@@ -71,6 +95,13 @@ def build(force: bool = False, jobs: int | None = None, verbose: bool = False, t
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    if not trace and not tag:
+        merged = {}
+        for o in objs:
+            if os.path.exists(o + ".res.json"):
+                merged.update(json.load(open(o + ".res.json")))
+        with open(RESOURCES, "w") as f:
+            json.dump(merged, f, indent=1, sort_keys=True)
     if verbose:
         print(lib)
     return lib

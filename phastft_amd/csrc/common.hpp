@@ -55,6 +55,45 @@ PHAST_HD void tw3_lookup(const cx_t<T> *tab, unsigned bits, unsigned e, T &wr, T
     wi = r * c.y + i * c.x;
 }
 
+// W = B * D^j for j = 0..P-1, handed to apply(integral_constant<int, j>, wr, wi) in ascending j.  G running values
+// B D^i (i < G, built by doubling: 1 + 2 + .. + G/2 products and log2 G squarings of D) stepped by D^G: G + P - G products
+// in all where a table of the powers D^j costs 2 P, and only G values are live (a P-entry table is 4 P registers of
+// f64 -- next to 4 P registers of data that spills).  Rounding: at most log2 G + P/G - 1 products on top of the
+// log2 G squarings, ~1.1e-16 each.
+template <typename T, int P, int G, typename F> PHAST_HD void tw_progression(T br, T bi, T dr, T di, F &&apply) {
+    static_assert(G >= 1 && P % G == 0 && (G & (G - 1)) == 0, "group size: a power of two dividing P");
+    T ar[G], ai[G];
+    ar[0] = br;
+    ai[0] = bi;
+    T qr = dr, qi = di;  // D^(2^s)
+    static_for<0, ilog2_c(G)>([&](auto s) {
+        constexpr int S = 1 << decltype(s)::value;
+        static_for<0, S>([&](auto i) {
+            constexpr int I = decltype(i)::value;
+            ar[S + I] = ar[I] * qr - ai[I] * qi;
+            ai[S + I] = ar[I] * qi + ai[I] * qr;
+        });
+        const T t = qr * qr - qi * qi;
+        qi = (T)2 * (qr * qi);
+        qr = t;
+    });
+    static_for<0, P / G>([&](auto h) {
+        constexpr int H = decltype(h)::value;
+        static_for<0, G>([&](auto i) {
+            constexpr int I = decltype(i)::value;
+            apply(std::integral_constant<int, H * G + I>{}, ar[I], ai[I]);
+        });
+        if constexpr (H + 1 < P / G) {
+            static_for<0, G>([&](auto i) {
+                constexpr int I = decltype(i)::value;
+                const T t = ar[I] * qr - ai[I] * qi;
+                ai[I] = ar[I] * qi + ai[I] * qr;
+                ar[I] = t;
+            });
+        }
+    });
+}
+
 // splitmix64-based synthetic input shared with oracle/pho_fill_* 
 __host__ __device__ inline unsigned long long splitmix64(unsigned long long x) {
     x += 0x9E3779B97F4A7C15ull;

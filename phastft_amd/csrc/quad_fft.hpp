@@ -103,20 +103,8 @@ template <typename T> struct QuadBody {
         T br, bi, dr, di;
         tw3_lookup<T>(tw3, a.tw_bits, (unsigned)(4 * wave + tau_of(lane)) * lo, br, bi);
         tw3_lookup<T>(tw3, a.tw_bits, 16u * lo, dr, di);
-        T pr[P], pi[P];
-        pr[0] = (T)1;
-        pi[0] = (T)0;
-        pr[1] = dr;
-        pi[1] = di;
-        static_for<2, P>([&](auto j) {
-            constexpr int J = decltype(j)::value, H = J / 2, G = J - H;
-            pr[J] = pr[H] * pr[G] - pi[H] * pi[G];
-            pi[J] = pr[H] * pi[G] + pi[H] * pr[G];
-        });
-        static_for<0, P>([&](auto q) {
-            constexpr int Q = decltype(q)::value, E = (Q & 3) + 4 * (Q >> 2);  // jj + 4 n_hi
-            const T wr = br * pr[E] - bi * pi[E], wi = br * pi[E] + bi * pr[E];
-            cmul(r.re[Q], r.im[Q], wr, wi);
+        tw_progression<T, P, 4>(br, bi, dr, di, [&](auto q, T wr, T wi) {  // register q = jj + 4 n_hi holds row 16 q + (4 wave + tau)
+            cmul(r.re[decltype(q)::value], r.im[decltype(q)::value], wr, wi);
         });
     }
 
@@ -235,25 +223,24 @@ template <typename T> __global__ void __launch_bounds__(256) quad_fft_kernel(con
     constexpr int TWK = 4;
     const unsigned n_tw3 = 3u << a.tw_bits;
     cx tw_stage[TWK];
-    cx twq_stage;
-    if (tid < Body::TWQ) twq_stage = reinterpret_cast<const cx *>(a.twr)[tid];
+    const cx twq_stage = reinterpret_cast<const cx *>(a.twr)[tid & (Body::TWQ - 1)];
 #pragma unroll
     for (int k = 0; k < TWK; ++k) {
         const unsigned i = (unsigned)tid + (unsigned)k * Body::NT;
-        if (i < n_tw3) tw_stage[k] = reinterpret_cast<const cx *>(a.tw3)[i];
+        tw_stage[k] = reinterpret_cast<const cx *>(a.tw3)[i < n_tw3 ? i : 0u];  // clamped, unconditional: stays in registers
     }
-    for (unsigned t = blockIdx.x; t < a.tiles_total; t += gridDim.x) {
-        Body::locate(a, t, r);
-        Body::load_raw(a, wave, lane, r);
-        if (t == blockIdx.x) {
-            if (tid < Body::TWQ) l_twq[tid] = twq_stage;
+    unsigned t = blockIdx.x;
+    if (t >= a.tiles_total) return;  // uniform over the workgroup
+    Body::locate(a, t, r);
+    Body::load_raw(a, wave, lane, r);
+    if (tid < Body::TWQ) l_twq[tid] = twq_stage;
 #pragma unroll
-            for (int k = 0; k < TWK; ++k) {
-                const unsigned i = (unsigned)tid + (unsigned)k * Body::NT;
-                if (i < n_tw3) l_tw3[i] = tw_stage[k];
-            }
-            for (unsigned i = (unsigned)tid + TWK * Body::NT; i < n_tw3; i += Body::NT) l_tw3[i] = reinterpret_cast<const cx *>(a.tw3)[i];
-        }
+    for (int k = 0; k < TWK; ++k) {
+        const unsigned i = (unsigned)tid + (unsigned)k * Body::NT;
+        if (i < n_tw3) l_tw3[i] = tw_stage[k];
+    }
+    for (unsigned i = (unsigned)tid + TWK * Body::NT; i < n_tw3; i += Body::NT) l_tw3[i] = reinterpret_cast<const cx *>(a.tw3)[i];
+    for (;;) {
         __syncthreads();  // tables visible / the previous tile's exchange reads done
         Body::pre_twiddle(a, l_tw3, wave, lane, r);
         Body::steps12(l_twq, wave, lane, r);
@@ -270,6 +257,10 @@ template <typename T> __global__ void __launch_bounds__(256) quad_fft_kernel(con
         quad_lane_exchange<T>(r.re, r.im);
         Body::step4(r);
         Body::store(a, wave, lane, r);
+        t += gridDim.x;
+        if (t >= a.tiles_total) break;
+        Body::locate(a, t, r);
+        Body::load_raw(a, wave, lane, r);
     }
 }
 

@@ -227,30 +227,17 @@ template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool 
                 de = (unsigned)M * lo;
             }
             if constexpr (sizeof(T) == 8 && LR >= 10 && LP == 5) {
-                // W^(e0 + j de) = W^e0 (W^de)^j: two look-ups and a power ladder (depth log2 P) instead of P look-ups --
-                // the same number of complex products, 6 LDS reads per thread instead of 3 P, none of them conflicting
+                // W^(e0 + j de) = W^e0 (W^de)^j: two look-ups and a geometric progression (tw_progression) instead of P look-ups
+                // -- fewer complex products, 6 LDS reads per thread instead of 3 P, none of them conflicting
                 // (the data-dependent table reads were 29 % of the LDS cycles of these passes, profiles/r01_sq_batch_lds.txt).
                 // Measured (profiles/r02_tw_ladder.log): the 1024 x 16 pass of the batched 2^20 transforms 2.17 -> 2.07 ms
                 // per 256 transforms; the 256 x 64 passes of 2^24 LOSE 3 % with it, hence the shape condition.  f64 only:
-                // the ladder adds <= 5 roundings (5.5e-16), nothing against 1e-13, too much of f32's margin.
+                // the progression adds <= 9 roundings (1e-15), nothing against 1e-13, too much of f32's margin.
                 T br, bi, dr, di;
                 tw3_lookup<T>(sh.tw3, a.tw_bits, e0, br, bi);
                 tw3_lookup<T>(sh.tw3, a.tw_bits, de, dr, di);
-                T pr[P], pi[P];
-                pr[0] = (T)1;
-                pi[0] = (T)0;
-                if constexpr (P > 1) {
-                    pr[1] = dr;
-                    pi[1] = di;
-                }
-                static_for<2, P>([&](auto j) {
-                    constexpr int J = decltype(j)::value, H = J / 2, G = J - H;
-                    pr[J] = pr[H] * pr[G] - pi[H] * pi[G];
-                    pi[J] = pr[H] * pi[G] + pi[H] * pr[G];
-                });
-                static_for<0, P>([&](auto j) {
-                    const T wr = br * pr[j] - bi * pi[j], wi = br * pi[j] + bi * pr[j];
-                    cmul(r.re[j], r.im[j], wr, wi);
+                tw_progression<T, P, (P >= 32 ? 8 : 4)>(br, bi, dr, di, [&](auto j, T wr, T wi) {
+                    cmul(r.re[decltype(j)::value], r.im[decltype(j)::value], wr, wi);
                 });
             } else {
                 static_for<0, P>([&](auto j) {

@@ -101,27 +101,16 @@ template <typename T, bool PRE_TW, bool TRANSPOSE> struct WaveBody {
     }
 
     // inter-pass twiddle W_{64 S}^{row * lo}: row = tau + 4 j  =>  W^(tau lo) * (W^(4 lo))^j.  Two table look-ups and a
-    // power ladder of depth <= 4 instead of 16 look-ups (48 LDS reads): the ladder's rounding (<= 4 extra complex
-    // products, ~1.3e-16 each) is far inside the 1e-13 budget (measured rel-L2 unchanged, tests/test_gpu_parity.py)
+    // geometric progression (tw_progression: 4 running values stepped by D^4, 17 products where a table of the powers costs
+    // 30) instead of 16 look-ups (48 LDS reads): its rounding (<= 7 extra complex products, ~1.1e-16 each) is far inside the 1e-13 budget (measured rel-L2 unchanged, tests/test_gpu_parity.py)
     PHAST_HD static void pre_twiddle(const TileArgs &a, const cx *tw3, int lane, Regs &r) {
         if constexpr (PRE_TW) {
             const unsigned lo = ((r.g0 + (unsigned)col_of(lane)) >> a.tw_shift) & a.tw_mask;
             T br, bi, dr, di;
             tw3_lookup<T>(tw3, a.tw_bits, (unsigned)tau_of(lane) * lo, br, bi);
             tw3_lookup<T>(tw3, a.tw_bits, (unsigned)TAUS * lo, dr, di);
-            T pr[P], pi[P];  // D^j: 1, D, D^2 = D D, D^3 = D^2 D, D^4 = D^2 D^2, ... (products of at most 4 factors deep)
-            pr[0] = (T)1;
-            pi[0] = (T)0;
-            pr[1] = dr;
-            pi[1] = di;
-            static_for<2, P>([&](auto j) {
-                constexpr int J = decltype(j)::value, H = J / 2, G = J - H;
-                pr[J] = pr[H] * pr[G] - pi[H] * pi[G];
-                pi[J] = pr[H] * pi[G] + pi[H] * pr[G];
-            });
-            static_for<0, P>([&](auto j) {
-                const T wr = br * pr[j] - bi * pi[j], wi = br * pi[j] + bi * pr[j];
-                cmul(r.re[j], r.im[j], wr, wi);
+            tw_progression<T, P, 4>(br, bi, dr, di, [&](auto j, T wr, T wi) {
+                cmul(r.re[decltype(j)::value], r.im[decltype(j)::value], wr, wi);
             });
         }
     }
@@ -279,14 +268,14 @@ __global__ void __launch_bounds__(64 * PHAST_WAVE_TILES_PER_BLOCK) wave_fft_kern
     // sit behind all 32 tile loads of the slowest wave; this way the barrier is passed while the tile is still in flight.
     constexpr int TWK = 4;  // table entries per thread held in registers (covers 3 * 2^tw_bits <= 1024: N <= 2^24)
     const unsigned n_tw3 = PRE_TW ? (3u << a.tw_bits) : 0u;
+    // (unconditional loads of a clamped index: a conditionally initialised register array lands in scratch memory)
     cx tw_stage[TWK];
-    cx twr_stage;
-    if (tid < 32) twr_stage = reinterpret_cast<const cx *>(a.twr)[tid];
+    const cx twr_stage = reinterpret_cast<const cx *>(a.twr)[tid & 31];
     if constexpr (PRE_TW) {
 #pragma unroll
         for (int k = 0; k < TWK; ++k) {
             const unsigned i = (unsigned)tid + (unsigned)k * Body::NT;
-            if (i < n_tw3) tw_stage[k] = reinterpret_cast<const cx *>(a.tw3)[i];
+            tw_stage[k] = reinterpret_cast<const cx *>(a.tw3)[i < n_tw3 ? i : 0u];
         }
     }
     typename Body::Regs r;

@@ -1,0 +1,51 @@
+"""Register budget of the compiled kernels (phastft_amd/lib/kernel_resources.json, written by phastft_amd/build.py from
+hipcc's kernel-resource-usage remarks).  A kernel that drifts into scratch memory -- a register array the optimiser
+could not keep in registers, or plain spills -- keeps passing every parity test while paying for it in HBM traffic
+(round 2: 80 bytes per lane of scratch in the wave/quad kernels showed up as +10 % FETCH_SIZE/WRITE_SIZE), so the
+build records the numbers and this test pins them."""
+import json
+import os
+
+import pytest
+
+import phastft_amd.build as B
+
+# kernels known to spill, with the bytes per lane they are allowed: none of them is the dominant kernel of a bench leg
+KNOWN_SCRATCH = {
+    "_ZN5phast15tile_fft_kernelIdLi10ELi4ELi5ELb1ELb0ELb1EEEvNS_8TileArgsE": 48,   # 256 VGPRs (32 f64 points per thread)
+    "_ZN5phast15tile_fft_kernelIfLi10ELi5ELi5ELb1ELb0ELb1EEEvNS_8TileArgsE": 96,   # 1024 threads: 128 VGPRs
+    "_ZN5phast24bitrev_persistent_kernelIjLi7ELi1024EEEvPT_jmjy": 96,              # tuning variant 4 only
+}
+
+
+@pytest.fixture(scope="module")
+def resources():
+    B.build()
+    assert os.path.exists(B.RESOURCES), "build.py did not write kernel_resources.json"
+    return json.load(open(B.RESOURCES))
+
+
+def test_every_unit_reported(resources):
+    names = " ".join(resources)
+    for kernel in ("tile_fft_kernel", "wave_fft_kernel", "quad_fft_kernel", "row_fft", "bitrev_persistent2_kernel",
+                   "untangle_kernel", "c2r_preprocess", "twiddle_grid", "fill_kernel"):
+        assert kernel in names, kernel
+    assert len(resources) > 100
+
+
+def test_no_kernel_uses_scratch_memory_unannounced(resources):
+    bad = {k: v["scratch"] for k, v in resources.items() if v.get("scratch", 0) > KNOWN_SCRATCH.get(k, 0)}
+    assert not bad, bad
+    for k in KNOWN_SCRATCH:
+        assert k in resources, f"{k} no longer exists: drop it from KNOWN_SCRATCH"
+
+
+def test_wave_and_quad_kernels_keep_four_waves_per_simd(resources):
+    """the headline kernels: 64 x 16 wave tiles and the 256 x 16 quad tile, no spills, <= 128 VGPRs"""
+    seen = 0
+    for k, v in resources.items():
+        if "wave_fft_kernel" in k or "quad_fft_kernel" in k:
+            seen += 1
+            assert v["scratch"] == 0 and v["vgpr_spill"] == 0, (k, v)
+            assert v["vgprs"] <= 128 and v["occupancy"] >= 4, (k, v)
+    assert seen >= 3
