@@ -26,6 +26,13 @@
 
 #include "common.hpp"
 
+#ifndef PHAST_TW_PROG_MIN_LR  // shapes whose pre-twiddle is a progression instead of P look-ups (tuning: tools/cmp_throughput.py)
+#define PHAST_TW_PROG_MIN_LR 10
+#endif
+#ifndef PHAST_TW_PROG_MIN_LP
+#define PHAST_TW_PROG_MIN_LP 5
+#endif
+
 namespace phast {
 
 // ---- literal twiddles: (re, im) *= W_N^J = exp(-2*pi*i*J/N), N in {2,4,8,16,32}, 0 <= J < N/2 ----
@@ -226,7 +233,7 @@ template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool 
                 e0 = (unsigned)tau * lo;
                 de = (unsigned)M * lo;
             }
-            if constexpr (sizeof(T) == 8 && LR >= 10 && LP == 5) {
+            if constexpr (sizeof(T) == 8 && LR >= PHAST_TW_PROG_MIN_LR && LP >= PHAST_TW_PROG_MIN_LP) {
                 // W^(e0 + j de) = W^e0 (W^de)^j: two look-ups and a geometric progression (tw_progression) instead of P look-ups
                 // -- fewer complex products, 6 LDS reads per thread instead of 3 P, none of them conflicting
                 // (the data-dependent table reads were 29 % of the LDS cycles of these passes, profiles/r01_sq_batch_lds.txt).
