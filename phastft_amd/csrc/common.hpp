@@ -43,16 +43,28 @@ template <typename T> PHAST_HD void cmul(T &re, T &im, T wr, T wi) {
 
 // Three-level twiddle lookup: W_{2^log_mod}^e = T0[e & m] * T1[(e >> B) & m] * T2[(e >> 2B) & m],
 // tables laid out [3][1 << B] (built on the host in long double, plan.cpp).  `tab` may be LDS or global.
+template <typename T> struct Tw3Raw {
+    cx_t<T> a, b, c;
+};
+// the three table reads alone (a kernel issues them ahead of other loads and multiplies later) ...
+template <typename T> PHAST_HD Tw3Raw<T> tw3_fetch(const cx_t<T> *tab, unsigned bits, unsigned e) {
+    const unsigned m = (1u << bits) - 1u;
+    Tw3Raw<T> t;
+    t.a = tab[e & m];
+    t.b = tab[(1u << bits) + ((e >> bits) & m)];
+    t.c = tab[(2u << bits) + ((e >> (2 * bits)) & m)];
+    return t;
+}
+// ... and their product
+template <typename T> PHAST_HD void tw3_combine(const Tw3Raw<T> &t, T &wr, T &wi) {
+    T r = t.a.x * t.b.x - t.a.y * t.b.y;
+    T i = t.a.x * t.b.y + t.a.y * t.b.x;
+    wr = r * t.c.x - i * t.c.y;
+    wi = r * t.c.y + i * t.c.x;
+}
 template <typename T>
 PHAST_HD void tw3_lookup(const cx_t<T> *tab, unsigned bits, unsigned e, T &wr, T &wi) {
-    const unsigned m = (1u << bits) - 1u;
-    cx_t<T> a = tab[e & m];
-    cx_t<T> b = tab[(1u << bits) + ((e >> bits) & m)];
-    cx_t<T> c = tab[(2u << bits) + ((e >> (2 * bits)) & m)];
-    T r = a.x * b.x - a.y * b.y;
-    T i = a.x * b.y + a.y * b.x;
-    wr = r * c.x - i * c.y;
-    wi = r * c.y + i * c.x;
+    tw3_combine<T>(tw3_fetch<T>(tab, bits, e), wr, wi);
 }
 
 // W = B * D^j for j = 0..P-1, handed to apply(integral_constant<int, j>, wr, wi) in ascending j.  G running values

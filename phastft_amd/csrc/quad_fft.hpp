@@ -209,7 +209,21 @@ template <typename T> __device__ __forceinline__ void quad_lane_exchange(T (&re)
     });
 }
 
-template <typename T> __global__ void __launch_bounds__(256) quad_fft_kernel(const TileArgs a) {
+// Stagger of the workgroups' first loads (cf. wave_fft.hpp): group g = block & mask sleeps g * units * 64 cycles; packed as
+// units | mask << 8, PHAST_QUAD_STAGGER="units,mask" overrides the default.
+#ifndef PHAST_QUAD_STAGGER_DEFAULT
+#define PHAST_QUAD_STAGGER_DEFAULT 0u
+#endif
+inline unsigned quad_stagger_setting() {
+    static const unsigned v = [] {
+        const char *e = getenv("PHAST_QUAD_STAGGER");
+        unsigned units = 0, mask = 0;
+        if (e && sscanf(e, "%u,%u", &units, &mask) == 2) return (units & 255u) | ((mask & 7u) << 8);
+        return (unsigned)PHAST_QUAD_STAGGER_DEFAULT;
+    }();
+    return v;
+}
+template <typename T> __global__ void __launch_bounds__(256) quad_fft_kernel(const TileArgs a, unsigned stagger) {
     using Body = QuadBody<T>;
     using cx = cx_t<T>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -219,27 +233,26 @@ template <typename T> __global__ void __launch_bounds__(256) quad_fft_kernel(con
     cx *l_twq = l_tw3 + (3u << a.tw_bits);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     typename Body::Regs r;
-    // tables: global loads first, the first tile's loads right behind them (loads return in order: see wave_fft.hpp)
-    constexpr int TWK = 4;
+    // tables: global loads first, the first tile's loads right behind them (loads return in order: see wave_fft.hpp).
+    // Four named registers, not an array: an array here lands in scratch memory as soon as control flow separates
+    // the loads from the LDS stores (tests/test_kernel_resources.py watches it).
     const unsigned n_tw3 = 3u << a.tw_bits;
-    cx tw_stage[TWK];
+    const cx *g_tw3 = reinterpret_cast<const cx *>(a.tw3);
+    const unsigned i0 = (unsigned)tid, i1 = i0 + Body::NT, i2 = i1 + Body::NT, i3 = i2 + Body::NT;
     const cx twq_stage = reinterpret_cast<const cx *>(a.twr)[tid & (Body::TWQ - 1)];
-#pragma unroll
-    for (int k = 0; k < TWK; ++k) {
-        const unsigned i = (unsigned)tid + (unsigned)k * Body::NT;
-        tw_stage[k] = reinterpret_cast<const cx *>(a.tw3)[i < n_tw3 ? i : 0u];  // clamped, unconditional: stays in registers
-    }
+    const cx ts0 = g_tw3[i0 < n_tw3 ? i0 : 0u], ts1 = g_tw3[i1 < n_tw3 ? i1 : 0u], ts2 = g_tw3[i2 < n_tw3 ? i2 : 0u],
+             ts3 = g_tw3[i3 < n_tw3 ? i3 : 0u];
     unsigned t = blockIdx.x;
     if (t >= a.tiles_total) return;  // uniform over the workgroup
     Body::locate(a, t, r);
+    for (unsigned k = ((blockIdx.x >> 3) & (stagger >> 8)) * (stagger & 255u); k > 0; --k) __builtin_amdgcn_s_sleep(1);
     Body::load_raw(a, wave, lane, r);
     if (tid < Body::TWQ) l_twq[tid] = twq_stage;
-#pragma unroll
-    for (int k = 0; k < TWK; ++k) {
-        const unsigned i = (unsigned)tid + (unsigned)k * Body::NT;
-        if (i < n_tw3) l_tw3[i] = tw_stage[k];
-    }
-    for (unsigned i = (unsigned)tid + TWK * Body::NT; i < n_tw3; i += Body::NT) l_tw3[i] = reinterpret_cast<const cx *>(a.tw3)[i];
+    if (i0 < n_tw3) l_tw3[i0] = ts0;
+    if (i1 < n_tw3) l_tw3[i1] = ts1;
+    if (i2 < n_tw3) l_tw3[i2] = ts2;
+    if (i3 < n_tw3) l_tw3[i3] = ts3;
+    for (unsigned i = i3 + Body::NT; i < n_tw3; i += Body::NT) l_tw3[i] = g_tw3[i];
     for (;;) {
         __syncthreads();  // tables visible / the previous tile's exchange reads done
         Body::pre_twiddle(a, l_tw3, wave, lane, r);
@@ -286,9 +299,9 @@ hipError_t launch_quad_inst(unsigned grid, hipStream_t stream, const TileArgs &a
         return hipSuccess;
     }
     if (ev_start && ev_stop)
-        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(Body::NT), (uint32_t)lds, stream, ev_start, ev_stop, 0, a);
+        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(Body::NT), (uint32_t)lds, stream, ev_start, ev_stop, 0, a, quad_stagger_setting());
     else
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(Body::NT), lds, stream, a);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(Body::NT), lds, stream, a, quad_stagger_setting());
     return hipGetLastError();
 }
 

@@ -22,6 +22,8 @@
 // Phase functions are __host__ __device__ (per lane); tests/emu/emu.hip runs them lane by lane with the swaps emulated.
 #pragma once
 
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "tile_fft.hpp"
@@ -54,7 +56,8 @@ template <typename T, bool PRE_TW, bool TRANSPOSE> struct WaveBody {
     };
 
     static size_t lds_bytes(unsigned tw_bits) {
-        return (PRE_TW ? (size_t)(3u << tw_bits) * sizeof(cx) : 0) + 32 * sizeof(cx) + (size_t)2 * XP * WAVES * sizeof(T);
+        (void)tw_bits;  // the inter-pass tables are read from global memory (six entries per lane)
+        return (size_t)WAVES * (32 * sizeof(cx) + (size_t)2 * XP * sizeof(T));  // per wave: W_64 table, transposing buffer
     }
 
     PHAST_HD static int col_of(int lane) { return lane & (COLS - 1); }
@@ -103,16 +106,26 @@ template <typename T, bool PRE_TW, bool TRANSPOSE> struct WaveBody {
     // inter-pass twiddle W_{64 S}^{row * lo}: row = tau + 4 j  =>  W^(tau lo) * (W^(4 lo))^j.  Two table look-ups and a
     // geometric progression (tw_progression: 4 running values stepped by D^4, 17 products where a table of the powers costs
     // 30) instead of 16 look-ups (48 LDS reads): its rounding (<= 7 extra complex products, ~1.1e-16 each) is far inside the 1e-13 budget (measured rel-L2 unchanged, tests/test_gpu_parity.py)
+    struct TwRaw {
+        Tw3Raw<T> b, d;
+    };
+    PHAST_HD static TwRaw pre_twiddle_fetch(const TileArgs &a, const cx *tw3, int lane, const Regs &r) {
+        const unsigned lo = ((r.g0 + (unsigned)col_of(lane)) >> a.tw_shift) & a.tw_mask;
+        TwRaw t;
+        t.b = tw3_fetch<T>(tw3, a.tw_bits, (unsigned)tau_of(lane) * lo);
+        t.d = tw3_fetch<T>(tw3, a.tw_bits, (unsigned)TAUS * lo);
+        return t;
+    }
+    PHAST_HD static void pre_twiddle_apply(const TwRaw &t, Regs &r) {
+        T br, bi, dr, di;
+        tw3_combine<T>(t.b, br, bi);
+        tw3_combine<T>(t.d, dr, di);
+        tw_progression<T, P, 4>(br, bi, dr, di, [&](auto j, T wr, T wi) {
+            cmul(r.re[decltype(j)::value], r.im[decltype(j)::value], wr, wi);
+        });
+    }
     PHAST_HD static void pre_twiddle(const TileArgs &a, const cx *tw3, int lane, Regs &r) {
-        if constexpr (PRE_TW) {
-            const unsigned lo = ((r.g0 + (unsigned)col_of(lane)) >> a.tw_shift) & a.tw_mask;
-            T br, bi, dr, di;
-            tw3_lookup<T>(tw3, a.tw_bits, (unsigned)tau_of(lane) * lo, br, bi);
-            tw3_lookup<T>(tw3, a.tw_bits, (unsigned)TAUS * lo, dr, di);
-            tw_progression<T, P, 4>(br, bi, dr, di, [&](auto j, T wr, T wi) {
-                cmul(r.re[decltype(j)::value], r.im[decltype(j)::value], wr, wi);
-            });
-        }
+        if constexpr (PRE_TW) pre_twiddle_apply(pre_twiddle_fetch(a, tw3, lane, r), r);
     }
 
     // W_64^e, e < 64, from the first 32 entries of host_twr(64): W^(e + 32) = -W^e
@@ -253,55 +266,59 @@ template <typename T> __device__ __forceinline__ void wave_exchange(T (&re)[16],
     });
 }
 
+// Stagger of the waves' loads (see the kernel): group g = ((block & 1) << 2 | wave) & mask sleeps g * units * 64 cycles.
+// Packed as units | mask << 8; PHAST_WAVE_STAGGER="units,mask" overrides the default (tuning, tools/sweep_stagger.py).
+#ifndef PHAST_WAVE_STAGGER_DEFAULT
+#define PHAST_WAVE_STAGGER_DEFAULT (6u | (3u << 8))
+#endif
+inline unsigned wave_stagger_setting() {
+    static const unsigned v = [] {
+        const char *e = getenv("PHAST_WAVE_STAGGER");
+        unsigned units = 0, mask = 0;
+        if (e && sscanf(e, "%u,%u", &units, &mask) == 2) return (units & 255u) | ((mask & 7u) << 8);
+        return (unsigned)PHAST_WAVE_STAGGER_DEFAULT;
+    }();
+    return v;
+}
 template <typename T, bool PRE_TW, bool TRANSPOSE>
-__global__ void __launch_bounds__(64 * PHAST_WAVE_TILES_PER_BLOCK) wave_fft_kernel(const TileArgs a, unsigned blocks_total) {
+__global__ void __launch_bounds__(64 * PHAST_WAVE_TILES_PER_BLOCK) wave_fft_kernel(const TileArgs a, unsigned blocks_total, unsigned stagger) {
     using Body = WaveBody<T, PRE_TW, TRANSPOSE>;
     using cx = cx_t<T>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    cx *l_tw3 = reinterpret_cast<cx *>(smem);
-    cx *l_twr = l_tw3 + (PRE_TW ? (3u << a.tw_bits) : 0u);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    T *xp = reinterpret_cast<T *>(l_twr + 32) + (size_t)wave * 2 * Body::XP;
+    // everything in LDS is private to a wave: its copy of the W_64 step-twiddle table and its transposing buffer.  No
+    // workgroup barrier anywhere: the four waves of a block are four independent tiles.
+    cx *l_twr = reinterpret_cast<cx *>(smem + (size_t)wave * (32 * sizeof(cx) + (size_t)2 * Body::XP * sizeof(T)));
+    T *xp = reinterpret_cast<T *>(l_twr + 32);
+    if ((blockIdx.x * Body::WAVES + (unsigned)wave) >= a.tiles_total) return;
 
     // Twiddle tables: their global loads go out FIRST and the tile's loads right behind them.  Loads return in order
-    // (one vmcnt counter), so the other way round the table values -- and with them the workgroup barrier below -- would
-    // sit behind all 32 tile loads of the slowest wave; this way the barrier is passed while the tile is still in flight.
-    constexpr int TWK = 4;  // table entries per thread held in registers (covers 3 * 2^tw_bits <= 1024: N <= 2^24)
-    const unsigned n_tw3 = PRE_TW ? (3u << a.tw_bits) : 0u;
-    // (unconditional loads of a clamped index: a conditionally initialised register array lands in scratch memory)
-    cx tw_stage[TWK];
-    const cx twr_stage = reinterpret_cast<const cx *>(a.twr)[tid & 31];
-    if constexpr (PRE_TW) {
-#pragma unroll
-        for (int k = 0; k < TWK; ++k) {
-            const unsigned i = (unsigned)tid + (unsigned)k * Body::NT;
-            tw_stage[k] = reinterpret_cast<const cx *>(a.tw3)[i < n_tw3 ? i : 0u];
-        }
-    }
+    // (one vmcnt counter), so the other way round the table values would sit behind all 32 tile loads.  The inter-pass
+    // tables are not staged at all: a lane needs six entries (two three-level look-ups), read straight from global
+    // memory (a few KiB, L2-resident).
     typename Body::Regs r;
     Body::locate(a, blockIdx.x, blocks_total, (unsigned)wave, r);
-    const bool active = (blockIdx.x * Body::WAVES + (unsigned)wave) < a.tiles_total;
-    if (active) Body::load_raw(a, lane, r);
-#if defined(PHAST_WAVE_DEBUG_SKIP) && PHAST_WAVE_DEBUG_SKIP >= 4  // tools only: no table staging, no barrier
-    if (a.tiles_total == 0xffffffffu) { l_twr[tid & 31] = twr_stage; l_tw3[tid] = tw_stage[0]; }
-    if (!active) return;
+    const cx twr_stage = reinterpret_cast<const cx *>(a.twr)[lane & 31];
+    typename Body::TwRaw twraw;
+    if constexpr (PRE_TW) twraw = Body::pre_twiddle_fetch(a, reinterpret_cast<const cx *>(a.tw3), lane, r);
+    // Staggered waves.  With one tile per SIMD every wave of the chip would wait for HBM, compute and store in step, the
+    // memory system idle while the arithmetic runs.  The waves of the later groups issue their loads a little later: the
+    // early groups' arithmetic and stores then overlap the late groups' loads (tools/pass_floor7.hip: 7.3 -> 6.5 us per
+    // pass for the copy model with this pass's arithmetic; nothing lost when there is no arithmetic).
+    for (unsigned k = ((((blockIdx.x & 1u) << 2) | (unsigned)wave) & (stagger >> 8)) * (stagger & 255u); k > 0; --k)
+        __builtin_amdgcn_s_sleep(1);
+    Body::load_raw(a, lane, r);
+#if defined(PHAST_WAVE_DEBUG_SKIP) && PHAST_WAVE_DEBUG_SKIP >= 4  // tools only: no table staging
+    if (a.tiles_total == 0xffffffffu) l_twr[lane & 31] = twr_stage;
     if constexpr (TRANSPOSE) { } else { Body::store_rows(a, lane, r); return; }
 #endif
-    if (tid < 32) l_twr[tid] = twr_stage;
-    if constexpr (PRE_TW) {
-#pragma unroll
-        for (int k = 0; k < TWK; ++k) {
-            const unsigned i = (unsigned)tid + (unsigned)k * Body::NT;
-            if (i < n_tw3) l_tw3[i] = tw_stage[k];
-        }
-        for (unsigned i = (unsigned)tid + TWK * Body::NT; i < n_tw3; i += Body::NT)  // larger tables (N > 2^24): the plain way
-            l_tw3[i] = reinterpret_cast<const cx *>(a.tw3)[i];
-    }
-    __syncthreads();  // the only workgroup barrier: tables visible
-    if (!active) return;
+    l_twr[lane & 31] = twr_stage;  // both half-waves write the same values
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #if !defined(PHAST_WAVE_DEBUG_SKIP) || PHAST_WAVE_DEBUG_SKIP < 3   // tools only: 1 = no pre-twiddle, 2 = + no exchange, 3 = no arithmetic at all
 #if !defined(PHAST_WAVE_DEBUG_SKIP) || PHAST_WAVE_DEBUG_SKIP < 1
-    Body::pre_twiddle(a, l_tw3, lane, r);
+    if constexpr (PRE_TW) Body::pre_twiddle_apply(twraw, r);
 #endif
     Body::step1(l_twr, lane, r);
 #if !defined(PHAST_WAVE_DEBUG_SKIP) || PHAST_WAVE_DEBUG_SKIP < 2
@@ -352,10 +369,13 @@ hipError_t launch_wave_inst(hipStream_t stream, const TileArgs &a, bool query_on
         return hipSuccess;
     }
     const unsigned blocks = (a.tiles_total + Body::WAVES - 1) / Body::WAVES;
+    // the stagger pays when every wave of the launch is resident at once and they would all move in step: at most one
+    // tile per SIMD (256 CUs x 4).  With two tiles per SIMD the waves already interleave (2^21: 43.4 us without, 45.0 with).
+    const unsigned stagger = a.tiles_total <= 1024u ? wave_stagger_setting() : 0u;
     if (ev_start && ev_stop)
-        hipExtLaunchKernelGGL(kern, dim3(blocks), dim3(Body::NT), (uint32_t)lds, stream, ev_start, ev_stop, 0, a, blocks);
+        hipExtLaunchKernelGGL(kern, dim3(blocks), dim3(Body::NT), (uint32_t)lds, stream, ev_start, ev_stop, 0, a, blocks, stagger);
     else
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(Body::NT), lds, stream, a, blocks);
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(Body::NT), lds, stream, a, blocks, stagger);
     return hipGetLastError();
 }
 
