@@ -209,21 +209,8 @@ template <typename T> __device__ __forceinline__ void quad_lane_exchange(T (&re)
     });
 }
 
-// Stagger of the workgroups' first loads (cf. wave_fft.hpp): group g = block & mask sleeps g * units * 64 cycles; packed as
-// units | mask << 8, PHAST_QUAD_STAGGER="units,mask" overrides the default.
-#ifndef PHAST_QUAD_STAGGER_DEFAULT
-#define PHAST_QUAD_STAGGER_DEFAULT 0u
-#endif
-inline unsigned quad_stagger_setting() {
-    static const unsigned v = [] {
-        const char *e = getenv("PHAST_QUAD_STAGGER");
-        unsigned units = 0, mask = 0;
-        if (e && sscanf(e, "%u,%u", &units, &mask) == 2) return (units & 255u) | ((mask & 7u) << 8);
-        return (unsigned)PHAST_QUAD_STAGGER_DEFAULT;
-    }();
-    return v;
-}
-template <typename T> __global__ void __launch_bounds__(256) quad_fft_kernel(const TileArgs a, unsigned stagger) {
+// (Staggering the workgroups' or the waves' first loads, as wave_fft.hpp does, buys nothing here: profiles/r02_stagger.log.)
+template <typename T> __global__ void __launch_bounds__(256) quad_fft_kernel(const TileArgs a) {
     using Body = QuadBody<T>;
     using cx = cx_t<T>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -245,7 +232,6 @@ template <typename T> __global__ void __launch_bounds__(256) quad_fft_kernel(con
     unsigned t = blockIdx.x;
     if (t >= a.tiles_total) return;  // uniform over the workgroup
     Body::locate(a, t, r);
-    for (unsigned k = ((blockIdx.x >> 3) & (stagger >> 8)) * (stagger & 255u); k > 0; --k) __builtin_amdgcn_s_sleep(1);
     Body::load_raw(a, wave, lane, r);
     if (tid < Body::TWQ) l_twq[tid] = twq_stage;
     if (i0 < n_tw3) l_tw3[i0] = ts0;
@@ -299,9 +285,9 @@ hipError_t launch_quad_inst(unsigned grid, hipStream_t stream, const TileArgs &a
         return hipSuccess;
     }
     if (ev_start && ev_stop)
-        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(Body::NT), (uint32_t)lds, stream, ev_start, ev_stop, 0, a, quad_stagger_setting());
+        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(Body::NT), (uint32_t)lds, stream, ev_start, ev_stop, 0, a);
     else
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(Body::NT), lds, stream, a, quad_stagger_setting());
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(Body::NT), lds, stream, a);
     return hipGetLastError();
 }
 

@@ -5,11 +5,7 @@ import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 settings = sys.argv[1:] or ["0,0", "4,3", "6,3", "8,3", "10,3", "12,3", "4,7", "6,7", "8,7", "8,1", "16,1"]
 for s in settings:
-    env = dict(os.environ)
-    if s.startswith("q"):   # "q8,1": the quad kernel's block stagger, wave stagger left at its default
-        env["PHAST_QUAD_STAGGER"] = s[1:]
-    else:
-        env["PHAST_WAVE_STAGGER"] = s
+    env = dict(os.environ, PHAST_WAVE_STAGGER=s)
     vals = []
     for rep in range(2):
         out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-configs", "--no-scaling-reference"],
