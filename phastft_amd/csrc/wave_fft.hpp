@@ -15,8 +15,9 @@
 //      afterwards lane tau' = (b5 b4), register (p3 p2 s1 s0) holds the value of tau = (s1 s0), k1 = bitrev4(p3 p2 b5 b4)
 //   4. radix-4 DIF over tau in registers, four independent groups     -> register 4 g + s holds k2 = bitrev2(s)
 //      output row k = k1 + 16 k2
-// No workgroup barrier anywhere in a tile's life (one at kernel start, behind the twiddle-table staging); the four
-// waves of a 256-thread block are four independent tiles.  Pass A's transposition to contiguous output runs goes through
+// No workgroup barrier anywhere: the four waves of a 256-thread block are four independent tiles (own copy of the W_64
+// table in LDS, inter-pass tables read from global memory), and their loads are deliberately issued a little apart
+// (see the kernel: staggered waves).  Pass A's transposition to contiguous output runs goes through
 // a WAVE-PRIVATE LDS buffer (written and read by the same wave: ordered by the LDS queue, no barrier).
 //
 // Phase functions are __host__ __device__ (per lane); tests/emu/emu.hip runs them lane by lane with the swaps emulated.
