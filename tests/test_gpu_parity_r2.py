@@ -374,3 +374,46 @@ def test_real_transforms_f64_through_wave_and_quad_plans(gpu, oracle, k):
     oracle.c2r_fft_f64(s_re.copy(), s_im.copy(), want)
     assert rel_l2_real(got, want) <= 1e-9, k
     assert rel_l2_real(got, c2r_model(s_re, s_im, n)) <= F64_REL, k
+
+
+def test_staggered_waves_change_timing_not_results(gpu, oracle):
+    """wave_fft.hpp issues the loads of a workgroup's waves a little apart (PHAST_WAVE_STAGGER="units,mask", read once per
+    process): whatever the setting, one 2^20-point transform must come out bit-identical -- and equal to the oracle's."""
+    import hashlib
+    import subprocess
+    import sys
+
+    import torch
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, hashlib, torch\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "import phastft_amd as P\n"
+        "n = 1 << 20\n"
+        "re = torch.empty(n, dtype=torch.float64, device='cuda'); im = torch.empty_like(re)\n"
+        "P.fill_uniform(re, im, n, seed=0xCAFE, first_id=3)\n"
+        "pl = P.PlannerDit64(n)\n"
+        "assert 'w16' in pl.describe().split('single=')[1]\n"
+        "P.fft_64_dit_with_planner(re, im, P.Direction.Forward, pl)\n"
+        "torch.cuda.synchronize()\n"
+        "print(hashlib.sha256(re.cpu().numpy().tobytes() + im.cpu().numpy().tobytes()).hexdigest())\n"
+    )
+    digests = {}
+    for setting in ("0,0", "6,3", "12,7", "40,1"):
+        env = dict(os.environ, PHAST_WAVE_STAGGER=setting)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests[setting] = out.stdout.strip().splitlines()[-1]
+    assert len(set(digests.values())) == 1, digests
+    # the same transform in this process (default setting), against the oracle
+    n = 1 << 20
+    re = torch.empty(n, dtype=torch.float64, device="cuda")
+    im = torch.empty_like(re)
+    gpu.fill_uniform(re, im, n, seed=0xCAFE, first_id=3)
+    gpu.fft_64_dit_with_planner(re, im, gpu.Direction.Forward, gpu.PlannerDit64(n))
+    g_re, g_im = re.cpu().numpy(), im.cpu().numpy()
+    assert hashlib.sha256(g_re.tobytes() + g_im.tobytes()).hexdigest() == digests["0,0"]
+    r, m = oracle.fill(n, np.float64, seed=0xCAFE, transform_id=3)
+    oracle.fft_64_dit(r, m, oracle.FORWARD)
+    assert rel_l2(g_re, g_im, r, m) <= F64_REL
