@@ -221,6 +221,111 @@ __global__ void __launch_bounds__(NTH) bitrev_persistent2_kernel(U *data, unsign
     }
 }
 
+// Third generation (round 2, late): tiles of 128 x 128 elements -- rows of 1 KiB in f64 where the 64 x 64 tiles have 512 B.
+// A large array loses its bandwidth to the permutation's access pattern (profiles/r02_bitrev_stride_probe.log: the same
+// kernel runs at 5.8 TB/s on contiguous tiles and 3.9 on rows 8 MiB apart -- every row of a tile on another page): twice
+// the row halves the number of rows per byte.  Two 128 KiB tiles do not fit the LDS together, so the pair lives in
+// REGISTERS (1024 threads x 2 x 8 x 16 B) and goes through ONE padded LDS buffer one tile at a time; the next pair's
+// loads are issued as soon as the second tile has left the registers, under the last transposition and its stores.
+template <typename U, int BETA, int NTH>
+__global__ void __launch_bounds__(NTH) bitrev_persistent3_kernel(U *data, unsigned log_n, size_t dist, unsigned tiles,
+                                                                 unsigned long long total) {
+    using V2 = typename Vec2<U>::type;
+    constexpr int B = 1 << BETA, PER = B * B / (2 * NTH);  // element PAIRS per thread per tile
+    static_assert(PER >= 1, "tile too small for this workgroup");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    U(*s)[B + 1] = reinterpret_cast<U(*)[B + 1]>(smem_raw);
+    const unsigned tile_bits = log_n - 2 * BETA;
+    const unsigned ustride_log = log_n - BETA;
+    auto rev_t = [&](unsigned t) { return tile_bits ? (__brev(t) >> (32u - tile_bits)) : 0u; };
+    auto advance = [&](unsigned long long w) {  // next work item at or after `w` whose tile is the smaller of its pair
+        while (w < total) {
+            const unsigned t = (unsigned)(w % tiles);
+            if (t <= rev_t(t)) break;
+            w += gridDim.x;
+        }
+        return w;
+    };
+    V2 ra[PER], rb[PER];
+    auto load = [&](unsigned long long w) {
+        const unsigned t = (unsigned)(w % tiles), tr = rev_t(t);
+        const U *x = data + (size_t)(w / tiles) * dist;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = i * NTH + threadIdx.x;
+            const unsigned u = idx >> (BETA - 1), v = (idx & (B / 2 - 1)) * 2;
+            ra[i] = __builtin_nontemporal_load(reinterpret_cast<const V2 *>(x + ((size_t)u << ustride_log) + ((size_t)t << BETA) + v));
+        }
+        if (t != tr) {
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int idx = i * NTH + threadIdx.x;
+                const unsigned u = idx >> (BETA - 1), v = (idx & (B / 2 - 1)) * 2;
+                rb[i] = __builtin_nontemporal_load(reinterpret_cast<const V2 *>(x + ((size_t)u << ustride_log) + ((size_t)tr << BETA) + v));
+            }
+        }
+    };
+    auto to_lds = [&](const V2(&r)[PER]) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = i * NTH + threadIdx.x;
+            const unsigned u = idx >> (BETA - 1), v = (idx & (B / 2 - 1)) * 2;
+            s[u][v] = r[i].x;
+            s[u][v + 1] = r[i].y;
+        }
+    };
+    auto transposed_to = [&](U *x, unsigned tile) {  // element (u, v) of `tile` <- s[rev v][rev u]
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int idx = i * NTH + threadIdx.x;
+            const unsigned u = idx >> (BETA - 1), v = (idx & (B / 2 - 1)) * 2;
+            const unsigned ru = __brev(u) >> (32 - BETA), rv = __brev(v) >> (32 - BETA);  // rev(v + 1) = rv + B/2
+            V2 o;
+            o.x = s[rv][ru];
+            o.y = s[rv + B / 2][ru];
+            __builtin_nontemporal_store(o, reinterpret_cast<V2 *>(x + ((size_t)u << ustride_log) + ((size_t)tile << BETA) + v));
+        }
+    };
+    unsigned long long w = advance(blockIdx.x);
+    if (w < total) load(w);
+    while (w < total) {
+        const unsigned t = (unsigned)(w % tiles), tr = rev_t(t);
+        U *x = data + (size_t)(w / tiles) * dist;
+        const unsigned long long wn = advance(w + gridDim.x);
+        __syncthreads();  // the previous pair's readers are done
+        if (t != tr) {
+            to_lds(rb);
+            __syncthreads();
+            transposed_to(x, t);  // tile t receives tile rev(t), transposed and reversed
+            __syncthreads();
+        }
+        to_lds(ra);
+        if (wn < total) load(wn);  // both tiles have left the registers: the next pair's loads fly under what follows
+        __syncthreads();
+        transposed_to(x, tr);
+        w = wn;
+    }
+}
+
+template <typename U, int BETA, int NTH>
+static hipError_t launch_bitrev_persistent3(U *data, unsigned log_n, size_t batch, size_t dist, hipStream_t stream) {
+    constexpr int B = 1 << BETA;
+    const unsigned tiles = 1u << (log_n - 2 * BETA);
+    const unsigned long long total = (unsigned long long)tiles * batch;
+    unsigned long long grid = 256ull;  // one workgroup per CU: the LDS buffer is 129 KiB
+    if (grid > total) grid = total;
+    const size_t lds = sizeof(U) * B * (B + 1);
+    auto kern = bitrev_persistent3_kernel<U, BETA, NTH>;
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        raised = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTH), lds, stream, data, log_n, dist, tiles, total);
+    return hipGetLastError();
+}
+
 template <typename U, int BETA, int NTH, bool SPREAD>
 static hipError_t launch_bitrev_persistent2(U *data, unsigned log_n, size_t batch, size_t dist, hipStream_t stream,
                                             unsigned wg_per_cu) {
@@ -289,11 +394,15 @@ template <> hipError_t launch_bitrev<double>(double *data, unsigned log_n, size_
     if (v == 6 && even) return launch_bitrev_persistent2<unsigned long long, 6, 512, true>(p, log_n, batch, dist, s, 4);
     if (v == 7 && even) return launch_bitrev_persistent2<unsigned long long, 6, 256, true>(p, log_n, batch, dist, s, 4);
     if (v == 8 && even) return launch_bitrev_persistent2<unsigned long long, 6, 512, true>(p, log_n, batch, dist, s, 2);
+    if (v == 9 && even && log_n >= 14) return launch_bitrev_persistent3<unsigned long long, 7, 1024>(p, log_n, batch, dist, s);
+    if (v == 10 && even && log_n >= 14) return launch_bitrev_persistent3<unsigned long long, 7, 512>(p, log_n, batch, dist, s);
     // round 2 (profiles/r02_sweep_bitrev.log): once the array is past the 256 MiB Infinity Cache the 16-byte-per-lane,
     // non-temporal generation is 4-10 % faster (2^26: 3.9 vs 3.6 TB/s with 256 threads, 2^30: 3.8 vs 3.4 with 512);
     // the spread tile order buys nothing (so HBM channel camping is not what holds this kernel at ~0.75 of the copy
     // rate), and for 4-byte elements the first generation stays ahead at every size
-    if (v == 0 && even && log_n >= 29) return launch_bitrev_persistent2<unsigned long long, 6, 512, false>(p, log_n, batch, dist, s, 4);
+    // 2^27 points and up: 128 x 128 tiles held in registers (1 KiB rows): 2^27 3.4 -> 4.1 TB/s, 2^28 3.9 -> 4.0, 2^30 3.8 -> 4.0
+    // (profiles/r02_sweep_bitrev.log); below that there are too few tiles per CU for its one workgroup per CU (2^26: 3.7 vs 3.9)
+    if (v == 0 && even && log_n >= 27) return launch_bitrev_persistent3<unsigned long long, 7, 1024>(p, log_n, batch, dist, s);
     if (v == 0 && even && (((size_t)batch << log_n) >= ((size_t)1 << 25)))
         return launch_bitrev_persistent2<unsigned long long, 6, 256, true>(p, log_n, batch, dist, s, 4);
     return launch_bitrev_persistent<unsigned long long, 6, 512>(p, log_n, batch, dist, s, 4);

@@ -70,6 +70,25 @@ def test_bit_reversal_large_involution_and_checksum(gpu):
     assert torch.equal(x, torch.arange(1 << n, dtype=torch.float64, device="cuda"))
 
 
+@pytest.mark.parametrize("n", [27, 28])
+def test_bit_reversal_128x128_register_tiles_full_permutation(gpu, n):
+    """2^27 points and up run the third-generation kernel (128 x 128 tiles through registers and one LDS buffer, the next
+    pair prefetched): the WHOLE permutation against integer index arithmetic, then the involution."""
+    import torch
+
+    x = torch.arange(1 << n, dtype=torch.float64, device="cuda")
+    gpu.bit_rev_bravo_f64(x, n)
+    i = torch.arange(1 << n, dtype=torch.int64, device="cuda")
+    rev = torch.zeros_like(i)
+    for b in range(n):
+        rev |= ((i >> b) & 1) << (n - 1 - b)
+    del i
+    assert torch.equal(x.to(torch.int64), rev)
+    del rev
+    gpu.bit_rev_bravo_f64(x, n)
+    assert torch.equal(x, torch.arange(1 << n, dtype=torch.float64, device="cuda"))
+
+
 # ---------------------------------------------------------------- C2C vs the oracle
 @pytest.mark.parametrize("k", list(range(0, 23)))
 def test_fft_64_vs_oracle(gpu, oracle, k):
