@@ -72,8 +72,8 @@ template <typename T> struct QuadBody {
 
     PHAST_HD static void locate(const TileArgs &a, unsigned t, Regs &r) {  // as TileBody::locate
         const unsigned tile = ((a.tiles_total & 7u) == 0u) ? (t & 7u) * (a.tiles_total >> 3) + (t >> 3) : t;
-        r.xform = tile / a.tiles_per_xform;
-        const unsigned ti = tile - r.xform * a.tiles_per_xform;
+        r.xform = tile >> (unsigned)__builtin_ctz(a.tiles_per_xform);  // a power of two (plan.hpp: geom_to_args)
+        const unsigned ti = tile & (a.tiles_per_xform - 1u);
         r.g0 = a.cs_bits ? (((ti >> a.cb_bits) << a.cs_bits) | ((ti & ((1u << a.cb_bits) - 1u)) << LC)) : (ti << LC);
     }
 
@@ -213,6 +213,7 @@ template <typename T> __device__ __forceinline__ void quad_lane_exchange(T (&re)
 template <typename T> __global__ void __launch_bounds__(256) quad_fft_kernel(const TileArgs a) {
     using Body = QuadBody<T>;
     using cx = cx_t<T>;
+    pin_tile_args(a);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T *ex_re = reinterpret_cast<T *>(smem);
     T *ex_im = ex_re + Body::EXCH;

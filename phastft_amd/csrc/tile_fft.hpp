@@ -178,8 +178,8 @@ template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool 
     // pages and L2 lines -- meet in one L2.
     PHAST_HD static void locate(const TileArgs &a, unsigned t, Regs &r) {
         const unsigned tile = ((a.tiles_total & 7u) == 0u) ? (t & 7u) * (a.tiles_total >> 3) + (t >> 3) : t;
-        r.xform = tile / a.tiles_per_xform;
-        const unsigned ti = tile - r.xform * a.tiles_per_xform;
+        r.xform = tile >> (unsigned)__builtin_ctz(a.tiles_per_xform);  // a power of two (plan.hpp: geom_to_args)
+        const unsigned ti = tile & (a.tiles_per_xform - 1u);
         r.g0 = a.cs_bits ? (((ti >> a.cb_bits) << a.cs_bits) | ((ti & ((1u << a.cb_bits) - 1u)) << LC)) : (ti << LC);
     }
 
@@ -407,6 +407,7 @@ __global__ void __launch_bounds__(1 << (LR + LC - LP), PHAST_MIN_WAVES(LR, LC)) 
     using Body = TileBody<T, LR, LC, LP, PRE_TW, TRANSPOSE, SEQ>;
     using cx = cx_t<T>;
     constexpr int NT = Body::NT;
+    pin_tile_args(a);  // all scalar loads of the arguments at once (common.hpp)
 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T *ex_re = reinterpret_cast<T *>(smem);

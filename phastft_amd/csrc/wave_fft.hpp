@@ -69,8 +69,8 @@ template <typename T, bool PRE_TW, bool TRANSPOSE> struct WaveBody {
     PHAST_HD static void locate(const TileArgs &a, unsigned block, unsigned blocks_total, unsigned wave, Regs &r) {
         const unsigned b = ((blocks_total & 7u) == 0u) ? (block & 7u) * (blocks_total >> 3) + (block >> 3) : block;
         const unsigned tile = b * WAVES + wave;
-        r.xform = tile / a.tiles_per_xform;
-        const unsigned ti = tile - r.xform * a.tiles_per_xform;
+        r.xform = tile >> (unsigned)__builtin_ctz(a.tiles_per_xform);  // a power of two (plan.hpp: geom_to_args)
+        const unsigned ti = tile & (a.tiles_per_xform - 1u);
         r.g0 = a.cs_bits ? (((ti >> a.cb_bits) << a.cs_bits) | ((ti & ((1u << a.cb_bits) - 1u)) << LC)) : (ti << LC);
     }
 
@@ -270,7 +270,7 @@ template <typename T> __device__ __forceinline__ void wave_exchange(T (&re)[16],
 // Stagger of the waves' loads (see the kernel): group g = ((block & 1) << 2 | wave) & mask sleeps g * units * 64 cycles.
 // Packed as units | mask << 8; PHAST_WAVE_STAGGER="units,mask" overrides the default (tuning, tools/sweep_stagger.py).
 #ifndef PHAST_WAVE_STAGGER_DEFAULT
-#define PHAST_WAVE_STAGGER_DEFAULT (6u | (3u << 8))
+#define PHAST_WAVE_STAGGER_DEFAULT (8u | (3u << 8))
 #endif
 inline unsigned wave_stagger_setting() {
     static const unsigned v = [] {
@@ -285,6 +285,8 @@ template <typename T, bool PRE_TW, bool TRANSPOSE>
 __global__ void __launch_bounds__(64 * PHAST_WAVE_TILES_PER_BLOCK) wave_fft_kernel(const TileArgs a, unsigned blocks_total, unsigned stagger) {
     using Body = WaveBody<T, PRE_TW, TRANSPOSE>;
     using cx = cx_t<T>;
+    pin_tile_args(a);
+    pin_scalars(blocks_total, stagger);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // everything in LDS is private to a wave: its copy of the W_64 step-twiddle table and its transposing buffer.  No
