@@ -166,9 +166,8 @@ template <typename T, bool PRE_TW, bool TRANSPOSE> struct WaveBody {
         return (size_t)(r.g0 & ((1u << a.out_lo_bits) - 1u)) * a.out_s1 + (size_t)(r.g0 >> a.out_lo_bits) * a.out_s2 +
                (size_t)r.xform * a.out_dist;
     }
-    PHAST_HD static void put(const TileArgs &a, size_t ubase, unsigned voff, T re, T im) {
-        const T scale = (T)a.scale;
-        if (TRANSPOSE || !a.out_interleaved) {
+    template <bool PAIRS> PHAST_HD static void put(const TileArgs &a, size_t ubase, unsigned voff, T re, T im, T scale) {
+        if constexpr (!PAIRS) {
             if constexpr (NT_STORE) {
                 __builtin_nontemporal_store(re * scale, reinterpret_cast<T *>(a.out_re) + ubase + voff);
                 __builtin_nontemporal_store(im * scale, reinterpret_cast<T *>(a.out_im) + ubase + voff);
@@ -183,13 +182,21 @@ template <typename T, bool PRE_TW, bool TRANSPOSE> struct WaveBody {
             (reinterpret_cast<cx *>(a.out_re) + ubase)[voff] = v;
         }
     }
-    // later passes: same column-wide pattern out as in
+    // later passes: same column-wide pattern out as in.  The planar / (re, im)-pair decision is taken ONCE, outside the
+    // sixteen stores (inside, it was a scalar branch per store).
     PHAST_HD static void store_rows(const TileArgs &a, int lane, const Regs &r) {
         const size_t base = out_base(a, r);
         const unsigned voff = (unsigned)col_of(lane) * (unsigned)a.out_s1 + krow_lane(lane) * (unsigned)a.out_row_stride;
-        static_for<0, P>([&](auto Q) {
-            put(a, base + (size_t)krow_const<decltype(Q)::value>() * a.out_row_stride, voff, r.re[Q], r.im[Q]);
-        });
+        const T scale = (T)a.scale;
+        if (!a.out_interleaved) {
+            static_for<0, P>([&](auto Q) {
+                put<false>(a, base + (size_t)krow_const<decltype(Q)::value>() * a.out_row_stride, voff, r.re[Q], r.im[Q], scale);
+            });
+        } else {
+            static_for<0, P>([&](auto Q) {
+                put<true>(a, base + (size_t)krow_const<decltype(Q)::value>() * a.out_row_stride, voff, r.re[Q], r.im[Q], scale);
+            });
+        }
     }
     // pass A: through the wave-private buffer [col][k], then register Q holds row k = lane of column Q
     template <int Q> PHAST_HD static int xp_write_addr(int lane) {
@@ -199,7 +206,8 @@ template <typename T, bool PRE_TW, bool TRANSPOSE> struct WaveBody {
     PHAST_HD static void store_runs(const TileArgs &a, int lane, const Regs &r) {
         const size_t base = out_base(a, r);
         const unsigned voff = (unsigned)lane * (unsigned)a.out_row_stride;
-        static_for<0, P>([&](auto Q) { put(a, base + (size_t)decltype(Q)::value * a.out_s1, voff, r.re[Q], r.im[Q]); });
+        const T scale = (T)a.scale;
+        static_for<0, P>([&](auto Q) { put<false>(a, base + (size_t)decltype(Q)::value * a.out_s1, voff, r.re[Q], r.im[Q], scale); });
     }
 };
 
@@ -311,6 +319,9 @@ __global__ void __launch_bounds__(64 * PHAST_WAVE_TILES_PER_BLOCK) wave_fft_kern
     for (unsigned k = ((((blockIdx.x & 1u) << 2) | (unsigned)wave) & (stagger >> 8)) * (stagger & 255u); k > 0; --k)
         __builtin_amdgcn_s_sleep(1);
     Body::load_raw(a, lane, r);
+#ifdef PHAST_WAVE_WAIT_ALL  // tools only: every load back before anything else happens
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
 #if defined(PHAST_WAVE_DEBUG_SKIP) && PHAST_WAVE_DEBUG_SKIP >= 4  // tools only: no table staging
     if (a.tiles_total == 0xffffffffu) l_twr[lane & 31] = twr_stage;
     if constexpr (TRANSPOSE) { } else { Body::store_rows(a, lane, r); return; }
