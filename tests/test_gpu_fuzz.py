@@ -55,3 +55,48 @@ def test_random_batches_against_pocketfft(gpu, chunk):
             for b in range(batch - 1):
                 gap = slice(b * dist + n, (b + 1) * dist)
                 assert np.array_equal(g_re[gap], re[gap]) and np.array_equal(g_im[gap], im[gap]), (k, batch, pad, dt, b)
+
+
+@pytest.mark.parametrize("chunk", range(3))
+def test_random_real_batches_against_pocketfft(gpu, chunk):
+    """R2C and C2R batches (inputs n apart, spectra n/2 + 1 apart): rfft / irfft in double precision.  The reference's
+    R2C twiddles are an f64 rotation recurrence (planner.rs:120-162) -- the GPU tables are exact to rounding, so f64
+    stays within 1e-13 of pocketfft (tests/test_gpu_parity.py compares with the oracle's drift separately)."""
+    import torch
+
+    rng0 = np.random.default_rng(0xBEA1 + chunk)
+    for _ in range(20):
+        k = int(rng0.integers(2, 22))
+        n = 1 << k
+        batch = int(min(rng0.choice([1, 2, 3, 5, 8, 16, 17, 33]), max(1, (1 << 23) >> k)))
+        dt = "f64" if rng0.random() < 0.6 else "f32"
+        np_t = np.float64 if dt == "f64" else np.float32
+        tol = F64_REL if dt == "f64" else F32_REL
+        rng = np.random.default_rng(k * 100 + batch)
+        x = rng.uniform(-1, 1, batch * n).astype(np_t)
+        planner = (gpu.PlannerR2c64 if dt == "f64" else gpu.PlannerR2c32)(n)
+        half = n // 2 + 1
+        d_x = torch.from_numpy(x.copy()).cuda()
+        d_re = torch.empty(batch * half, dtype=d_x.dtype, device="cuda")
+        d_im = torch.empty_like(d_re)
+        gpu.r2c_fft_batched(d_x, d_re, d_im, planner, batch)
+        assert torch.equal(d_x.cpu(), torch.from_numpy(x)), "R2C must not modify its input (r2c.rs:535)"
+        g_re, g_im = d_re.cpu().numpy().astype(np.float64), d_im.cpu().numpy().astype(np.float64)
+        for b in range(batch):
+            want = np.fft.rfft(x[b * n:(b + 1) * n].astype(np.float64))
+            got = g_re[b * half:(b + 1) * half] + 1j * g_im[b * half:(b + 1) * half]
+            err = np.linalg.norm(got - want) / np.linalg.norm(want)
+            assert err <= tol, ("r2c", k, batch, dt, b, err)
+        # C2R of a random Hermitian-consistent spectrum
+        s_re = rng.uniform(-1, 1, batch * half).astype(np_t)
+        s_im = rng.uniform(-1, 1, batch * half).astype(np_t)
+        s_im[0::half] = 0   # irfft ignores Im(DC) and Im(Nyquist); the reference's formulas use them (r2c.rs:263-489,
+        s_im[half - 1::half] = 0  # covered against the oracle in tests/test_gpu_parity_r2.py): keep the comparison Hermitian
+        d_out = torch.empty(batch * n, dtype=d_x.dtype, device="cuda")
+        gpu.c2r_fft_batched(torch.from_numpy(s_re.copy()).cuda(), torch.from_numpy(s_im.copy()).cuda(), d_out, planner, batch)
+        g = d_out.cpu().numpy().astype(np.float64)
+        for b in range(batch):
+            spec = s_re[b * half:(b + 1) * half].astype(np.float64) + 1j * s_im[b * half:(b + 1) * half].astype(np.float64)
+            want = np.fft.irfft(spec, n)
+            err = np.linalg.norm(g[b * n:(b + 1) * n] - want) / np.linalg.norm(want)
+            assert err <= tol, ("c2r", k, batch, dt, b, err)
