@@ -42,7 +42,7 @@ struct RowArgs {
 };
 
 template <typename T, int LR, int LC, int LP> struct RowBody {
-    using Body = TileBody<T, LR, LC, LP, false, true, false>;
+    using Body = TileBody<T, LR, LC, LP, false, true, false, false>;  // its own park / store: the classic transposing exchange
     using Regs = typename Body::Regs;
     using Shared = typename Body::Shared;
     using cx = cx_t<T>;

@@ -115,7 +115,7 @@ template <typename T, int R, int OFF, int P> PHAST_HD void fft_reg_dif(T (&re)[P
 //     sees consecutive rows by construction; exchange 1 (whose writers stride by K_1 rows) gets one pad row per
 //     n' = n_rest when the group spans G > 1 rows.
 // After the last step register I*R_S + j of thread tau holds frequency row bitrev(j)*K_{S-1} + tau + M*I.
-template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool SEQ> struct TileBody {
+template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool SEQ, bool ALLOW_DIRECT = true> struct TileBody {
     using cx = cx_t<T>;
     static constexpr int ROWS = 1 << LR;
     static constexpr int COLS = 1 << LC;
@@ -134,9 +134,23 @@ template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool 
     static constexpr int CS = ROWS + GW;
     static constexpr int E1S = P + (G > 1 ? 1 : 0);  // rows per n' in exchange 1 (P used + padding)
     static constexpr int TWR = ROWS > 1024 ? 32 + ROWS / 32 : 64;  // staged entries of the W_ROWS table (plan.hpp: host_twr)
-    static constexpr int EXCH_E1 = M * E1S * COLS;
-    static constexpr int EXCH_ET = TRANSPOSE ? COLS * CS : 0;
-    static constexpr int EXCH = EXCH_E1 > EXCH_ET ? EXCH_E1 : EXCH_ET;
+    // DIRECT (first passes with at least one exchange and runs of >= 128 bytes per M threads): no transposing exchange.
+    // The readers of the LAST exchange take the thread order (tau fastest, then column) instead of (column fastest, tau),
+    // so that after the last radix step the lanes of a wave hold M consecutive output rows of a column: the stores go
+    // out as runs of M elements straight from the registers, and one whole LDS round trip (two or four barriers) of the
+    // pass is gone.  The last exchange then has a column pitch of COLS + 32/M cells, which keeps the row-fastest
+    // readers (and the column-fastest writers) free of bank conflicts (tests/test_emulator.py audits every shape).
+#ifndef PHAST_DIRECT_RUNS
+#define PHAST_DIRECT_RUNS 1
+#endif
+    static constexpr bool DIRECT = PHAST_DIRECT_RUNS && ALLOW_DIRECT && TRANSPOSE && S >= 2 && M * (int)sizeof(T) >= 128 && M <= 32 &&
+                                   COLS * (int)sizeof(T) >= 128;  // (narrower tiles: a write group spans rows, pitch rules differ)
+    static constexpr int PITCH_L = DIRECT ? COLS + 32 / M : COLS;  // column pitch of exchange S - 1
+    template <int E> static constexpr int pitch() { return (DIRECT && E == S - 1) ? PITCH_L : COLS; }
+    static constexpr int EXCH_E1 = M * E1S * pitch<1>();
+    static constexpr int EXCH_EL = S > 2 ? ROWS * pitch<S - 1>() : 0;
+    static constexpr int EXCH_ET = (TRANSPOSE && !DIRECT) ? COLS * CS : 0;
+    static constexpr int EXCH = EXCH_E1 > EXCH_ET ? (EXCH_E1 > EXCH_EL ? EXCH_E1 : EXCH_EL) : (EXCH_ET > EXCH_EL ? EXCH_ET : EXCH_EL);
     // Non-temporal global accesses when a tile row is a whole 128-byte line or more: every byte is touched once
     // per pass, and the strided-copy microbenchmark gains 5-10 % (profiles/r01_strided_copy_nt.log).  Narrower
     // rows share their line with the neighbouring tile and NEED the L2 (nt loads cost 25 % there).
@@ -283,7 +297,10 @@ template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool 
 
     // frequency index (row of the tile FFT output) held by register Q after the last step
     //   = krow_lane(tid) + krow_const<Q>()
-    PHAST_HD static unsigned krow_lane(int tid) { return (unsigned)tau_of(tid); }
+    // thread order of the last radix step: (column fastest, tau), or (tau fastest, column) for DIRECT passes
+    PHAST_HD static int tau_last(int tid) { return DIRECT ? (tid & (M - 1)) : tau_of(tid); }
+    PHAST_HD static int col_last(int tid) { return DIRECT ? (tid >> LM) : col_of(tid); }
+    PHAST_HD static unsigned krow_lane(int tid) { return (unsigned)tau_last(tid); }
     template <int Q> PHAST_HD static constexpr unsigned krow_const() {
         constexpr int RB = rbits(S), R = 1 << RB;
         return (unsigned)(bitrev_c(Q % R, RB) << kbits(S - 1)) + (unsigned)(M * (Q / R));
@@ -301,19 +318,20 @@ template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool 
             constexpr int RB = rbits(E), R = 1 << RB, KB = kbits(E - 1);
             constexpr int I = Q / R, KE = bitrev_c(Q % R, RB);
             const int b = tau + M * I, k_low = b & ((1 << KB) - 1), n_rest = b >> KB;
-            return (phys_row<E>(n_rest, (KE << KB) + k_low) << LC) + col;
+            return phys_row<E>(n_rest, (KE << KB) + k_low) * pitch<E>() + col;
         } else {  // [col][k]
             return col * CS + (int)krow_lane(tid) + (int)krow_const<Q>();
         }
     }
     template <int E, int Q> PHAST_HD static int raddr(int tid) {
-        const int col = col_of(tid), tau = tau_of(tid);
+        // the readers of the last exchange are the threads of the last step: their order may differ (DIRECT)
+        const int col = (E == S - 1) ? col_last(tid) : col_of(tid), tau = (E == S - 1) ? tau_last(tid) : tau_of(tid);
         if constexpr (E < S) {  // read by step E+1: register Q = I*R + j holds input digit n_{E+1} = j
             constexpr int RB = rbits(E + 1), R = 1 << RB, KB = kbits(E);
             constexpr int I = Q / R, J = Q % R;
             constexpr int L = ROWS >> (KB + RB);  // values of the digits after n_{E+1}
             const int b = tau + M * I, k_low = b & ((1 << KB) - 1), n_rest = b >> KB;
-            return (phys_row<E>(J * L + n_rest, k_low) << LC) + col;
+            return phys_row<E>(J * L + n_rest, k_low) * pitch<E>() + col;
         } else {
             const int f = Q * NT + tid;
             return (f >> LR) * CS + (f & (ROWS - 1));
@@ -361,8 +379,8 @@ template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool 
     }
     PHAST_HD static void store(const TileArgs &a, int tid, const Regs &r) {
         const size_t base = out_base(a, r);
-        if constexpr (!TRANSPOSE) {  // register Q holds row krow_lane + krow_const<Q> of column g0 + col
-            const unsigned voff = (unsigned)col_of(tid) * (unsigned)a.out_s1 + krow_lane(tid) * (unsigned)a.out_row_stride;
+        if constexpr (!TRANSPOSE || DIRECT) {  // register Q holds row krow_lane + krow_const<Q> of column g0 + col
+            const unsigned voff = (unsigned)col_last(tid) * (unsigned)a.out_s1 + krow_lane(tid) * (unsigned)a.out_row_stride;
             static_for<0, P>([&](auto Q) {
                 put(a, base + (size_t)krow_const<decltype(Q)::value>() * a.out_row_stride, voff, r.re[Q], r.im[Q]);
             });
@@ -391,7 +409,7 @@ template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool 
             do_step(i);
             if constexpr (decltype(i)::value < S) do_exchange(i);
         });
-        if constexpr (TRANSPOSE) do_exchange(std::integral_constant<int, S>{});
+        if constexpr (TRANSPOSE && !DIRECT) do_exchange(std::integral_constant<int, S>{});
     }
 };
 

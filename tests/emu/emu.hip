@@ -135,7 +135,7 @@ template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE> stati
         }
     };
     static_for<1, Body::S>([&](auto e) { audit(e); });
-    if constexpr (TRANSPOSE) audit(std::integral_constant<int, Body::S>{});
+    if constexpr (TRANSPOSE && !Body::DIRECT) audit(std::integral_constant<int, Body::S>{});
     *max_read_ways = rw;
     *max_write_ways = ww;
     return errors;
