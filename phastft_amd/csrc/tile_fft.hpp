@@ -247,13 +247,15 @@ template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool 
                 e0 = (unsigned)tau * lo;
                 de = (unsigned)M * lo;
             }
-            if constexpr (sizeof(T) == 8 && LR >= PHAST_TW_PROG_MIN_LR && LP >= PHAST_TW_PROG_MIN_LP) {
+            if constexpr (LR >= PHAST_TW_PROG_MIN_LR && LP >= PHAST_TW_PROG_MIN_LP) {
                 // W^(e0 + j de) = W^e0 (W^de)^j: two look-ups and a geometric progression (tw_progression) instead of P look-ups
                 // -- fewer complex products, 6 LDS reads per thread instead of 3 P, none of them conflicting
                 // (the data-dependent table reads were 29 % of the LDS cycles of these passes, profiles/r01_sq_batch_lds.txt).
                 // Measured (profiles/r02_tw_ladder.log): the 1024 x 16 pass of the batched 2^20 transforms 2.17 -> 2.07 ms
-                // per 256 transforms; the 256 x 64 passes of 2^24 LOSE 3 % with it, hence the shape condition.  f64 only:
-                // the progression adds <= 9 roundings (1e-15), nothing against 1e-13, too much of f32's margin.
+                // per 256 transforms; the 256 x 64 passes of 2^24 LOSE 3 % with it, hence the shape condition.  The progression
+                // adds <= 9 roundings: 1e-15 in f64 against the 1e-13 budget; in f32 the 1024 x 32 pass gains 9 % (2.12 -> 1.90 ms
+                // per 512 transforms: this shape spills registers under 32 look-ups) and the batch's rel-L2 error stays at
+                // 6e-7 against 1e-5.
                 T br, bi, dr, di;
                 tw3_lookup<T>(sh.tw3, a.tw_bits, e0, br, bi);
                 tw3_lookup<T>(sh.tw3, a.tw_bits, de, dr, di);
