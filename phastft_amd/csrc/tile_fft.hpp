@@ -27,7 +27,7 @@
 #include "common.hpp"
 
 #ifndef PHAST_TW_PROG_MIN_LR  // shapes whose pre-twiddle is a progression instead of P look-ups (tuning: tools/cmp_throughput.py)
-#define PHAST_TW_PROG_MIN_LR 10
+#define PHAST_TW_PROG_MIN_LR 9
 #endif
 #ifndef PHAST_TW_PROG_MIN_LP
 #define PHAST_TW_PROG_MIN_LP 5
@@ -252,7 +252,8 @@ template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool 
                 // -- fewer complex products, 6 LDS reads per thread instead of 3 P, none of them conflicting
                 // (the data-dependent table reads were 29 % of the LDS cycles of these passes, profiles/r01_sq_batch_lds.txt).
                 // Measured (profiles/r02_tw_ladder.log): the 1024 x 16 pass of the batched 2^20 transforms 2.17 -> 2.07 ms
-                // per 256 transforms; the 256 x 64 passes of 2^24 LOSE 3 % with it, hence the shape condition.  The progression
+                // per 256 transforms; 512-row tiles gain 1-3 % (2^26: 49.3 -> 50.3 GSamples/s, 2^28: 39.1 -> 40.2); the 256 x 64
+                // passes of 2^24 LOSE 3 % with it, hence the shape condition (rows >= 512, 32 points per thread).  The progression
                 // adds <= 9 roundings: 1e-15 in f64 against the 1e-13 budget; in f32 the 1024 x 32 pass gains 9 % (2.12 -> 1.90 ms
                 // per 512 transforms: this shape spills registers under 32 look-ups) and the batch's rel-L2 error stays at
                 // 6e-7 against 1e-5.
