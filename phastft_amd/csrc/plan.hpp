@@ -186,14 +186,9 @@ inline void heuristic_plan(unsigned L, bool latency, std::vector<unsigned> &lrs,
         split(3);
         if (!f64 && L % 3 == 1) std::swap(lrs[0], lrs[1]);  // f32: the odd one out in the middle (+2..8 %)
         tls.assign(1, 13);
-    } else if (L <= 27 || !f64) {
-        split(3);
+    } else {  // (f64, L >= 28: the last pass's twiddle tables no longer fit the LDS next to a 16384-point tile -- those
+        split(3);  //  passes read their six table entries per thread from global memory, TileBody::tw3_global)
         tls.assign(1, (!f64 && L >= 26) ? 15 : 14);
-        lp = 5;
-    } else {  // f64, L >= 28: the last pass's twiddle tables leave no room for a 16384-point tile
-        split(3);
-        if (L % 3 == 1) std::swap(lrs[0], lrs[1]);
-        tls.assign(1, 13);
         lp = 5;
     }
 }

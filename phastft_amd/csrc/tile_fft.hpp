@@ -164,9 +164,18 @@ template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool 
     static constexpr int rbits(int i) { return i < S ? LP : LR - LP * (S - 1); }
     static constexpr int kbits(int i) { return i <= 0 ? 0 : (i < S ? LP * i : LR); }
 
+    // the pre-twiddle as two look-ups + a progression (see pre_twiddle): six table entries per thread and tile
+    static constexpr bool PROG = PRE_TW && LR >= PHAST_TW_PROG_MIN_LR && LP >= PHAST_TW_PROG_MIN_LP;
+    // ... which may as well come straight from global memory when the three-level tables (48 KiB from N = 2^28 on)
+    // no longer fit the LDS next to the tile: the 16384-point tiles stay available for the largest transforms
+    // (2^28 f64: 1024 x 8 tiles with 64-byte rows were the fallback, 20 % slower)
+    PHAST_HD static bool tw3_global(unsigned tw_bits) {
+        const size_t exch = (size_t)EXCH * sizeof(T) * (PLANE_SEQ ? 1 : 2);
+        return PROG && exch + (size_t)(3u << tw_bits) * sizeof(cx) + TWR * sizeof(cx) > (size_t)160 * 1024;
+    }
     static size_t lds_bytes(unsigned tw_bits) {
         size_t exch = (size_t)EXCH * sizeof(T) * (PLANE_SEQ ? 1 : 2);
-        size_t tw3 = PRE_TW ? (size_t)(3u << tw_bits) * sizeof(cx) : 0;
+        size_t tw3 = (PRE_TW && !tw3_global(tw_bits)) ? (size_t)(3u << tw_bits) * sizeof(cx) : 0;
         return exch + tw3 + TWR * sizeof(cx);
     }
 
@@ -232,22 +241,35 @@ template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool 
             });
         }
     }
+    // exponent of row j*M + tau of this thread's column: e0 + j*de (mod 2^32, a multiple of every table modulus)
+    PHAST_HD static void pre_twiddle_exps(const TileArgs &a, int tid, const Regs &r, unsigned &e0, unsigned &de) {
+        const int col = col_of(tid), tau = tau_of(tid);
+        if (a.grid_mode) {  // input twiddle of a four-step split: (row << shift | glo) * (col0 + c)
+            const unsigned g = r.g0 + (unsigned)col, k = a.grid_col0 + (g & a.grid_col_mask), glo = g >> a.tw_shift;
+            const unsigned big = k << a.grid_row_shift;
+            e0 = (unsigned)tau * big + glo * k;
+            de = (unsigned)M * big;
+        } else {
+            const unsigned lo = ((r.g0 + (unsigned)col) >> a.tw_shift) & a.tw_mask;
+            e0 = (unsigned)tau * lo;
+            de = (unsigned)M * lo;
+        }
+    }
+    // PROG: the progression W^e0 (W^de)^j from the six raw table entries (fetched by the caller from LDS or global memory)
+    PHAST_HD static void pre_twiddle_progress(const Tw3Raw<T> &tb, const Tw3Raw<T> &td, Regs &r) {
+        T br, bi, dr, di;
+        tw3_combine<T>(tb, br, bi);
+        tw3_combine<T>(td, dr, di);
+        tw_progression<T, P, (P >= 32 ? 8 : 4)>(br, bi, dr, di, [&](auto j, T wr, T wi) {
+            cmul(r.re[decltype(j)::value], r.im[decltype(j)::value], wr, wi);
+        });
+    }
     // inter-pass twiddle W_{ROWS*S_in}^{row*lo} on the freshly loaded rows (needs the LDS tables)
     PHAST_HD static void pre_twiddle(const TileArgs &a, const Shared &sh, int tid, Regs &r) {
         if constexpr (PRE_TW) {
-            const int col = col_of(tid), tau = tau_of(tid);
-            unsigned e0, de;  // exponent of row j*M + tau: e0 + j*de (mod 2^32, a multiple of every table modulus)
-            if (a.grid_mode) {  // input twiddle of a four-step split: (row << shift | glo) * (col0 + c)
-                const unsigned g = r.g0 + (unsigned)col, k = a.grid_col0 + (g & a.grid_col_mask), glo = g >> a.tw_shift;
-                const unsigned big = k << a.grid_row_shift;
-                e0 = (unsigned)tau * big + glo * k;
-                de = (unsigned)M * big;
-            } else {
-                const unsigned lo = ((r.g0 + (unsigned)col) >> a.tw_shift) & a.tw_mask;
-                e0 = (unsigned)tau * lo;
-                de = (unsigned)M * lo;
-            }
-            if constexpr (LR >= PHAST_TW_PROG_MIN_LR && LP >= PHAST_TW_PROG_MIN_LP) {
+            unsigned e0, de;
+            pre_twiddle_exps(a, tid, r, e0, de);
+            if constexpr (PROG) {
                 // W^(e0 + j de) = W^e0 (W^de)^j: two look-ups and a geometric progression (tw_progression) instead of P look-ups
                 // -- fewer complex products, 6 LDS reads per thread instead of 3 P, none of them conflicting
                 // (the data-dependent table reads were 29 % of the LDS cycles of these passes, profiles/r01_sq_batch_lds.txt).
@@ -257,12 +279,7 @@ template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool 
                 // adds <= 9 roundings: 1e-15 in f64 against the 1e-13 budget; in f32 the 1024 x 32 pass gains 9 % (2.12 -> 1.90 ms
                 // per 512 transforms: this shape spills registers under 32 look-ups) and the batch's rel-L2 error stays at
                 // 6e-7 against 1e-5.
-                T br, bi, dr, di;
-                tw3_lookup<T>(sh.tw3, a.tw_bits, e0, br, bi);
-                tw3_lookup<T>(sh.tw3, a.tw_bits, de, dr, di);
-                tw_progression<T, P, (P >= 32 ? 8 : 4)>(br, bi, dr, di, [&](auto j, T wr, T wi) {
-                    cmul(r.re[decltype(j)::value], r.im[decltype(j)::value], wr, wi);
-                });
+                pre_twiddle_progress(tw3_fetch<T>(sh.tw3, a.tw_bits, e0), tw3_fetch<T>(sh.tw3, a.tw_bits, de), r);
             } else {
                 static_for<0, P>([&](auto j) {
                     T wr, wi;
@@ -433,7 +450,8 @@ __global__ void __launch_bounds__(1 << (LR + LC - LP), PHAST_MIN_WAVES(LR, LC)) 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T *ex_re = reinterpret_cast<T *>(smem);
     cx *l_tw3 = reinterpret_cast<cx *>(smem + (size_t)Body::EXCH * sizeof(T) * (Body::PLANE_SEQ ? 1 : 2));
-    cx *l_twr = l_tw3 + (PRE_TW ? (3u << a.tw_bits) : 0u);
+    const bool tw_global = Body::tw3_global(a.tw_bits);  // uniform: inter-pass tables read from global memory, not staged
+    cx *l_twr = l_tw3 + ((PRE_TW && !tw_global) ? (3u << a.tw_bits) : 0u);
     const typename Body::Shared sh{ex_re, Body::PLANE_SEQ ? ex_re : ex_re + Body::EXCH, l_tw3, l_twr};
 
     int tid = threadIdx.x;
@@ -462,7 +480,8 @@ __global__ void __launch_bounds__(1 << (LR + LC - LP), PHAST_MIN_WAVES(LR, LC)) 
     }
     for (int i = tid; i < Body::TWR; i += NT) l_twr[i] = reinterpret_cast<const cx *>(a.twr)[i];
     if constexpr (PRE_TW)
-        for (unsigned i = tid; i < (3u << a.tw_bits); i += NT) l_tw3[i] = reinterpret_cast<const cx *>(a.tw3)[i];
+        if (!tw_global)
+            for (unsigned i = tid; i < (3u << a.tw_bits); i += NT) l_tw3[i] = reinterpret_cast<const cx *>(a.tw3)[i];
     __syncthreads();
     stamp();  // 1: twiddle tables in LDS
 
@@ -501,7 +520,21 @@ __global__ void __launch_bounds__(1 << (LR + LC - LP), PHAST_MIN_WAVES(LR, LC)) 
         // addresses, ~100 values) is then recomputed per tile with a few integer ops instead of being hoisted out
         // of this loop and kept live -- or spilled -- across it.
         asm volatile("" : "+v"(tid));
-        Body::pre_twiddle(a, sh, tid, r);
+        if constexpr (Body::PROG) {  // only the six table reads differ (ds_read / global_load); the arithmetic is shared
+            unsigned e0, de;
+            Body::pre_twiddle_exps(a, tid, r, e0, de);
+            Tw3Raw<T> tb, td;
+            if (tw_global) {
+                tb = tw3_fetch<T>(reinterpret_cast<const cx *>(a.tw3), a.tw_bits, e0);
+                td = tw3_fetch<T>(reinterpret_cast<const cx *>(a.tw3), a.tw_bits, de);
+            } else {
+                tb = tw3_fetch<T>(l_tw3, a.tw_bits, e0);
+                td = tw3_fetch<T>(l_tw3, a.tw_bits, de);
+            }
+            Body::pre_twiddle_progress(tb, td, r);
+        } else {
+            Body::pre_twiddle(a, sh, tid, r);
+        }
         stamp();  // 2: tile loaded (+ pre-twiddle)
         Body::chain(do_step, exchange);
         Body::store(a, tid, r);
