@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--plan", default=None, help="experiment: force a plan, e.g. 6,8,6@12p8 (default: the library's own)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for dry runs)")
     ap.add_argument("--same-gpu", action="store_true", help="dry run: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--sharded", action="store_true",
+                    help="run the N > 1 code path (process group, sharded batch, digest gather) even with WORLD_SIZE=1: on "
+                         "a one-GPU box this is what puts RCCL init and the device collectives on real hardware")
     return ap.parse_args()
 
 
@@ -375,8 +378,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    multi = world > 1
+    multi = world > 1 or args.sharded
     if multi:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         import torch.distributed as dist
 
         if args.same_gpu:
@@ -406,7 +413,7 @@ def main():
     plan_text = planner.describe()
     check_info = None
 
-    if n_gpus == 1:
+    if not multi:
         steps = args.steps if args.steps is not None else 200
         warmup = args.warmup if args.warmup is not None else 20
         ring = max(steps + warmup, 40)  # >= 640 MiB of distinct transforms; no buffer is transformed twice
@@ -530,7 +537,7 @@ def main():
         roofline, dom = roofline_of(pass_ms, alg_bytes, plan_used=f"{used} plan {plan_list}")
         achieved = roofline["achieved"]
         out = {
-            "metric": "GSamples/s f64 forward FFT N=2^20" + (" (N=2^26, round trip, R2C: see configs)" if n_gpus == 1 else ""),
+            "metric": "GSamples/s f64 forward FFT N=2^20" + (" (N=2^26, round trip, R2C: see configs)" if not multi else ""),
             "value": value, "unit": "GSamples/s",
             "n_gpus": n_gpus, "steps": steps, "warmup": warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
@@ -539,32 +546,32 @@ def main():
                        "plan": plan_text, "plan_used": used, "launch": launch},
             "roofline": roofline,
         }
-        if n_gpus > 1:
+        if multi:
             out["config"]["digest_gather"] = f"all_gather of {samples_per_step // N} x 32 B digests over RCCL"
             out["config"]["digest_ok"] = digest_ok
             out["config"]["digest_check"] = dict(check_info, what="every rank: Parseval on all transforms of its shard + "
                                                  "sampled transforms vs digests of the CPU oracle's output; rank 0's numbers")
-        traffic = load_profiled_traffic(n_gpus, dom, len(pass_ms), kernel_tags(plan_list))
+        traffic = load_profiled_traffic(2 if multi else 1, dom, len(pass_ms), kernel_tags(plan_list))
         if traffic is not None:
-            if n_gpus > 1:  # profiled per 256-transform launch; kernel_ms / algorithmic bytes here are per pass over the shard
+            if multi:  # profiled per 256-transform launch; kernel_ms / algorithmic bytes here are per pass over the shard
                 traffic["traffic"] *= units / 256.0
                 traffic["traffic_note"] = "PMC bytes of one 256-transform launch scaled to the shard"
             roofline.update(traffic)
-        if n_gpus == 1:
+        if not multi:
             probe = hbm_copy_probe(torch, dev)
             roofline["copy_probe_GBps"] = probe          # measured d2d copy rate of this box, same run
             roofline["frac_of_copy_probe"] = achieved / probe
             torch.cuda.empty_cache()
-        cpu = n_gpus == 1 and not args.no_cpu_baseline
+        cpu = not multi and not args.no_cpu_baseline
         if cpu:
             out["cpu_baseline"] = cpu_baseline()
-        if n_gpus == 1 and not args.no_configs:
+        if not multi and not args.no_configs:
             fwd, rt = config_n2p26(P, torch, dev, 5, cpu)
             out["configs"] = {"n2p26_forward": fwd, "n2p26_roundtrip": rt, "r2c_f32_2p24": config_r2c(P, torch, dev, 20, cpu)}
             t26 = load_profiled_traffic_key("single_2p26", fwd["roofline"])
             if t26:
                 fwd["roofline"].update(t26)
-        if n_gpus == 1 and not args.no_scaling_reference:
+        if not multi and not args.no_scaling_reference:
             out["weak_scaling_reference"] = shard_on_one_gpu(P, torch, dev, args.shard)
         print(json.dumps(out), flush=True)
     if multi:

@@ -20,6 +20,16 @@
  * buffer, so an internal lock makes every call's launch sequence atomic -- the blocking host-slice calls hold it
  * for the whole call, the _dev calls while they enqueue.  _dev calls on one planner must therefore be issued on
  * ONE stream (or be ordered by the caller across streams); use one planner per stream for concurrent streams.
+ *
+ * Devices: a planner belongs to the HIP device that is current when it is created (its tables and scratch live
+ * there).  One process may hold planners on several devices (one host thread per GPU, or one thread switching):
+ * every call on a planner runs on the planner's device whatever the calling thread's current device is, and the
+ * caller's current device is restored before the call returns.  Data pointers and the stream of a _dev call must
+ * belong to (or be accessible from) the planner's device.
+ *
+ * Memory: scratch and staging buffers grow on demand (geometrically); an outgrown buffer is released as soon as the
+ * work that used it has completed, never under stream capture.  When the device is out of memory a batched call
+ * falls back to smaller chunks before it reports PHAST_ERR_HIP.
  */
 #ifndef PHASTFT_HIP_H
 #define PHASTFT_HIP_H

@@ -16,6 +16,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libphastft_oracle.so")
+_FAST_SO = os.path.join(_HERE, "libphastft_oracle_fast.so")
 
 FORWARD = 1
 REVERSE = -1
@@ -135,13 +136,29 @@ class PlannerR2c32(PlannerR2c64):
 
 
 # ---- C2C (lib.rs:143-226) ----
-def _fft(name, dtype, reals, imags, direction, planner=None):
+_flib = None
+
+
+def fast_lib() -> C.CDLL:
+    """The prebuilt -O3 build of the same source (Makefile: `fast`; bit-identical to the checker build,
+    tests/test_oracle_pin.py) -- for the parity tests at N >= 2^23, where the -O2 checker takes several seconds per
+    transform.  Planner handles are plain heap structs of the same source: one made by lib() serves here too."""
+    global _flib
+    if _flib is None:
+        build()
+        _flib = C.CDLL(_FAST_SO)
+        _flib.pho_strerror.restype = C.c_char_p
+    return _flib
+
+
+def _fft(name, dtype, reals, imags, direction, planner=None, fast=False):
     _req(reals, dtype), _req(imags, dtype)
+    l = fast_lib() if fast else lib()
     if planner is None:
-        _check(getattr(lib(), name)(_p(reals), _sz(reals.size), _p(imags), _sz(imags.size), C.c_int(direction)))
+        _check(getattr(l, name)(_p(reals), _sz(reals.size), _p(imags), _sz(imags.size), C.c_int(direction)))
     else:
-        _check(getattr(lib(), name + "_with_planner")(_p(reals), _sz(reals.size), _p(imags), _sz(imags.size),
-                                                      C.c_int(direction), planner._h))
+        _check(getattr(l, name + "_with_planner")(_p(reals), _sz(reals.size), _p(imags), _sz(imags.size),
+                                                  C.c_int(direction), planner._h))
 
 
 def fft_64_dit(reals, imags, direction=FORWARD):
@@ -165,12 +182,12 @@ def fft_32_dit_with_planner_parallel(reals, imags, direction, planner: PlannerDi
                                                       C.c_int(direction), planner._h))
 
 
-def fft_64_dit_with_planner(reals, imags, direction, planner: PlannerDit64):
-    _fft("pho_fft_64_dit", np.float64, reals, imags, direction, planner)
+def fft_64_dit_with_planner(reals, imags, direction, planner: PlannerDit64, fast: bool = False):
+    _fft("pho_fft_64_dit", np.float64, reals, imags, direction, planner, fast)
 
 
-def fft_32_dit_with_planner(reals, imags, direction, planner: PlannerDit32):
-    _fft("pho_fft_32_dit", np.float32, reals, imags, direction, planner)
+def fft_32_dit_with_planner(reals, imags, direction, planner: PlannerDit32, fast: bool = False):
+    _fft("pho_fft_32_dit", np.float32, reals, imags, direction, planner, fast)
 
 
 # ---- bit reversal (bravo.rs) ----
@@ -275,7 +292,6 @@ def fill(n: int, dtype, seed: int = 0xCAFE, transform_id: int = 0):
 # The timing legs run in the TIMING build of the same source (-O3, vectorised butterfly loops; Makefile: `fast`, or
 # `native` = -march=native compiled on the box that runs the benchmark).  tests/test_oracle_pin.py checks that it
 # returns bit-identical results to the checker build above.
-_FAST_SO = os.path.join(_HERE, "libphastft_oracle_fast.so")
 _NATIVE_SO = os.path.join(_HERE, "_native", "libphastft_oracle_native.so")
 _tlib = None
 _tkind = ""

@@ -65,6 +65,9 @@ class PlannerMode(enum.IntEnum):
     Tune = 1
 
 
+ERR_INVALID_ARG = 16  # PHAST_ERR_INVALID_ARG (include/phastft_hip.h): e.g. a shape the strided kernels do not cover
+
+
 class PhastPanic(AssertionError):
     """A reference ``assert!`` / ``assert_eq!`` would have fired; ``str(e)`` is the reference's message."""
 

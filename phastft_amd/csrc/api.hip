@@ -37,39 +37,67 @@ static int hip_fail(hipError_t e, const char *what) {
         if (e_ != hipSuccess) return hip_fail(e_, #call);   \
     } while (0)
 
-static int g_cus = 0;
-static int g_device = -1;  // the library keeps per-device state (CU count, raised dynamic-LDS limits): one device per process
-static int g_wg_per_cu_override = 0;
-static unsigned long long *g_trace = nullptr;  // tuning hook (phast_debug_set_trace)  // tuning hook (phast_debug_set_wg_per_cu)
-static int ensure_device() {
+static PerDeviceInt g_cus_of;  // CU count per device ordinal (device_state.hpp)
+static int g_wg_per_cu_override = 0;           // tuning hook (phast_debug_set_wg_per_cu)
+static unsigned long long *g_trace = nullptr;  // tuning hook (phast_debug_set_trace)
+
+static int cus_of(int dev) {
+    return g_cus_of.get(dev, [&] {
+        hipDeviceProp_t prop;
+        int c = 0;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) c = prop.multiProcessorCount;
+        return c > 0 ? c : 256;
+    });
+}
+
+// Is there a device at all, and which one is current?  The library holds no process-wide device: a planner belongs to
+// the device that is current when it is created (its tables and scratch live there), several planners on several
+// devices may coexist in one process (planner.rs:38-39: a planner is a plain value usable from any thread), and every
+// call on a planner runs on the planner's device whatever the calling thread's current device is (DeviceGuard).
+static int ensure_device(int *dev_out = nullptr) {
     static std::once_flag once;
     static int status = PHAST_OK;
+    static char why[160] = "";
     std::call_once(once, [] {
         int count = 0;
         hipError_t e = hipGetDeviceCount(&count);
         if (e != hipSuccess || count == 0) {
-            std::snprintf(g_hip_err, sizeof g_hip_err, "hipGetDeviceCount: %s", hipGetErrorString(e));
+            std::snprintf(why, sizeof why, "hipGetDeviceCount: %s", hipGetErrorString(e));
             status = PHAST_ERR_NO_DEVICE;
-            return;
         }
-        int dev = 0;
-        hipGetDevice(&dev);
-        g_device = dev;
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) g_cus = prop.multiProcessorCount;
-        if (g_cus <= 0) g_cus = 256;
     });
-    if (status == PHAST_OK) {  // one process drives one device (one rank per GPU): refuse to plan on another one
-        int dev = -1;
-        if (hipGetDevice(&dev) == hipSuccess && dev != g_device) {
-            std::snprintf(g_hip_err, sizeof g_hip_err,
-                          "libphastft_hip was initialised on device %d and is now asked to plan on device %d: one "
-                          "device per process", g_device, dev);
-            return PHAST_ERR_INVALID_ARG;
+    if (status != PHAST_OK) {
+        std::snprintf(g_hip_err, sizeof g_hip_err, "%s", why);
+        return status;
+    }
+    int dev = 0;
+    PHAST_HIP(hipGetDevice(&dev));
+    if (dev_out) *dev_out = dev;
+    return PHAST_OK;
+}
+
+// Run a call on the device `want` owns its memory on; the caller's current device is restored on exit.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int want) {
+        if (want < 0) return;
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != want) {
+            err = hipSetDevice(want);
+            switched = err == hipSuccess;
         }
     }
-    return status;
-}
+    ~DeviceGuard() {
+        if (switched) hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+#define PHAST_ON_DEVICE(dev)                                              \
+    DeviceGuard device_guard_(dev);                                       \
+    if (device_guard_.err != hipSuccess) return hip_fail(device_guard_.err, "hipSetDevice(planner's device)")
 
 static inline bool is_pow2(size_t n) { return n != 0 && (n & (n - 1)) == 0; }
 static inline unsigned ilog2(size_t n) { return 63u - (unsigned)__builtin_clzll((unsigned long long)n); }
@@ -182,10 +210,65 @@ template <typename T> struct Planner {
     mutable void *h_pin = nullptr;    // pinned host mirror of the staging buffer for SMALL host-slice calls
     mutable size_t pin_bytes = 0;
     mutable size_t table_bytes = 0;
-    // A buffer that has to grow is replaced, never freed inside a call: kernels already enqueued may still use the
-    // old one, and a hipDeviceSynchronize + hipFree in the middle of a launch sequence is a hidden device-wide sync
-    // (and illegal under stream capture).  The predecessors are released with the planner.
-    mutable std::vector<void *> retired_dev, retired_pin;
+    int device = -1;  // the device this planner's tables and scratch live on (current at creation); calls run there
+    // A buffer that has to grow is replaced, never freed inside the call that outgrew it: kernels already enqueued may
+    // still use the old one.  The predecessor is RETIRED with an event recorded behind the last work enqueued through
+    // this planner; a later call frees it once that event has completed (reap(): never under stream capture, where a
+    // hipFree is illegal).  Scratch grows geometrically, so what is retained at any time stays below the live size.
+    struct Retired {
+        void *p;
+        size_t bytes;
+        hipEvent_t done;  // nullptr: retired under stream capture -- released with the planner
+        bool pinned;
+    };
+    mutable std::vector<Retired> retired;
+    mutable size_t retired_dev_bytes = 0;
+    mutable hipStream_t last_stream = nullptr;  // the stream the previous call enqueued on (call_mu held)
+
+    static bool capturing(hipStream_t s) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &st) != hipSuccess) {
+            (void)hipGetLastError();
+            return true;  // cannot tell: behave as if it were
+        }
+        return st != hipStreamCaptureStatusNone;
+    }
+    void retire(void *p, size_t bytes, bool pinned) const {
+        if (!p) return;
+        Retired r{p, bytes, nullptr, pinned};
+        if (!capturing(last_stream)) {
+            hipEvent_t ev = nullptr;
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
+                if (hipEventRecord(ev, last_stream) == hipSuccess) r.done = ev;
+                else hipEventDestroy(ev);
+            }
+            (void)hipGetLastError();
+        }
+        if (!pinned) retired_dev_bytes += bytes;
+        retired.push_back(r);
+    }
+    // free what is provably idle; `wait`: block for it (out-of-memory recovery).  Not under capture of `stream`.
+    void reap(hipStream_t stream, bool wait = false) const {
+        if (retired.empty() || capturing(stream)) return;
+        size_t keep = 0;
+        for (size_t i = 0; i < retired.size(); ++i) {
+            Retired &r = retired[i];
+            bool idle = false;
+            if (r.done) idle = (wait ? hipEventSynchronize(r.done) : hipEventQuery(r.done)) == hipSuccess;
+            if (idle) {
+                if (r.pinned) hipHostFree(r.p);
+                else {
+                    hipFree(r.p);
+                    retired_dev_bytes -= r.bytes;
+                }
+                hipEventDestroy(r.done);
+            } else {
+                retired[keep++] = r;
+            }
+        }
+        retired.resize(keep);
+        (void)hipGetLastError();  // hipEventQuery's hipErrorNotReady is not an error of the call being made
+    }
     // plans of strided batches (column FFTs), built on first use per (log2 stride, log2 batch): see make_strided_passes
     struct StridedPlan {
         unsigned s = 0, sb = 0, grid_log_n = 0;
@@ -206,11 +289,9 @@ template <typename T> struct Planner {
     }
     int pinned(size_t bytes, void **out) const {
         if (pin_bytes < bytes) {
-            if (h_pin) {
-                retired_pin.push_back(h_pin);
-                h_pin = nullptr;
-                pin_bytes = 0;
-            }
+            retire(h_pin, pin_bytes, true);
+            h_pin = nullptr;
+            pin_bytes = 0;
             PHAST_HIP(hipHostMalloc(&h_pin, bytes ? bytes : 1, hipHostMallocDefault));
             pin_bytes = bytes;
         }
@@ -220,11 +301,9 @@ template <typename T> struct Planner {
     // device staging buffer of at least `bytes` (call with call_mu held)
     int stage(size_t bytes, void **out) const {
         if (stage_bytes < bytes) {
-            if (d_stage) {
-                retired_dev.push_back(d_stage);
-                d_stage = nullptr;
-                stage_bytes = 0;
-            }
+            retire(d_stage, stage_bytes, false);
+            d_stage = nullptr;
+            stage_bytes = 0;
             PHAST_HIP(hipMalloc(&d_stage, bytes ? bytes : 1));
             stage_bytes = bytes;
         }
@@ -240,8 +319,8 @@ template <typename T> struct Planner {
     }
     void retire_passes(std::vector<PassDesc> &v) {
         for (auto &p : v) {
-            if (p.d_tw3) retired_dev.push_back(p.d_tw3);
-            if (p.d_twr) retired_dev.push_back(p.d_twr);
+            retire(p.d_tw3, p.pre_tw ? ((size_t)3 << p.tw_bits) * sizeof(cx_t<T>) : 0, false);
+            retire(p.d_twr, 64 * sizeof(cx_t<T>), false);
         }
         v.clear();
     }
@@ -254,15 +333,19 @@ template <typename T> struct Planner {
         free_passes(passes_one);
     }
     void release() {
+        DeviceGuard on(device);
         release_passes();
         if (d_small_tw) hipFree(d_small_tw);
         if (d_scratch) hipFree(d_scratch);
         if (d_stage) hipFree(d_stage);
         if (h_pin) hipHostFree(h_pin);
-        for (void *q : retired_dev) hipFree(q);
-        for (void *q : retired_pin) hipHostFree(q);
-        retired_dev.clear();
-        retired_pin.clear();
+        for (const Retired &r : retired) {  // hipFree waits for the device: whatever still used them is done afterwards
+            if (r.pinned) hipHostFree(r.p);
+            else hipFree(r.p);
+            if (r.done) hipEventDestroy(r.done);
+        }
+        retired.clear();
+        retired_dev_bytes = 0;
         h_pin = nullptr;
         pin_bytes = 0;
         d_small_tw = nullptr;
@@ -291,6 +374,7 @@ template <typename T> struct Planner {
     int set_plan(const std::vector<unsigned> &lrs, const std::vector<unsigned> &tls, int which = 0, unsigned lp = 4) {
         std::vector<PassGeom> geo;
         if (!make_passes(log_n, lrs, tls, geo, lp, sizeof(T))) return PHAST_ERR_INVALID_ARG;
+        PHAST_ON_DEVICE(device);
         std::vector<PassDesc> ps(geo.size());
         for (size_t i = 0; i < geo.size(); ++i) static_cast<PassGeom &>(ps[i]) = geo[i];
         size_t tb = 0;
@@ -327,7 +411,7 @@ template <typename T> struct Planner {
     int init(size_t num_points) {
         n = num_points;
         log_n = ilog2(n);
-        int rc = ensure_device();
+        int rc = ensure_device(&device);
         if (rc) return rc;
         if (log_n <= kSmallMaxLog) {
             std::vector<cx_t<T>> h = host_twr<T>((unsigned)n);  // W_N^j two-level table of the one-pass kernel
@@ -366,27 +450,46 @@ template <typename T> struct Planner {
         return PHAST_OK;
     }
 
-    // scratch for `want` transforms in flight (capped by the target footprint, at least 1)
-    int ensure_scratch(size_t batch, size_t *cap_out, bool exact = false) const {
+    // scratch for `want` transforms in flight (capped by the target footprint, at least 1).  Grows geometrically: a
+    // sequence of slowly growing batches retires O(log) buffers whose sizes sum to less than the live one (and reap()
+    // frees them as soon as the work that used them is done).  Out of device memory: idle retired buffers are
+    // released, then the request is halved (exec() loops over chunks) down to the reserved batch.
+    int ensure_scratch(size_t batch, size_t *cap_out, bool exact = false, hipStream_t stream = nullptr) const {
         if (passes.empty() && !exact) {  // whole transforms on chip: no scratch (strided batches of such sizes need one)
             *cap_out = batch;
             return PHAST_OK;
         }
         std::lock_guard<std::mutex> lk(mu);
+        reap(stream);
         const size_t per = 2 * n * sizeof(T);
-        size_t want = scratch_target_bytes() / per;
-        if (want < 1) want = 1;
-        if (want < reserve) want = reserve;
+        size_t target = scratch_target_bytes() / per;
+        if (target < 1) target = 1;
+        if (target < reserve) target = reserve;
+        size_t want = target;
         if (want > batch && batch >= reserve) want = batch;
         if (exact && want < batch) want = batch;  // work that cannot be cut into chunks (strided batches)
         if (scratch_cap < want) {
-            if (d_scratch) {
-                retired_dev.push_back(d_scratch);
-                d_scratch = nullptr;
-                scratch_cap = 0;
-            }
+            if (!exact && scratch_cap && want < 2 * scratch_cap) want = std::min(2 * scratch_cap, std::max(target, want));
+            const size_t floor_cap = exact ? want : std::max<size_t>(std::max<size_t>(reserve, 1), scratch_cap + 1);
             void *d = nullptr;
-            PHAST_HIP(hipMalloc(&d, want * per));
+            hipError_t e = hipMalloc(&d, want * per);
+            if (e == hipErrorOutOfMemory && !capturing(stream)) {
+                (void)hipGetLastError();
+                reap(stream, true);  // whatever retired buffers are idle (or become so) go first
+                e = hipMalloc(&d, want * per);
+                while (e == hipErrorOutOfMemory && want > floor_cap) {
+                    (void)hipGetLastError();
+                    want = std::max(floor_cap, want / 2);
+                    e = hipMalloc(&d, want * per);
+                }
+                if (e == hipErrorOutOfMemory && !exact && scratch_cap >= std::max<size_t>(reserve, 1)) {
+                    (void)hipGetLastError();  // cannot grow: keep working in the chunks the present scratch allows
+                    *cap_out = scratch_cap;
+                    return PHAST_OK;
+                }
+            }
+            if (e != hipSuccess) return hip_fail(e, "hipMalloc(scratch)");
+            retire(d_scratch, scratch_cap * per, false);
             d_scratch = reinterpret_cast<T *>(d);
             scratch_cap = want;
         }
@@ -394,7 +497,8 @@ template <typename T> struct Planner {
         return PHAST_OK;
     }
 
-    size_t device_bytes() const { return table_bytes + scratch_cap * 2 * n * sizeof(T); }
+    // live tables and scratch plus what is retired but not yet released
+    size_t device_bytes() const { return table_bytes + scratch_cap * 2 * n * sizeof(T) + stage_bytes + retired_dev_bytes; }
 
     // tables + launch parameters of a pass list (shared by set_plan and the strided plans)
     int prepare_passes(std::vector<PassDesc> &ps, size_t *table_bytes_out) const {
@@ -432,7 +536,7 @@ template <typename T> struct Planner {
     }
 
     hipError_t launch_pass(const PassDesc &p, const TileArgs &ta, hipStream_t stream, hipEvent_t e0, hipEvent_t e1) const {
-        unsigned grid = (unsigned)(g_wg_per_cu_override > 0 ? g_wg_per_cu_override : p.blocks_per_cu) * (unsigned)g_cus;
+        unsigned grid = (unsigned)(g_wg_per_cu_override > 0 ? g_wg_per_cu_override : p.blocks_per_cu) * (unsigned)cus_of(device);
         if (grid > ta.tiles_total) grid = ta.tiles_total;
         if (grid >= 8) grid &= ~7u;  // keep tile%8 == workgroup%8 (XCD affinity of the tile order)
         return p.wave      ? launch_wave<T>(p.transpose, stream, ta, false, nullptr, nullptr, e0, e1)
@@ -446,6 +550,7 @@ template <typename T> struct Planner {
     int exec_strided(T *re, T *im, unsigned s_bits, unsigned sb_bits, double scale, hipStream_t stream,
                      unsigned grid_log_n = 0, unsigned grid_col0 = 0) const {
         std::lock_guard<std::recursive_mutex> call_lock(call_mu);
+        PHAST_ON_DEVICE(device);
         const StridedPlan *plan = nullptr;
         for (const auto &sp : strided_plans)
             if (sp.s == s_bits && sp.sb == sb_bits && sp.grid_log_n == grid_log_n) plan = &sp;
@@ -466,8 +571,9 @@ template <typename T> struct Planner {
         // the whole [2^log_n][2^s] array is one unit of work: scratch for all of it (2^s "transforms" of n points)
         const size_t cols = (size_t)1 << s_bits;
         size_t cap = 0;
-        int rc = ensure_scratch(cols, &cap, true);
+        int rc = ensure_scratch(cols, &cap, true, stream);
         if (rc) return rc;
+        last_stream = stream;
         T *s_re = d_scratch, *s_im = d_scratch + cap * n;
         const size_t np = plan->passes.size();
         for (size_t i = 0; i < np; ++i) {
@@ -521,6 +627,8 @@ template <typename T> struct Planner {
                         hipStream_t stream) const {
         if (batch == 0) return PHAST_OK;
         std::lock_guard<std::recursive_mutex> call_lock(call_mu);
+        PHAST_ON_DEVICE(device);
+        last_stream = stream;
         const size_t chunk = (size_t)1 << 30;
         const size_t in_el = mode == 1 ? 2 * sizeof(T) : sizeof(T), out_el = mode == 1 ? sizeof(T) : 2 * sizeof(T);
         for (size_t b0 = 0; b0 < batch; b0 += chunk) {
@@ -553,7 +661,9 @@ template <typename T> struct Planner {
              PassTimer *timer = nullptr) const {
         if (batch == 0) return PHAST_OK;
         std::lock_guard<std::recursive_mutex> call_lock(call_mu);
+        PHAST_ON_DEVICE(device);
         if (passes.empty()) {
+            last_stream = stream;
             const size_t chunk = (size_t)1 << 30;  // transforms per launch: the tile count stays below 2^32
             for (size_t b0 = 0; b0 < batch; b0 += chunk) {
                 SmallArgs sa{};
@@ -578,8 +688,9 @@ template <typename T> struct Planner {
             return PHAST_OK;
         }
         size_t cap = 0;
-        int rc = ensure_scratch(batch, &cap);
+        int rc = ensure_scratch(batch, &cap, false, stream);
         if (rc) return rc;
+        last_stream = stream;
         T *s_re = d_scratch;               // plane layout: all re planes, then all im planes
         T *s_im = d_scratch + cap * n;
         const std::vector<PassDesc> &passes = plan_for(batch);
@@ -640,11 +751,10 @@ template <typename T> struct PlannerR2c {
     mutable T *d_z = nullptr;  // C2R workspace [cap][2][n/2]
     mutable size_t z_cap = 0;
     mutable std::mutex mu;
-    mutable std::vector<void *> retired;  // outgrown workspaces, released with the planner (see Planner::retired_dev)
     ~PlannerR2c() {
+        DeviceGuard on(dit.device);
         if (d_tw3) hipFree(d_tw3);
         if (d_z) hipFree(d_z);
-        for (void *q : retired) hipFree(q);
     }
     int init(size_t n_) {
         n = n_;
@@ -653,20 +763,31 @@ template <typename T> struct PlannerR2c {
         tw_bits = tw3_bits_for(ilog2(n));
         return upload<T>(host_tw3<T>(ilog2(n), tw_bits), &d_tw3);
     }
-    int ensure_z(size_t batch, size_t *cap_out) const {
+    // C2R workspace for `batch` transforms (call with dit.call_mu held); outgrown ones are retired through the inner
+    // planner (freed once idle, Planner::reap), growth is geometric
+    int ensure_z(size_t batch, size_t *cap_out, hipStream_t stream) const {
         std::lock_guard<std::mutex> lk(mu);
         const size_t per = n * sizeof(T);  // 2 planes of n/2
-        size_t want = scratch_target_bytes() / per;
-        if (want < 1) want = 1;
-        if (want > batch) want = batch;
+        size_t target = scratch_target_bytes() / per;
+        if (target < 1) target = 1;
+        size_t want = target < batch ? target : batch;
         if (z_cap < want) {
-            if (d_z) {
-                retired.push_back(d_z);
-                d_z = nullptr;
-                z_cap = 0;
-            }
+            if (z_cap && want < 2 * z_cap) want = std::min(2 * z_cap, target);
             void *d = nullptr;
-            PHAST_HIP(hipMalloc(&d, want * per));
+            hipError_t e = hipMalloc(&d, want * per);
+            while (e == hipErrorOutOfMemory && want > z_cap + 1 && !Planner<T>::capturing(stream)) {
+                (void)hipGetLastError();
+                dit.reap(stream, true);
+                want = std::max(z_cap + 1, want / 2);
+                e = hipMalloc(&d, want * per);
+            }
+            if (e == hipErrorOutOfMemory && z_cap) {
+                (void)hipGetLastError();
+                *cap_out = z_cap;
+                return PHAST_OK;
+            }
+            if (e != hipSuccess) return hip_fail(e, "hipMalloc(c2r workspace)");
+            dit.retire(d_z, z_cap * per, false);
             d_z = reinterpret_cast<T *>(d);
             z_cap = want;
         }
@@ -680,6 +801,7 @@ template <typename T> struct PlannerR2c {
         const size_t half = n / 2;
         if (in_dist & 1) return PHAST_ERR_INVALID_ARG;  // the input is read as (even, odd) pairs
         std::lock_guard<std::recursive_mutex> call_lock(dit.call_mu);
+        PHAST_ON_DEVICE(dit.device);
         if (dit.passes.empty())  // N/2 <= 8192: one kernel, the untangle is its epilogue
             return dit.exec_small_real(1, d_in, nullptr, in_dist / 2, d_ore, d_oim, out_dist, batch, 1.0, d_tw3, tw_bits, s);
         int rc = dit.exec(d_in, nullptr, in_dist / 2, 1, d_ore, d_oim, out_dist, 0, batch, 1.0, s, timer);
@@ -707,11 +829,12 @@ template <typename T> struct PlannerR2c {
         const size_t half = n / 2;
         if (out_dist & 1) return PHAST_ERR_INVALID_ARG;
         std::lock_guard<std::recursive_mutex> call_lock(dit.call_mu);
+        PHAST_ON_DEVICE(dit.device);
         if (dit.passes.empty())  // N/2 <= 8192: one kernel, the preprocess is its prologue
             return dit.exec_small_real(2, d_ire, d_iim, in_dist, d_out, nullptr, out_dist / 2, batch, 1.0 / (double)half,
                                        d_tw3, tw_bits, s);
         size_t cap = 0;
-        int rc = ensure_z(batch, &cap);
+        int rc = ensure_z(batch, &cap, s);
         if (rc) return rc;
         for (size_t b0 = 0; b0 < batch; b0 += cap) {
             const size_t nb = batch - b0 < cap ? batch - b0 : cap;
@@ -812,6 +935,7 @@ static int time_passes(const Planner<T> *pl, T *d_re, T *d_im, size_t batch, siz
                        int *n_passes, hipStream_t s) {
     if (!pl || !d_re || !d_im || !pass_ms || !n_passes || reps < 1) return PHAST_ERR_INVALID_ARG;
     const int np = pl->passes.empty() ? 1 : (int)pl->plan_for(batch).size();
+    PHAST_ON_DEVICE(pl->device);
     double acc[3] = {0, 0, 0};
     for (int r = 0; r < reps; ++r) {
         PassTimer tm;
@@ -836,6 +960,7 @@ static int time_passes_r2c(const PlannerR2c<T> *pl, const T *d_in, T *d_ore, T *
                            size_t out_dist, int reps, float *pass_ms, int *n_passes, hipStream_t s) {
     if (!pl || !d_in || !d_ore || !d_oim || !pass_ms || !n_passes || reps < 1) return PHAST_ERR_INVALID_ARG;
     const int np = pl->dit.passes.empty() ? 1 : (int)pl->dit.plan_for(batch).size() + 1;
+    PHAST_ON_DEVICE(pl->dit.device);
     double acc[4] = {0, 0, 0, 0};
     for (int r = 0; r < reps; ++r) {
         PassTimer tm;
@@ -937,6 +1062,8 @@ static int fft_host(T *re, size_t re_len, T *im, size_t im_len, int direction, c
     if (ilog2(re_len) != pl->log_n) return PHAST_ERR_PLANNER_SIZE;  // dit.rs:289
     const size_t n = re_len, bytes = n * sizeof(T), total = 2 * bytes;
     std::lock_guard<std::recursive_mutex> call_lock(pl->call_mu);
+    PHAST_ON_DEVICE(pl->device);
+    pl->reap(nullptr);
     void *stage = nullptr;
     int rc = pl->stage(total, &stage);
     if (rc) return rc;
@@ -954,6 +1081,8 @@ template <typename T> static int fft_interleaved_host(T *signal, size_t n, int d
     if (!is_pow2(n)) return PHAST_ERR_NOT_POW2;
     if (ilog2(n) != pl->log_n) return PHAST_ERR_PLANNER_SIZE;
     std::lock_guard<std::recursive_mutex> call_lock(pl->call_mu);
+    PHAST_ON_DEVICE(pl->device);
+    pl->reap(nullptr);
     const size_t total = 2 * n * sizeof(T);
     void *stage = nullptr;
     int rc = pl->stage(total, &stage);
@@ -985,6 +1114,8 @@ static int r2c_host(const T *in, size_t in_len, T *ore, size_t ore_len, T *oim, 
     if (ore_len != half + 1) return PHAST_ERR_R2C_OUT_RE_LEN;
     if (oim_len != half + 1) return PHAST_ERR_R2C_OUT_IM_LEN;
     std::lock_guard<std::recursive_mutex> call_lock(pl->dit.call_mu);
+    PHAST_ON_DEVICE(pl->dit.device);
+    pl->dit.reap(nullptr);
     const size_t ob = (half + 1) * sizeof(T), total = n * sizeof(T) + 2 * ob;
     void *stage = nullptr;
     int rc = pl->dit.stage(total, &stage);
@@ -1010,6 +1141,8 @@ static int c2r_host(const T *ire, size_t ire_len, const T *iim, size_t iim_len, 
     if (check_scratch && sre_len != half) return PHAST_ERR_C2R_SCRATCH_RE;
     if (check_scratch && sim_len != half) return PHAST_ERR_C2R_SCRATCH_IM;
     std::lock_guard<std::recursive_mutex> call_lock(pl->dit.call_mu);
+    PHAST_ON_DEVICE(pl->dit.device);
+    pl->dit.reap(nullptr);
     const size_t ib = (half + 1) * sizeof(T), total = n * sizeof(T) + 2 * ib;
     void *stage = nullptr;
     int rc = pl->dit.stage(total, &stage);
@@ -1079,12 +1212,14 @@ struct phast_planner_r2c32 : PlannerR2c<float> {};
 // W_N^(r*c) tables of a four-step split (twiddle.hip)
 template <typename T> struct TwiddleGrid {
     unsigned log_n = 0, tw_bits = 1;
+    int device = -1;
     void *d_tw3 = nullptr;
     ~TwiddleGrid() {
+        DeviceGuard on(device);
         if (d_tw3) hipFree(d_tw3);
     }
     int init(size_t n) {
-        int rc = ensure_device();
+        int rc = ensure_device(&device);
         if (rc) return rc;
         log_n = ilog2(n);
         if (log_n > 32) return PHAST_ERR_INVALID_ARG;  // exponents are reduced to 32 bits
@@ -1095,6 +1230,7 @@ template <typename T> struct TwiddleGrid {
     int apply(T *d_re, T *d_im, size_t rows, size_t cols, size_t row_pitch, size_t row0, size_t col0, hipStream_t s) const {
         if ((!d_re || !d_im) && rows * cols) return PHAST_ERR_INVALID_ARG;
         if (row_pitch < cols) return PHAST_ERR_INVALID_ARG;
+        PHAST_ON_DEVICE(device);
         TwiddleGridArgs a{};
         a.re = d_re;
         a.im = d_im;
@@ -1190,6 +1326,7 @@ int phast_options_guess(size_t input_size, phast_options *out) {
     int phast_planner_dit##SFX##_reserve_batch(phast_planner_dit##SFX *p, size_t max_batch) {                      \
         if (!p || max_batch == 0) return PHAST_ERR_INVALID_ARG;                                                    \
         std::lock_guard<std::recursive_mutex> call_lock(p->call_mu);                                               \
+        PHAST_ON_DEVICE(p->device);                                                                                \
         p->reserve = max_batch;                                                                                    \
         size_t cap;                                                                                                \
         return p->ensure_scratch(max_batch, &cap);                                                                 \

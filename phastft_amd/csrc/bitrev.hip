@@ -316,12 +316,8 @@ static hipError_t launch_bitrev_persistent3(U *data, unsigned log_n, size_t batc
     if (grid > total) grid = total;
     const size_t lds = sizeof(U) * B * (B + 1);
     auto kern = bitrev_persistent3_kernel<U, BETA, NTH>;
-    static bool raised = false;
-    if (!raised) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        raised = true;
-    }
+    static PerDeviceLimit lds_limit;
+    if (hipError_t e = raise_lds_limit(lds_limit, reinterpret_cast<const void *>(kern), lds); e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(NTH), lds, stream, data, log_n, dist, tiles, total);
     return hipGetLastError();
 }

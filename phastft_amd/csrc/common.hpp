@@ -7,6 +7,8 @@
 #include <cstdint>
 #include <type_traits>
 
+#include "device_state.hpp"
+
 #define PHAST_HD __host__ __device__ __forceinline__
 
 
@@ -179,5 +181,22 @@ __device__ __forceinline__ void pin_scalars(unsigned x, unsigned y) { asm volati
 PHAST_HD inline void pin_tile_args(const TileArgs &) {}
 PHAST_HD inline void pin_scalars(unsigned, unsigned) {}
 #endif
+
+// host: make sure `kern` may be launched with `lds` bytes of dynamic LDS ON THE CURRENT DEVICE.  The limit is an
+// attribute of the function per device; `cache` (one per kernel instantiation) remembers what was raised where, so the
+// steady state issues no runtime call besides the launch itself (a launch sequence can be captured into a HIP graph), and
+// the first launches of two host threads do not race (device_state.hpp).
+inline hipError_t raise_lds_limit(PerDeviceLimit &cache, const void *kern, size_t lds) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    hipError_t err = hipSuccess;
+    const int rc = cache.ensure(dev, lds, [&](size_t want) {
+        err = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want);
+        return err == hipSuccess ? 0 : 1;
+    });
+    if (rc < 0) return hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  // ordinal beyond the cache
+    return err;
+}
 
 }  // namespace phast

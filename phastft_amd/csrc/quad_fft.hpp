@@ -275,12 +275,8 @@ hipError_t launch_quad_inst(unsigned grid, hipStream_t stream, const TileArgs &a
         if (query_only && blocks_per_cu) *blocks_per_cu = 0;
         return query_only ? hipSuccess : hipErrorInvalidValue;
     }
-    static size_t lds_limit = 0;
-    if (lds > lds_limit) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        lds_limit = lds;
-    }
+    static PerDeviceLimit lds_limit;
+    if (hipError_t e = raise_lds_limit(lds_limit, reinterpret_cast<const void *>(kern), lds); e != hipSuccess) return e;
     if (query_only) {
         if (blocks_per_cu) *blocks_per_cu = (int)((160 * 1024) / lds) < 2 ? (int)((160 * 1024) / lds) : 2;
         return hipSuccess;

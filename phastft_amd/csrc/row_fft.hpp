@@ -242,13 +242,8 @@ hipError_t launch_row_inst(const RowArgs &a, hipStream_t stream, hipEvent_t ev_s
     using RB = RowBody<T, LR, LC, LP>;
     auto kern = row_fft_kernel<T, LR, LC, LP, REAL>;
     const size_t lds = RB::lds_bytes() + (REAL ? ((size_t)3 << a.rtw_bits) * sizeof(cx_t<T>) : 0);
-    static bool raised = false;  // once per instantiation: nothing but the launch in the steady state (graph capture)
-    if (!raised) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds);
-        if (e != hipSuccess) return e;
-        raised = true;
-    }
+    static PerDeviceLimit lds_limit;  // raised once per instantiation and device: nothing but the launch in the steady state (graph capture)
+    if (hipError_t e = raise_lds_limit(lds_limit, reinterpret_cast<const void *>(kern), lds); e != hipSuccess) return e;
     // persistent workgroups: enough to fill the chip several times over, grid-stride over the tiles
     const unsigned per_cu = (unsigned)((160 * 1024) / lds) < 8u ? (unsigned)((160 * 1024) / lds) : 8u;
     unsigned grid = 256u * (per_cu ? per_cu : 1u);

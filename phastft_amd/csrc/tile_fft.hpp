@@ -561,13 +561,8 @@ hipError_t launch_tile_inst(unsigned grid, hipStream_t stream, const TileArgs &a
         if (query_only && blocks_per_cu) *blocks_per_cu = 0;
         return query_only ? hipSuccess : hipErrorInvalidValue;
     }
-    static size_t lds_limit = 0;
-    if (lds > lds_limit) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        lds_limit = lds;
-    }
+    static PerDeviceLimit lds_limit;
+    if (hipError_t e = raise_lds_limit(lds_limit, reinterpret_cast<const void *>(kern), lds); e != hipSuccess) return e;
     if (query_only) {
         // residency from the kernel's real register count and LDS request (MI355X_MICROARCH.md: 512 VGPRs per
         // lane per SIMD in granules of 8, 160 KiB LDS per CU, 32 waves per CU); the occupancy API is only a

@@ -37,13 +37,9 @@ template <typename T> hipError_t launch_twiddle_grid(const TwiddleGridArgs &a, h
     if (a.rows == 0 || a.cols == 0) return hipSuccess;
     const size_t lds = ((size_t)3 << a.tw_bits) * sizeof(cx_t<T>);
     if (lds > (size_t)160 * 1024) return hipErrorInvalidValue;  // TwiddleGrid::init rejects such sizes up front
-    static size_t lds_limit = 0;  // raised only when the request grows (as launch_tile_inst): steady state = launch only
-    if (lds > lds_limit) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(twiddle_grid_kernel<T>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        lds_limit = lds;
-    }
+    static PerDeviceLimit lds_limit;  // raised only when the request grows (as launch_tile_inst): steady state = launch only
+    if (hipError_t e = raise_lds_limit(lds_limit, reinterpret_cast<const void *>(twiddle_grid_kernel<T>), lds); e != hipSuccess)
+        return e;
     unsigned gx = (unsigned)((a.cols + 255) / 256);
     if (gx > 64) gx = 64;
     unsigned gy = (unsigned)(a.rows < 65535 ? a.rows : 65535);

@@ -372,12 +372,8 @@ hipError_t launch_wave_inst(hipStream_t stream, const TileArgs &a, bool query_on
         if (query_only && blocks_per_cu) *blocks_per_cu = 0;
         return query_only ? hipSuccess : hipErrorInvalidValue;
     }
-    static size_t lds_limit = 0;
-    if (lds > lds_limit) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        lds_limit = lds;
-    }
+    static PerDeviceLimit lds_limit;
+    if (hipError_t e = raise_lds_limit(lds_limit, reinterpret_cast<const void *>(kern), lds); e != hipSuccess) return e;
     if (query_only) {
         if (blocks_per_cu) *blocks_per_cu = (int)((160 * 1024) / lds) < 4 ? (int)((160 * 1024) / lds) : 4;
         return hipSuccess;

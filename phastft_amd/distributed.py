@@ -71,8 +71,10 @@ class DistributedFft:
         """rank q receives every rank's q-th equal chunk of `send`; returns the chunks in source-rank order"""
         import torch
 
-        if self.world == 1:
+        if self.dist is None:  # a single process without a process group
             return send
+        # with a process group the exchange is a real collective even for one rank (world-size-1 "nccl" group: RCCL's
+        # all_to_all_single on device tensors, the one-GPU hardware test of this path)
         recv = torch.empty_like(send)
         if self.dist.get_backend() == "gloo" and send.is_cuda:  # dry run on one GPU: through host memory
             r = torch.empty(send.shape, dtype=send.dtype)
@@ -101,7 +103,7 @@ class DistributedFft:
 
         # exchange 1 -> [n1][n2 mine] (source-major = natural n1 order): column FFTs over n1
         a_re, a_im = self._all_to_all(pack(re)), self._all_to_all(pack(im))
-        if w == 1:
+        if self.dist is None:  # no exchange happened: a_re / a_im still alias the caller's slab
             a_re, a_im = a_re.clone(), a_im.clone()
         self._fft(a_re, a_im, n1, c2)
         # The inter-factor twiddle W_N^(k1 * n2) commutes with the exchange (it is element-wise): it is applied on the
@@ -140,7 +142,9 @@ def gpu_transform(n: int, rank: int, world: int, dist=None, dtype: str = "f64") 
     def column_fft(re, im, length, count):
         try:
             P.fft_dit_strided(re, im, length, P.Direction.Forward, planners[length], batch=count, stride=count)
-        except P.PhastPanic:
+        except P.PhastPanic as e:
+            if e.code != P.ERR_INVALID_ARG:  # only "this shape is not covered" falls back; real failures propagate
+                raise
             # shapes the strided kernels do not cover (fewer than 64 points, or too few columns for a tile row):
             # transpose, contiguous batch, transpose back
             t_re = re.view(length, count).t().contiguous().view(-1)
@@ -157,7 +161,9 @@ def gpu_transform(n: int, rank: int, world: int, dist=None, dtype: str = "f64") 
             P.fft_dit_strided(re, im, length, P.Direction.Forward, planners[length], batch=count, stride=count,
                               twiddle_n=n, twiddle_col0=col0)
             return True
-        except P.PhastPanic:
+        except P.PhastPanic as e:
+            if e.code != P.ERR_INVALID_ARG:
+                raise
             return False
 
     t = DistributedFft(n, rank, world, column_fft, twiddle, dist, column_fft_tw)

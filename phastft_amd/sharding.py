@@ -49,8 +49,10 @@ class ShardedBatch:
         import torch
 
         mine = self._digest(self.first, self.count)
-        if dist is None or self.world == 1:
+        if dist is None:  # no process group: a single process
             return mine
+        # with a process group the collective runs even for one rank (a world-size-1 "nccl" group on a one-GPU box
+        # is how RCCL init and the device-tensor all_gather are exercised on hardware, tests/test_gpu_parity_r3.py)
         if dist.get_backend() == "gloo":  # CPU collectives (tests, dry runs)
             mine = mine.cpu()
         counts = [shard_bounds(self.total, self.world, r)[1] for r in range(self.world)]

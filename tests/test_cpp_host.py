@@ -40,3 +40,15 @@ def test_cpp_host_side_on_gpu(exe):
     r = subprocess.run([exe, "gpu"], capture_output=True, text=True)
     sys.stdout.write(r.stdout)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_per_device_caches_with_fake_device_ids(tmp_path):
+    """the library's per-device state (raised dynamic-LDS limits, CU counts) is keyed by the device
+    ordinal and race-free; phastft_amd/csrc/device_state.hpp has no HIP types, so g++ compiles the test as it stands."""
+    out = str(tmp_path / "device_state_test")
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-pthread", "-I", os.path.join(ROOT, "phastft_amd", "csrc"),
+           os.path.join(ROOT, "tests", "cpp", "device_state_test.cpp"), "-o", out]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([out], capture_output=True, text=True)
+    assert r.returncode == 0 and "device_state: ok" in r.stdout, r.stdout + r.stderr

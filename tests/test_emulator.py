@@ -61,7 +61,9 @@ PLANS = [(12, (6, 6), 12, 4), (13, (7, 6), 12, 4), (15, (8, 7), 12, 4), (16, (8,
          # round 2: 1024- and 2048-point tiles (several workgroups per CU)
          (18, (6, 6, 6), 10, 3), (18, (6, 6, 6), 10, 4), (20, (7, 7, 6), 11, 3), (20, (7, 6, 7), 11, 4), (21, (7, 7, 7), 11, 5),
          # WAVE tiles (points code | 0x10: wave_fft.hpp, the cross-lane swaps emulated): all three passes
-         (18, (6, 6, 6), 10, 4 | 0x10)]
+         (18, (6, 6, 6), 10, 4 | 0x10),
+         # round 3: the forced plans that replaced the uninstantiable (9, 8, 3) of tests/test_gpu_parity.py
+         (20, (8, 6, 6), 12, 4), (20, (6, 6, 8), 12, 4)]
 
 
 @pytest.mark.parametrize("L,lrs,tl,lp", PLANS)

@@ -157,7 +157,7 @@ def test_inverse_matches_oracle(gpu, oracle):
         assert rel_l2(d_re.cpu().numpy(), d_im.cpu().numpy(), re, im) <= F64_REL
 
 
-@pytest.mark.parametrize("plan", [((10, 10), 13, 4), ((7, 7, 6), 12, 4), ((9, 8, 3), 12, 4), ((10, 10), 14, 5),
+@pytest.mark.parametrize("plan", [((10, 10), 13, 4), ((7, 7, 6), 12, 4), ((8, 6, 6), 12, 4), ((6, 6, 8), 12, 4), ((10, 10), 14, 5),
                                   ((10, 10), 14, 4), ((10, 10), 13, 5), ((10, 10), 12, 5), ((6, 8, 6), 12, 3),
                                   ((10, 10), 12, 3),
                                   # small tiles (several workgroups per CU) and WAVE tiles (points code | 0x10: every
@@ -169,10 +169,7 @@ def test_forced_plans_agree_2p20(gpu, oracle, plan):
     n = 1 << 20
     lrs, tl, lp = plan
     planner = gpu.PlannerDit64(n)
-    try:
-        planner.set_plan(lrs, tl, lp)
-    except gpu.PhastPanic:
-        pytest.skip(f"plan {plan} not instantiable")
+    planner.set_plan(lrs, tl, lp)  # every plan of the list exists as kernels: a refusal is a regression of set_plan
     re, im = oracle.fill(n, np.float64, transform_id=5)
     d_re, d_im = dev(re.copy()), dev(im.copy())
     gpu.fft_64_dit_with_planner(d_re, d_im, gpu.Direction.Forward, planner)

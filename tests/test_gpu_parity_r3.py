@@ -1,0 +1,335 @@
+"""Round-3 GPU parity tests ("Next round" items 1 and 2).
+
+* EVERY output of single transforms of 2^23 ... 2^26 points (both dtypes, the plan a single transform gets and the
+  throughput plan) and of one `tw3_global` size (2^28 f64) against the oracle -- the reference's own tests compare all
+  bins (lib.rs:298-338); rounds 1-2 held these sizes to Parseval + sampled bins only.
+* the committed golden fixtures (tests/golden/, made by make_golden.py from an independent extended-precision FFT)
+  through the HIP path.
+* the N > 1 code on a world-size-1 "nccl" group: RCCL init and all_gather / all_reduce / all_to_all_single on device
+  tensors really execute on the one GPU this pool gives a session.
+* planner memory: outgrown scratch is released once idle.
+
+Tolerances as tests/test_gpu_parity.py: C2C f64 rel-L2 <= 1e-13, f32 <= 1e-5.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "fft_golden.npz")
+F64_REL = 1e-13
+F32_REL = 1e-5
+
+
+def rel_l2(got_re, got_im, ref_re, ref_im):
+    """blockwise (the arrays are up to 2 GiB each: no full-size float64 temporaries)"""
+    num = den = 0.0
+    step = 1 << 22
+    for i in range(0, ref_re.size, step):
+        sl = slice(i, i + step)
+        a, b = got_re[sl].astype(np.float64), got_im[sl].astype(np.float64)
+        c, d = ref_re[sl].astype(np.float64), ref_im[sl].astype(np.float64)
+        num += float(np.sum((a - c) ** 2 + (b - d) ** 2))
+        den += float(np.sum(c ** 2 + d ** 2))
+    return np.sqrt(num / den) if den else np.sqrt(num)
+
+
+def max_bin_err(got_re, got_im, ref_re, ref_im):
+    """largest single-bin error relative to the rms bin magnitude: a permutation error confined to a few bins moves the
+    rel-L2 by ~sqrt(bins/N) only, this catches it outright"""
+    worst = 0.0
+    energy = 0.0
+    step = 1 << 22
+    for i in range(0, ref_re.size, step):
+        sl = slice(i, i + step)
+        c, d = ref_re[sl].astype(np.float64), ref_im[sl].astype(np.float64)
+        e = np.maximum(np.abs(got_re[sl].astype(np.float64) - c), np.abs(got_im[sl].astype(np.float64) - d))
+        worst = max(worst, float(e.max()))
+        energy += float(np.sum(c ** 2 + d ** 2))
+    return worst / np.sqrt(energy / ref_re.size)
+
+
+def dev(x):
+    import torch
+
+    return torch.from_numpy(x).cuda()
+
+
+def host_mem_gib():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                return int(line.split()[1]) / (1 << 20)
+    except OSError:
+        pass
+    return 0.0
+
+
+def _types(gpu, oracle, dt):
+    import torch
+
+    if dt == "f64":
+        return (np.float64, torch.float64, F64_REL, gpu.PlannerDit64, oracle.PlannerDit64, gpu.fft_64_dit_with_planner,
+                oracle.fft_64_dit_with_planner)
+    return (np.float32, torch.float32, F32_REL, gpu.PlannerDit32, oracle.PlannerDit32, gpu.fft_32_dit_with_planner,
+            oracle.fft_32_dit_with_planner)
+
+
+# ---------------------------------------------------------------- every output at 2^23 ... 2^26 (lib.rs:298-338)
+@pytest.mark.parametrize("dt", ["f64", "f32"])
+@pytest.mark.parametrize("k", [23, 24, 25, 26])
+def test_every_output_vs_oracle_large(gpu, oracle, k, dt):
+    """One transform through the plan a single transform gets, then a batch large enough for the THROUGHPUT plan
+    (2^27 points in flight: past every crossover of plan.hpp) whose first and last transforms are compared -- every
+    bin, rel-L2 and the worst single bin.  N = 2^26 also runs the inverse against the oracle's inverse."""
+    import torch
+
+    n = 1 << k
+    ndt, tdt, tol, GP, OP, gfft, offt = _types(gpu, oracle, dt)
+    bin_tol = 1e-11 if dt == "f64" else 1e-3  # worst bin / rms bin: ~ eps * log2(N) * a few sigma
+    planner, oplanner = GP(n), OP(n)
+    batch = max(2, (1 << 27) // n)
+    ids = [7, 7 + batch - 1]
+    refs = {}
+    for tid in sorted(set([k] + ids)):
+        r, m = oracle.fill(n, ndt, seed=0xCAFE, transform_id=tid)
+        offt(r, m, oracle.FORWARD, oplanner, fast=True)
+        refs[tid] = (r, m)
+    # (a) one transform: the single / latency / throughput plan plan_for(1) picks
+    h_re, h_im = oracle.fill(n, ndt, seed=0xCAFE, transform_id=k)
+    d_re, d_im = dev(h_re), dev(h_im)
+    gfft(d_re, d_im, gpu.Direction.Forward, planner)
+    g_re, g_im = d_re.cpu().numpy(), d_im.cpu().numpy()
+    err, worst = rel_l2(g_re, g_im, *refs[k]), max_bin_err(g_re, g_im, *refs[k])
+    assert err <= tol and worst <= bin_tol, (err, worst, planner.describe())
+    if k == 26:  # inverse of the forward result against the oracle's inverse of ITS forward result
+        gfft(d_re, d_im, gpu.Direction.Reverse, planner)
+        o_re, o_im = refs[k][0].copy(), refs[k][1].copy()
+        offt(o_re, o_im, oracle.REVERSE, oplanner, fast=True)
+        g_re, g_im = d_re.cpu().numpy(), d_im.cpu().numpy()
+        err, worst = rel_l2(g_re, g_im, o_re, o_im), max_bin_err(g_re, g_im, o_re, o_im)
+        assert err <= tol and worst <= bin_tol, ("inverse", err, worst)
+        assert float(np.max(np.abs(g_re - h_re))) < (1e-10 if dt == "f64" else 1e-4)
+        del o_re, o_im
+    del d_re, d_im, g_re, g_im
+    # (b) the throughput plan: `batch` transforms in flight, first and last against the oracle
+    re = torch.empty(n * batch, dtype=tdt, device="cuda")
+    im = torch.empty_like(re)
+    gpu.fill_uniform(re, im, n, seed=0xCAFE, first_id=7)
+    gpu.fft_dit_batched(re, im, n, gpu.Direction.Forward, planner)
+    for b, tid in ((0, ids[0]), (batch - 1, ids[1])):
+        sl = slice(b * n, (b + 1) * n)
+        g_re, g_im = re[sl].cpu().numpy(), im[sl].cpu().numpy()
+        err, worst = rel_l2(g_re, g_im, *refs[tid]), max_bin_err(g_re, g_im, *refs[tid])
+        assert err <= tol and worst <= bin_tol, (b, err, worst, planner.describe())
+
+
+def test_every_output_vs_oracle_2p28_tw3_global(gpu, oracle):
+    """N = 2^28 f64: the three-level inter-pass tables (48 KiB) no longer fit the LDS next to a 16384-point tile and
+    the passes read their table entries from global memory (TileBody::tw3_global) -- every bin against the oracle."""
+    if host_mem_gib() < 40:
+        pytest.skip("needs ~24 GiB of host memory for the oracle's 2^28-point planner and buffers")
+    n = 1 << 28
+    planner, oplanner = gpu.PlannerDit64(n), oracle.PlannerDit64(n)
+    h_re, h_im = oracle.fill(n, np.float64, seed=0xCAFE, transform_id=28)
+    d_re, d_im = dev(h_re), dev(h_im)
+    gpu.fft_64_dit_with_planner(d_re, d_im, gpu.Direction.Forward, planner)
+    oracle.fft_64_dit_with_planner(h_re, h_im, oracle.FORWARD, oplanner, fast=True)
+    del oplanner
+    g_re, g_im = d_re.cpu().numpy(), d_im.cpu().numpy()
+    err, worst = rel_l2(g_re, g_im, h_re, h_im), max_bin_err(g_re, g_im, h_re, h_im)
+    assert err <= F64_REL and worst <= 1e-11, (err, worst, planner.describe())
+
+
+# ---------------------------------------------------------------- committed golden vectors through the HIP path
+def test_golden_fixtures_gpu(gpu):
+    """tests/golden/fft_golden.npz (ramp / seeded-uniform C2C and R2C, both dtypes, N = 2^4 ... 2^12; generated by the
+    committed make_golden.py from numpy's pocketfft in long double): device tensors AND host slices."""
+    g = np.load(GOLDEN)
+    seen = 0
+    for key in g.files:
+        if not key.startswith("in_"):
+            continue
+        tag = key[3:]
+        kind, dt, k = tag.split("_")
+        dtype = np.float64 if dt == "f64" else np.float32
+        x = g[key]
+        exp_re, exp_im = g["re_" + tag], g["im_" + tag]
+        tol = 1e-13 if dtype == np.float64 else 2e-6
+        den = np.sqrt(np.sum(exp_re ** 2 + exp_im ** 2))
+        for on_device in (True, False):
+            if kind in ("ramp", "rand"):
+                re, im = x[0].astype(dtype).copy(), x[1].astype(dtype).copy()
+                fn = gpu.fft_64_dit if dtype == np.float64 else gpu.fft_32_dit
+                if on_device:
+                    d_re, d_im = dev(re), dev(im)
+                    fn(d_re, d_im, gpu.Direction.Forward)
+                    re, im = d_re.cpu().numpy(), d_im.cpu().numpy()
+                else:
+                    fn(re, im, gpu.Direction.Forward)
+            else:  # r2c
+                n = x.shape[-1]
+                fn = gpu.r2c_fft_f64 if dtype == np.float64 else gpu.r2c_fft_f32
+                if on_device:
+                    import torch
+
+                    tdt = torch.float64 if dtype == np.float64 else torch.float32
+                    d_in = dev(x.astype(dtype).copy())
+                    d_re = torch.zeros(n // 2 + 1, dtype=tdt, device="cuda")
+                    d_im = torch.zeros_like(d_re)
+                    fn(d_in, d_re, d_im)
+                    re, im = d_re.cpu().numpy(), d_im.cpu().numpy()
+                else:
+                    re, im = np.zeros(n // 2 + 1, dtype), np.zeros(n // 2 + 1, dtype)
+                    fn(x.astype(dtype).copy(), re, im)
+            num = np.sqrt(np.sum((re - exp_re) ** 2 + (im - exp_im) ** 2))
+            assert num <= tol * den, (tag, on_device, num / den)
+            seen += 1
+    assert seen >= 60, seen
+
+
+# ---------------------------------------------------------------- the N > 1 code on a world-size-1 RCCL group
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _dist_env():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    return env
+
+
+def test_bench_sharded_branch_on_world1_rccl(gpu):
+    """bench.py's N > 1 branch (init_process_group("nccl", device_id=...), ShardedBatch.step, barrier, max_over_ranks,
+    check_shard, gather_digests = all_gather of DEVICE tensors, the MIN all-reduce of the verdicts) with one rank:
+    everything RCCL-side runs on hardware; only the xGMI hops are missing."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--sharded", "--shard", "64",
+                        "--steps", "2", "--warmup", "1"], capture_output=True, text=True, env=_dist_env(), timeout=600,
+                       cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 1 and out["config"]["digest_ok"] is True, out["config"]
+    assert out["config"]["transforms_per_step"] == 64 and out["value"] > 1.0
+    assert "RCCL" in out["config"]["digest_gather"]
+
+
+_WORLD1_DISTRIBUTED = r"""
+import os, sys, json
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from oracle import oracle as O
+from phastft_amd.distributed import gpu_transform
+from phastft_amd.sharding import ShardedBatch, max_over_ranks
+import phastft_amd as P
+
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+assert dist.get_backend() == "nccl"
+res = {}
+for log_n, dt in ((21, "f64"), (20, "f32")):
+    n = 1 << log_n
+    ndt = np.float64 if dt == "f64" else np.float32
+    h_re, h_im = O.fill(n, ndt, seed=0xD157, transform_id=log_n)
+    re, im = torch.from_numpy(h_re.copy()).cuda(), torch.from_numpy(h_im.copy()).cuda()
+    t = gpu_transform(n, 0, 1, dist, dt)      # three all_to_all_single exchanges per plane on HIP tensors
+    t.run(re, im)
+    (O.fft_64_dit if dt == "f64" else O.fft_32_dit)(h_re, h_im, O.FORWARD)
+    scale = float(np.sqrt(np.sum(h_re.astype(np.float64) ** 2 + h_im.astype(np.float64) ** 2)))
+    res[dt] = float(np.sqrt(np.sum((re.cpu().numpy().astype(np.float64) - h_re) ** 2 +
+                                   (im.cpu().numpy().astype(np.float64) - h_im) ** 2))) / scale
+# the batch path's collectives on device tensors
+n, total = 1 << 12, 24
+re = torch.empty(total * n, dtype=torch.float64, device="cuda"); im = torch.empty_like(re)
+P.fill_uniform(re, im, n, seed=1, first_id=0)
+pl = P.PlannerDit64(n)
+sb = ShardedBatch(total, n, 0, 1, lambda f, c: P.fft_dit_batched(re, im, n, P.Direction.Forward, pl),
+                  lambda f, c: P.digest(re, im, n, probe=1))
+sb.step()
+d = sb.gather_digests(dist)
+res["digest_rows"] = int(d.shape[0]); res["digest_cuda"] = bool(d.is_cuda); res["digest_finite"] = bool(torch.isfinite(d).all())
+res["max_over_ranks"] = max_over_ranks(0.25, dist, torch.device("cuda", 0))
+dist.barrier()
+dist.destroy_process_group()
+print("RESULT " + json.dumps(res))
+"""
+
+
+def test_distributed_transform_and_digest_gather_on_world1_rccl(gpu, tmp_path):
+    """phastft_amd.distributed (one transform over the ranks: pack / all_to_all_single / column FFTs) and the sharded
+    batch's digest all_gather with a REAL nccl (= RCCL) process group of one rank, results against the oracle."""
+    script = tmp_path / "world1.py"
+    script.write_text(_WORLD1_DISTRIBUTED)
+    r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, env=_dist_env(), timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    assert res["f64"] <= F64_REL and res["f32"] <= F32_REL, res
+    assert res["digest_rows"] == 24 and res["digest_cuda"] and res["digest_finite"], res
+    assert res["max_over_ranks"] == 0.25
+
+
+# ---------------------------------------------------------------- planner memory
+def test_outgrown_scratch_is_released(gpu):
+    """A long-lived planner fed slowly growing batches: the scratch grows geometrically and every outgrown buffer is
+    freed once the work that used it has completed -- device_bytes() (live + retired) stays below 2 x what the largest
+    batch needs, where round 2 retained every predecessor (batches 1..1024 of 2^20 f64 summed to ~8 TB of requests)."""
+    import torch
+
+    n = 1 << 16
+    per = 2 * n * 8
+    planner = gpu.PlannerDit64(n)
+    re = torch.zeros(n * 300, dtype=torch.float64, device="cuda")
+    im = torch.zeros_like(re)
+    peak = 0
+    for batch in range(1, 301, 7):
+        gpu.fft_dit_batched(re[: n * batch], im[: n * batch], n, gpu.Direction.Forward, planner)
+        torch.cuda.synchronize()
+        peak = max(peak, planner.device_bytes())
+        assert planner.device_bytes() <= 3 * batch * per + (1 << 20), (batch, planner.device_bytes())
+    gpu.fft_dit_batched(re, im, n, gpu.Direction.Forward, planner)  # same size again: reaps what is idle, no growth
+    torch.cuda.synchronize()
+    gpu.fft_dit_batched(re, im, n, gpu.Direction.Forward, planner)
+    assert planner.device_bytes() <= 2 * 300 * per + (1 << 20), planner.device_bytes()
+    assert peak <= 3 * 300 * per
+
+
+def test_planner_follows_its_device_not_the_callers(gpu, oracle):
+    """A planner belongs to the device current at its creation; calls run there and leave the caller's current device
+    alone (one process may hold planners on several GPUs).  On a one-GPU box: the guard is a no-op that must not disturb
+    anything, from the creating thread and from another host thread."""
+    import threading
+
+    import torch
+
+    n = 1 << 15
+    planner = gpu.PlannerDit64(n)
+    h_re, h_im = oracle.fill(n, np.float64, transform_id=3)
+    ref_re, ref_im = h_re.copy(), h_im.copy()
+    oracle.fft_64_dit(ref_re, ref_im, oracle.FORWARD)
+    errs = []
+
+    def work():
+        torch.cuda.set_device(0)
+        a, b = dev(h_re.copy()), dev(h_im.copy())
+        gpu.fft_64_dit_with_planner(a, b, gpu.Direction.Forward, planner)
+        errs.append(rel_l2(a.cpu().numpy(), b.cpu().numpy(), ref_re, ref_im))
+        errs.append(torch.cuda.current_device())
+
+    work()
+    t = threading.Thread(target=work)
+    t.start()
+    t.join()
+    assert errs[0] <= F64_REL and errs[2] <= F64_REL and errs[1] == 0 and errs[3] == 0, errs
