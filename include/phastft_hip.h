@@ -229,6 +229,12 @@ int phast_digest_f64_dev(const double *d_reals, const double *d_imags, size_t n,
 int phast_digest_f32_dev(const float *d_reals, const float *d_imags, size_t n, size_t batch, size_t dist,
                          size_t probe, double *d_digest, void *stream);
 
+/* The _dev entry points are stream-capture safe (no allocation, no synchronisation in the steady state), so a
+ * launch-bound sequence of transforms is captured into a HIP graph with the plain HIP API around them.  This helper is
+ * hipGraphUpload for hosts that hold a hipGraphExec_t but cannot call HIP themselves (bench.py: the exec handle of a
+ * torch CUDAGraph): the first launch of an instantiated graph otherwise pays the upload inside the timed region. */
+int phast_hip_graph_upload(void *graph_exec, void *stream);
+
 /* ---- one transform spread over several GPUs (no reference counterpart: the reference's
  * recursion, algorithms/dit.rs:33-164, never leaves one address space).  A four-step split N = N1*N2 needs, between
  * its two local FFT stages, every element (r, c) of a rank's row-major slab multiplied by W_N^((row0 + r)*(col0 + c));

@@ -299,6 +299,7 @@ _tkind = ""
 
 def _declare_timing(l: C.CDLL) -> C.CDLL:
     for name, args in (("pho_time_fft_64_dit", [C.c_size_t, C.c_int, C.c_ulonglong]),
+                       ("pho_time_fft_32_dit", [C.c_size_t, C.c_int, C.c_ulonglong]),
                        ("pho_time_fft_64_dit_parallel", [C.c_size_t, C.c_int, C.c_ulonglong, C.c_int]),
                        ("pho_time_fft_64_roundtrip", [C.c_size_t, C.c_int, C.c_ulonglong]),
                        ("pho_time_r2c_fft_f32", [C.c_size_t, C.c_int, C.c_ulonglong])):
@@ -331,6 +332,10 @@ def timing_build() -> str:
 
 def time_fft_64_dit(n: int, iters: int, seed: int = 0xCAFE) -> float:
     return timing_lib().pho_time_fft_64_dit(n, iters, seed)
+
+
+def time_fft_32_dit(n: int, iters: int, seed: int = 0xCAFE) -> float:
+    return timing_lib().pho_time_fft_32_dit(n, iters, seed)
 
 
 def time_fft_64_dit_parallel(n: int, iters: int, seed: int = 0xCAFE, threads: int = 0) -> float:

@@ -198,6 +198,25 @@ static double time_fft_64(size_t n, int iters, unsigned long long seed, int par)
     return total;
 }
 
+/* f32 twin of pho_time_fft_64_dit (bench.py configs f32_2p20 / f32_2p26): planner outside the timer, input regenerated
+ * before every timed call */
+double pho_time_fft_32_dit(size_t n, int iters, unsigned long long seed) {
+    pho_planner_dit32 *planner;
+    if (pho_planner_dit32_new(n, &planner)) return -1.0;
+    float *re = malloc(n * sizeof(float)), *im = malloc(n * sizeof(float));
+    double total = 0.0;
+    for (int it = 0; it < iters && re && im; ++it) {
+        pho_fill_f32(re, im, n, seed, (unsigned long long)it);
+        double t0 = pho_now();
+        pho_fft_32_dit_with_planner(re, n, im, n, PHO_FORWARD, planner);
+        total += pho_now() - t0;
+    }
+    free(re);
+    free(im);
+    pho_planner_dit32_free(planner);
+    return total;
+}
+
 /* BASELINE configs[2]: forward then inverse on the same buffers, timed together */
 double pho_time_fft_64_roundtrip(size_t n, int iters, unsigned long long seed) {
     pho_planner_dit64 *planner;

@@ -144,6 +144,7 @@ const char *pho_strerror(int code);
  * examples/benchmark.rs:19-63 does; returns the SUM of the timed seconds.
  */
 double pho_time_fft_64_dit(size_t n, int iters, unsigned long long seed);
+double pho_time_fft_32_dit(size_t n, int iters, unsigned long long seed);
 double pho_time_fft_64_dit_parallel(size_t n, int iters, unsigned long long seed, int threads); /* feature `parallel` emulated; threads <= 0: OpenMP default */
 int pho_parallel_threads(void);
 double pho_time_fft_64_roundtrip(size_t n, int iters, unsigned long long seed); /* forward + inverse per iteration */

@@ -696,6 +696,23 @@ def digest(reals, imags, n: int, probe: int = 1):
     return out
 
 
+def graph_upload(graph, stream=None) -> bool:
+    """hipGraphUpload of an instantiated ``torch.cuda.CUDAGraph`` (so that its first replay does not pay the upload);
+    False when this torch build does not expose the exec handle."""
+    get = getattr(graph, "raw_cuda_graph_exec", None)
+    if get is None:
+        return False
+    try:
+        handle = get()
+    except Exception:  # handle not kept by this torch version / graph not instantiated yet
+        return False
+    import torch
+
+    s = stream if stream is not None else torch.cuda.current_stream()
+    _check(_lib.lib().phast_hip_graph_upload(C.c_void_p(int(handle)), C.c_void_p(s.cuda_stream)))
+    return True
+
+
 def device_info() -> dict:
     name = C.create_string_buffer(256)
     cus, lds, mem = C.c_int(), C.c_size_t(), C.c_size_t()

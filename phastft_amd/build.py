@@ -23,9 +23,12 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libphastft_hip.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
-UNITS = ["api", "tile_f64_a", "tile_f64_bc", "tile_f32_a", "tile_f32_bc", "wave_f64", "quad_f64", "small_fft", "bitrev", "r2c", "fill", "twiddle"]
+UNITS = ["api", "tile_f64_a", "tile_f64_bc", "tile_f64_bc_wide", "tile_f32_a", "tile_f32_bc", "tile_f32_bc_wide", "wave_f64", "quad_f64", "small_fft", "bitrev", "r2c", "fill", "twiddle"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-ffp-contract=fast", "-Rpass-analysis=kernel-resource-usage"]
+# per-unit compiler options (the scheduling strategy is a translation-unit option: tile_dispatch.hpp says why)
+UNIT_FLAGS = {"tile_f64_bc_wide": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+              "tile_f32_bc_wide": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 RESOURCES = os.path.join(LIB_DIR, "kernel_resources.json")  # per kernel: VGPRs, scratch bytes per lane, occupancy, spills
 
 
@@ -52,7 +55,7 @@ def _compile(unit: str, force: bool, trace: bool = False, extra: tuple = (), tag
     src = os.path.join(SRC, unit + ".hip")
     obj = os.path.join(OBJ, unit + ("_trace" if trace else "") + tag + ".o")
     if force or _stale(obj, [src] + _deps()):
-        cmd = [hipcc(), *FLAGS, *(["-DPHAST_TRACE"] if trace else []), *extra, "-I", INCLUDE, "-c", src, "-o", obj]
+        cmd = [hipcc(), *FLAGS, *(["-DPHAST_TRACE"] if trace else []), *UNIT_FLAGS.get(unit, []), *extra, "-I", INCLUDE, "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {unit}:\n{r.stdout}\n{r.stderr}")

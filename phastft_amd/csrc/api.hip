@@ -1276,6 +1276,12 @@ const char *phast_strerror(int code) {
 
 const char *phast_last_hip_error(void) { return g_hip_err; }
 
+int phast_hip_graph_upload(void *graph_exec, void *stream) {
+    if (!graph_exec) return PHAST_ERR_INVALID_ARG;
+    PHAST_HIP(hipGraphUpload(static_cast<hipGraphExec_t>(graph_exec), static_cast<hipStream_t>(stream)));
+    return PHAST_OK;
+}
+
 void phast_debug_set_wg_per_cu(int wg_per_cu) { g_wg_per_cu_override = wg_per_cu; }
 void phast_debug_set_trace(unsigned long long *d_trace) { g_trace = d_trace; }
 

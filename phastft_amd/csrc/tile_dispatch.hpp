@@ -8,6 +8,20 @@
 
 namespace phast {
 
+// The 1024 x 16 f64 pre-twiddle pass at 32 points per thread (second pass of the batched 2^20 transforms, BASELINE
+// configs[4]) sits exactly at the 256-register budget of a 512-thread workgroup: under the default scheduling strategy
+// the compiler spills 10 VGPRs (44 bytes of scratch per lane) in the second radix-32 step, under
+// -amdgpu-sched-strategy=max-ilp it does not (and the pass runs 1.5 % faster; the other kernels do not gain from that
+// strategy, profiles/r03_sched_strategy_max_ilp_cmp.log).  The strategy is a per-translation-unit option, so this one
+// instantiation lives in tile_f64_bc_wide.hip (phastft_amd/build.py: UNIT_FLAGS) and is only declared here.
+extern template hipError_t launch_tile_inst<double, 10, 4, 5, true, false, true>(unsigned, hipStream_t, const TileArgs &, bool, int *,
+                                                                                 size_t *, hipEvent_t, hipEvent_t);
+// Its f32 twin, the 1024 x 32 pass on 1024 threads (128 registers per lane): 19 spilled VGPRs under the default
+// options -- the SLP vectoriser pairs f32 operations into v_pk_add/v_pk_fma at the price of ~180 extra v_mov and
+// even-aligned register pairs -- none with -fno-slp-vectorize and the max-ilp strategy (tile_f32_bc_wide.hip).
+extern template hipError_t launch_tile_inst<float, 10, 5, 5, true, false, true>(unsigned, hipStream_t, const TileArgs &, bool, int *,
+                                                                                size_t *, hipEvent_t, hipEvent_t);
+
 // LDS exchange flavour per instantiation: f64 tiles with 16 points per thread exchange the re and im planes one
 // after the other (half the LDS -> more workgroups per CU); everything else exchanges both planes at once.
 template <typename T, bool PRE_TW, bool TRANSPOSE>

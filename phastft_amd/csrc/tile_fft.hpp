@@ -33,6 +33,10 @@
 #define PHAST_TW_PROG_MIN_LP 5
 #endif
 
+#ifndef PHAST_TW_PROG_G  // running values of the progression form of the pre-twiddle (common.hpp: tw_progression)
+#define PHAST_TW_PROG_G(P) ((P) >= 32 ? 8 : 4)
+#endif
+
 namespace phast {
 
 // ---- literal twiddles: (re, im) *= W_N^J = exp(-2*pi*i*J/N), N in {2,4,8,16,32}, 0 <= J < N/2 ----
@@ -221,15 +225,17 @@ template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool 
         if (PRE_TW || !a.in_interleaved) {
             const T *pr = reinterpret_cast<const T *>(a.in_re) + ubase;
             const T *pi = reinterpret_cast<const T *>(a.in_im) + ubase;
+            const size_t ustep = (size_t)M << a.log_s_in;
             static_for<0, P>([&](auto j) {
-                const size_t urow = (size_t)(decltype(j)::value * M) << a.log_s_in;
                 if constexpr (NT_HINT) {
-                    r.re[j] = __builtin_nontemporal_load(pr + urow + voff);
-                    r.im[j] = __builtin_nontemporal_load(pi + urow + voff);
+                    r.re[j] = __builtin_nontemporal_load(pr + voff);
+                    r.im[j] = __builtin_nontemporal_load(pi + voff);
                 } else {
-                    r.re[j] = (pr + urow)[voff];
-                    r.im[j] = (pi + urow)[voff];
+                    r.re[j] = pr[voff];
+                    r.im[j] = pi[voff];
                 }
+                pr += ustep;
+                pi += ustep;
             });
         } else {
             const cx *pz = reinterpret_cast<const cx *>(a.in_re) + ubase;
@@ -260,7 +266,7 @@ template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool 
         T br, bi, dr, di;
         tw3_combine<T>(tb, br, bi);
         tw3_combine<T>(td, dr, di);
-        tw_progression<T, P, (P >= 32 ? 8 : 4)>(br, bi, dr, di, [&](auto j, T wr, T wi) {
+        tw_progression<T, P, PHAST_TW_PROG_G(P)>(br, bi, dr, di, [&](auto j, T wr, T wi) {
             cmul(r.re[decltype(j)::value], r.im[decltype(j)::value], wr, wi);
         });
     }
@@ -455,6 +461,16 @@ __global__ void __launch_bounds__(1 << (LR + LC - LP), PHAST_MIN_WAVES(LR, LC)) 
     const typename Body::Shared sh{ex_re, Body::PLANE_SEQ ? ex_re : ex_re + Body::EXCH, l_tw3, l_twr};
 
     int tid = threadIdx.x;
+    // The thread id is not kept in a VGPR across the phases of a tile: the wave's first thread id sits in an SGPR and
+    // the lane number is two mbcnt instructions away.  fresh_tid() launders the SGPR, so nothing derived from the
+    // thread id (LDS exchange and twiddle-table addresses, ~100 values) can be hoisted out of the tile loop or kept
+    // live -- or spilled -- across a phase; each phase recomputes what it needs with a few integer ops.  (Round 2
+    // laundered a VGPR copy of the id once per tile: that VGPR and `col` were what the 32-point f32 kernel spilled.)
+    unsigned wave_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
+    auto fresh_tid = [&]() {
+        asm volatile("" : "+s"(wave_base));
+        return (int)(wave_base | __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
+    };
     // Phase stamps exist only in the -DPHAST_TRACE build (tools/trace_tile.py): even behind a uniform branch the
     // drains below wreck register allocation (256 VGPRs + 300 spills), so the product kernels carry none.
 #ifdef PHAST_TRACE
@@ -488,6 +504,7 @@ __global__ void __launch_bounds__(1 << (LR + LC - LP), PHAST_MIN_WAVES(LR, LC)) 
     // one exchange: barrier (previous readers done), write, barrier, read -- per plane when PLANE_SEQ
     auto exchange = [&](auto e) {
         constexpr int E = decltype(e)::value;
+        tid = fresh_tid();
         if constexpr (!Body::PLANE_SEQ) {
             __syncthreads();
             Body::template ex_write<E>(sh, tid, r, 0);
@@ -511,15 +528,13 @@ __global__ void __launch_bounds__(1 << (LR + LC - LP), PHAST_MIN_WAVES(LR, LC)) 
         stamp();
     };
     auto do_step = [&](auto i) {
+        tid = fresh_tid();
         Body::template step<decltype(i)::value>(sh, tid, r);
         stamp();
     };
 
     while (t < a.tiles_total) {
-        // Launder the thread id once per tile: everything derived from it (LDS exchange and twiddle-table
-        // addresses, ~100 values) is then recomputed per tile with a few integer ops instead of being hoisted out
-        // of this loop and kept live -- or spilled -- across it.
-        asm volatile("" : "+v"(tid));
+        tid = fresh_tid();  // (see fresh_tid above: nothing derived from the thread id survives a phase)
         if constexpr (Body::PROG) {  // only the six table reads differ (ds_read / global_load); the arithmetic is shared
             unsigned e0, de;
             Body::pre_twiddle_exps(a, tid, r, e0, de);
@@ -537,10 +552,12 @@ __global__ void __launch_bounds__(1 << (LR + LC - LP), PHAST_MIN_WAVES(LR, LC)) 
         }
         stamp();  // 2: tile loaded (+ pre-twiddle)
         Body::chain(do_step, exchange);
+        tid = fresh_tid();
         Body::store(a, tid, r);
         stamp();  // last: stores retired
         t += gridDim.x;
         if (t < a.tiles_total) {  // next tile's loads go out right behind the stores
+            tid = fresh_tid();
             Body::locate(a, t, r);
             Body::load_raw(a, tid, r);
         }
