@@ -138,7 +138,7 @@ template <> struct Types<double> {
 template <typename T> static hipError_t launch_wave(bool transpose, hipStream_t s, const TileArgs &a, bool q, int *b, size_t *l,
                                                     hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
     if constexpr (sizeof(T) == 8) return launch_wave_f64(transpose, s, a, q, b, l, e0, e1);
-    else return hipErrorInvalidValue;  // wave tiles exist for f64 only (make_passes never asks for them in f32)
+    else return launch_wave_f32(transpose, s, a, q, b, l, e0, e1);
 }
 template <typename T> static hipError_t launch_quad(unsigned grid, hipStream_t s, const TileArgs &a, bool q, int *b, size_t *l,
                                                     hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {

@@ -128,7 +128,7 @@ constexpr unsigned kWaveTiles = 0x10;  // flag in a plan's points-per-thread cod
 struct PassGeom {
     unsigned lr = 0, lc = 0;
     unsigned lp = 4;  // log2(points per thread): 4 = throughput tiles, 3 = latency tiles (twice the waves)
-    bool wave = false;  // one wave per 64 x 16 tile, exchange by cross-lane swaps (wave_fft.hpp; f64 only)
+    bool wave = false;  // one wave per 64-row x 128-byte tile, exchange by cross-lane swaps (wave_fft.hpp)
     bool quad = false;  // four waves per 256 x 16 tile, one LDS + one cross-lane exchange (quad_fft.hpp; f64, later passes)
     bool pre_tw = false, transpose = false;
     unsigned log_s_in = 0, out_lo_bits = 0, tw_bits = 1;
@@ -258,19 +258,19 @@ inline bool make_passes(unsigned L, const std::vector<unsigned> &lrs, const std:
     if (tile_logs.size() != 1 && tile_logs.size() != lrs.size()) return false;
     ps.assign(lrs.size(), PassGeom());
     const unsigned a = lrs[0], b = lrs[1], c = lrs.size() == 3 ? lrs[2] : 0;
-    // lp & 0x10 (kWaveTiles): every pass whose tile is 64 rows x 16 columns runs as wave tiles, every later pass with
-    // 256 x 16 tiles as the four-wave kernel (f64 only);
+    // lp & 0x10 (kWaveTiles): every pass whose tile is 64 rows x 128 bytes (16 f64 / 32 f32 columns) runs as wave tiles,
+    // every later f64 pass with 256 x 16 tiles as the four-wave kernel;
     // lp & 0xf = log2(points per thread) of the other passes
-    const bool want_wave = (lp & kWaveTiles) != 0 && elem_bytes == 8;
+    const bool want_wave = (lp & kWaveTiles) != 0;
     lp &= 0xfu;
     for (size_t i = 0; i < lrs.size(); ++i) {
         const unsigned tl = tile_logs.size() == 1 ? tile_logs[0] : tile_logs[i];
         if (lrs[i] > tl) return false;
         ps[i].lr = lrs[i];
         ps[i].lc = tl - lrs[i];
-        ps[i].wave = want_wave && lrs[i] == 6 && tl == 10;
-        ps[i].quad = want_wave && lrs[i] == 8 && tl == 12 && i > 0;
-        ps[i].lp = (ps[i].wave || ps[i].quad) ? 4 : lp;
+        ps[i].wave = want_wave && lrs[i] == 6 && tl == (elem_bytes == 8 ? 10u : 11u);
+        ps[i].quad = want_wave && elem_bytes == 8 && lrs[i] == 8 && tl == 12 && i > 0;
+        ps[i].lp = ps[i].wave ? (elem_bytes == 8 ? 4u : 5u) : ps[i].quad ? 4u : lp;
         if (!ps[i].wave && !ps[i].quad && !shape_exists(lrs[i], tl - lrs[i], lp, elem_bytes)) return false;
     }
     ps[0].transpose = true;  // FFT over the top `a` index bits; every column leaves as one contiguous run

@@ -33,6 +33,12 @@
 #define PHAST_TW_PROG_MIN_LP 5
 #endif
 
+#ifndef PHAST_RUNNING_ROW_PTR  // measured, not adopted: see TileBody::load_raw
+#define PHAST_RUNNING_ROW_PTR 0
+#endif
+#ifndef PHAST_FRESH_TID
+#define PHAST_FRESH_TID 1
+#endif
 #ifndef PHAST_TW_PROG_G  // running values of the progression form of the pre-twiddle (common.hpp: tw_progression)
 #define PHAST_TW_PROG_G(P) ((P) >= 32 ? 8 : 4)
 #endif
@@ -225,17 +231,30 @@ template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool 
         if (PRE_TW || !a.in_interleaved) {
             const T *pr = reinterpret_cast<const T *>(a.in_re) + ubase;
             const T *pi = reinterpret_cast<const T *>(a.in_im) + ubase;
+            // With P independent 64-bit row bases per plane the compiler materialises all of them up front -- 128 SGPRs for
+            // 32 rows x 2 planes, 50-79 of them parked in VGPR lanes (v_writelane / v_readlane) in the 32-point kernels.
+            // PHAST_RUNNING_ROW_PTR=1 makes them running pointers (two scalar adds per row, no SGPR spills) -- and the
+            // loads then issue one address computation apart instead of back to back: the 256 x 64 pass of 2^24 x 4 ran
+            // 4 % SLOWER, nothing else moved (profiles/r03_ablation_tid_rowptr.log).  Not adopted.
             const size_t ustep = (size_t)M << a.log_s_in;
+            (void)ustep;
             static_for<0, P>([&](auto j) {
+#if PHAST_RUNNING_ROW_PTR
+                const size_t urow = 0;
+#else
+                const size_t urow = (size_t)(decltype(j)::value * M) << a.log_s_in;
+#endif
                 if constexpr (NT_HINT) {
-                    r.re[j] = __builtin_nontemporal_load(pr + voff);
-                    r.im[j] = __builtin_nontemporal_load(pi + voff);
+                    r.re[j] = __builtin_nontemporal_load(pr + urow + voff);
+                    r.im[j] = __builtin_nontemporal_load(pi + urow + voff);
                 } else {
-                    r.re[j] = pr[voff];
-                    r.im[j] = pi[voff];
+                    r.re[j] = (pr + urow)[voff];
+                    r.im[j] = (pi + urow)[voff];
                 }
+#if PHAST_RUNNING_ROW_PTR
                 pr += ustep;
                 pi += ustep;
+#endif
             });
         } else {
             const cx *pz = reinterpret_cast<const cx *>(a.in_re) + ubase;
@@ -467,9 +486,16 @@ __global__ void __launch_bounds__(1 << (LR + LC - LP), PHAST_MIN_WAVES(LR, LC)) 
     // live -- or spilled -- across a phase; each phase recomputes what it needs with a few integer ops.  (Round 2
     // laundered a VGPR copy of the id once per tile: that VGPR and `col` were what the 32-point f32 kernel spilled.)
     unsigned wave_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
+    bool first_fresh = true;
     auto fresh_tid = [&]() {
+#if PHAST_FRESH_TID
         asm volatile("" : "+s"(wave_base));
         return (int)(wave_base | __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
+#else  // tools only: round 2's form, one laundered VGPR copy per tile
+        (void)wave_base;
+        if (first_fresh) asm volatile("" : "+v"(tid));
+        return tid;
+#endif
     };
     // Phase stamps exist only in the -DPHAST_TRACE build (tools/trace_tile.py): even behind a uniform branch the
     // drains below wreck register allocation (256 VGPRs + 300 spills), so the product kernels carry none.
@@ -534,7 +560,9 @@ __global__ void __launch_bounds__(1 << (LR + LC - LP), PHAST_MIN_WAVES(LR, LC)) 
     };
 
     while (t < a.tiles_total) {
+        first_fresh = true;
         tid = fresh_tid();  // (see fresh_tid above: nothing derived from the thread id survives a phase)
+        first_fresh = false;
         if constexpr (Body::PROG) {  // only the six table reads differ (ds_read / global_load); the arithmetic is shared
             unsigned e0, de;
             Body::pre_twiddle_exps(a, tid, r, e0, de);

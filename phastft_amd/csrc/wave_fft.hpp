@@ -1,20 +1,23 @@
 // wave_fft.hpp -- one pass of the multi-pass FFT with ONE WAVE PER TILE and the butterfly exchange done by
-// cross-lane swaps instead of LDS + barriers (f64; BASELINE.json north_star: "cross-lane shuffles via
+// cross-lane swaps instead of LDS + barriers (BASELINE.json north_star: "cross-lane shuffles via
 // DS_PERMUTE/ds_swizzle wavefront primitives" -- on gfx950 the cheapest member of that family for this pattern is
 // v_permlane16_swap / v_permlane32_swap, one VALU instruction per swapped dword pair, no LDS round trip).
 //
 // Same pass algebra as tile_fft.hpp (see there for the reference citations: kernels/dit.rs, algorithms/dit.rs,
-// algorithms/bravo.rs): a tile is ROWS = 64 rows x COLS = 16 adjacent columns (128-byte rows in f64) = 1024 points,
-// held by the 64 lanes of one wave at P = 16 points per lane:
-//     lane = (col = lane & 15, tau = lane >> 4),   register j holds row n = 4 j + tau        (j = 0..15)
-//   1. radix-16 DIF over j in registers (literal twiddles)            -> register p holds digit k1 = bitrev4(p)
+// algorithms/bravo.rs): a tile is ROWS = 64 rows x COLS adjacent columns with 128-BYTE ROWS in either type, held by the
+// 64 lanes of one wave:
+//     f64: COLS = 16, TAUS = 4 lanes per column, P = 16 points per lane  (1024-point tiles; round 2)
+//     f32: COLS = 32, TAUS = 2 lanes per column, P = 32 points per lane  (2048-point tiles; round 3: the f32 twin)
+//     lane = (col = lane & (COLS - 1), tau = lane >> LC),   register j holds row n = TAUS j + tau        (j < P)
+//   1. radix-P DIF over j in registers (literal twiddles)             -> register p holds digit k1 = bitrev(p)
 //   2. inter-digit twiddle W_64^(tau * k1)
-//   3. EXCHANGE: the 4 x 4 transposition between the lane bits (5, 4) = tau and the register bits (p1, p0):
-//         round 1: v_permlane32_swap on the register pairs (p, p | 2)   -- lane bit 5 <-> register bit 1
-//         round 2: v_permlane16_swap on the register pairs (p, p | 1)   -- lane bit 4 <-> register bit 0
-//      afterwards lane tau' = (b5 b4), register (p3 p2 s1 s0) holds the value of tau = (s1 s0), k1 = bitrev4(p3 p2 b5 b4)
-//   4. radix-4 DIF over tau in registers, four independent groups     -> register 4 g + s holds k2 = bitrev2(s)
-//      output row k = k1 + 16 k2
+//   3. EXCHANGE: the transposition between the lane bits above the column and the low register bits:
+//         f64: v_permlane32_swap on the register pairs (p, p | 2)   -- lane bit 5 <-> register bit 1
+//              v_permlane16_swap on the register pairs (p, p | 1)   -- lane bit 4 <-> register bit 0
+//         f32: v_permlane32_swap on the register pairs (p, p | 1)   -- lane bit 5 <-> register bit 0
+//      afterwards lane tau', register (g, s) holds the value of tau = s, k1 = bitrev((g << LT) | tau')
+//   4. radix-TAUS DIF over tau in registers, P / TAUS independent groups -> register TAUS g + s holds k2 = bitrev(s)
+//      output row k = k1 + P k2
 // No workgroup barrier anywhere: the four waves of a 256-thread block are four independent tiles (own copy of the W_64
 // table in LDS, inter-pass tables read from global memory), and their loads are deliberately issued a little apart
 // (see the kernel: staggered waves).  Pass A's transposition to contiguous output runs goes through
@@ -33,8 +36,10 @@ namespace phast {
 
 template <typename T, bool PRE_TW, bool TRANSPOSE> struct WaveBody {
     using cx = cx_t<T>;
-    static constexpr int LR = 6, LC = 4, LP = 4;
-    static constexpr int ROWS = 64, COLS = 16, P = 16, TAUS = 4;
+    static constexpr int LR = 6, LC = sizeof(T) == 8 ? 4 : 5;  // 128-byte rows
+    static constexpr int LT = 6 - LC, LP = 6 - LT;               // lanes per column 2^LT, points per lane 2^LP
+    static constexpr int ROWS = 64, COLS = 1 << LC, P = 1 << LP, TAUS = 1 << LT;
+    static_assert(P == COLS, "the transposing buffer of pass A hands register Q column Q");
 // tiles (= waves) per workgroup: 4 measured best for the single 2^20 transform (26.5 us; 27.2 / 27.5 / 29.2 at 1 / 2 / 8)
 #ifndef PHAST_WAVE_TILES_PER_BLOCK
 #define PHAST_WAVE_TILES_PER_BLOCK 4
@@ -104,7 +109,7 @@ template <typename T, bool PRE_TW, bool TRANSPOSE> struct WaveBody {
         }
     }
 
-    // inter-pass twiddle W_{64 S}^{row * lo}: row = tau + 4 j  =>  W^(tau lo) * (W^(4 lo))^j.  Two table look-ups and a
+    // inter-pass twiddle W_{64 S}^{row * lo}: row = tau + TAUS j  =>  W^(tau lo) * (W^(TAUS lo))^j.  Two table look-ups and a
     // geometric progression (tw_progression: 4 running values stepped by D^4, 17 products where a table of the powers costs
     // 30) instead of 16 look-ups (48 LDS reads): its rounding (<= 7 extra complex products, ~1.1e-16 each) is far inside the 1e-13 budget (measured rel-L2 unchanged, tests/test_gpu_parity.py)
     struct TwRaw {
@@ -137,10 +142,10 @@ template <typename T, bool PRE_TW, bool TRANSPOSE> struct WaveBody {
     }
 
     PHAST_HD static void step1(const cx *twr, int lane, Regs &r) {
-        fft_reg_dif<T, 16, 0, P>(r.re, r.im);
+        fft_reg_dif<T, P, 0, P>(r.re, r.im);
         const unsigned tau = (unsigned)tau_of(lane);
         static_for<1, P>([&](auto p) {
-            constexpr int K1 = bitrev_c(decltype(p)::value, 4);
+            constexpr int K1 = bitrev_c(decltype(p)::value, LP);
             T wr, wi;
             w64(twr, tau * K1, wr, wi);
             cmul(r.re[p], r.im[p], wr, wi);
@@ -148,18 +153,20 @@ template <typename T, bool PRE_TW, bool TRANSPOSE> struct WaveBody {
     }
 
     PHAST_HD static void step2(Regs &r) {
-        static_for<0, 4>([&](auto g) { fft_reg_dif<T, 4, decltype(g)::value * 4, P>(r.re, r.im); });
+        static_for<0, P / TAUS>([&](auto g) { fft_reg_dif<T, TAUS, decltype(g)::value * TAUS, P>(r.re, r.im); });
     }
 
-    // output row held by register Q = 4 g + s of lane tau' after step2:  k1 + 16 k2,
-    //   k1 = bitrev4(p3 p2 b5 b4) = 8 b4 + 4 b5 + 2 p2 + p3  (g = p3 p2, tau' = b5 b4),  k2 = bitrev2(s)
+    // output row held by register Q = TAUS g + s of lane tau' after step2:  k1 + P k2,
+    //   k1 = bitrev_LP((g << LT) | tau') = (bitrev_LT(tau') << (LP - LT)) + bitrev_(LP-LT)(g),   k2 = bitrev_LT(s)
+    //   (f64: k1 = bitrev4(p3 p2 b5 b4) = 8 b4 + 4 b5 + 2 p2 + p3;  f32: k1 = bitrev5(p4 p3 p2 p1 b5) = 16 b5 + bitrev4(g))
     PHAST_HD static unsigned krow_lane(int lane) {
         const unsigned t = (unsigned)tau_of(lane);
-        return ((t & 1u) << 3) | ((t >> 1) << 2);
+        if constexpr (LT == 2) return ((t & 1u) << 3) | ((t >> 1) << 2);
+        else return t << (LP - LT);
     }
     template <int Q> PHAST_HD static constexpr unsigned krow_const() {
-        constexpr int G = Q >> 2, S = Q & 3;
-        return (unsigned)(((G & 1) << 1) | (G >> 1)) + 16u * (unsigned)bitrev_c(S, 2);
+        constexpr int G = Q >> LT, S = Q & (TAUS - 1);
+        return (unsigned)bitrev_c(G, LP - LT) + (unsigned)P * (unsigned)bitrev_c(S, LT);
     }
 
     PHAST_HD static size_t out_base(const TileArgs &a, const Regs &r) {
@@ -258,7 +265,7 @@ template <bool HALVES> __device__ __forceinline__ void swap_pair(float &a, float
     a = __uint_as_float(x);
     b = __uint_as_float(y);
 }
-template <typename T> __device__ __forceinline__ void wave_exchange(T (&re)[16], T (&im)[16]) {
+template <typename T> __device__ __forceinline__ void wave_exchange(T (&re)[16], T (&im)[16]) {  // f64: two lane bits
     static_for<0, 16>([&](auto p) {  // round 1: lane bit 5 <-> register bit 1
         constexpr int Pp = decltype(p)::value;
         if constexpr ((Pp & 2) == 0) {
@@ -271,6 +278,15 @@ template <typename T> __device__ __forceinline__ void wave_exchange(T (&re)[16],
         if constexpr ((Pp & 1) == 0) {
             swap_pair<false>(re[Pp], re[Pp | 1]);
             swap_pair<false>(im[Pp], im[Pp | 1]);
+        }
+    });
+}
+template <typename T> __device__ __forceinline__ void wave_exchange(T (&re)[32], T (&im)[32]) {  // f32: one lane bit
+    static_for<0, 32>([&](auto p) {  // lane bit 5 <-> register bit 0
+        constexpr int Pp = decltype(p)::value;
+        if constexpr ((Pp & 1) == 0) {
+            swap_pair<true>(re[Pp], re[Pp | 1]);
+            swap_pair<true>(im[Pp], im[Pp | 1]);
         }
     });
 }
@@ -343,14 +359,14 @@ __global__ void __launch_bounds__(64 * PHAST_WAVE_TILES_PER_BLOCK) wave_fft_kern
     if constexpr (TRANSPOSE) {
         // wave-private transposition: this wave writes and then reads its own buffer; LDS operations of one wave
         // execute in order, and the compiler's s_waitcnt lgkmcnt covers the data dependency -- no barrier
-        static_for<0, 16>([&](auto Q) {
+        static_for<0, Body::P>([&](auto Q) {
             xp[Body::template xp_write_addr<decltype(Q)::value>(lane)] = r.re[Q];
             xp[Body::XP + Body::template xp_write_addr<decltype(Q)::value>(lane)] = r.im[Q];
         });
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        static_for<0, 16>([&](auto Q) {
+        static_for<0, Body::P>([&](auto Q) {
             r.re[Q] = xp[Body::template xp_read_addr<decltype(Q)::value>(lane)];
             r.im[Q] = xp[Body::XP + Body::template xp_read_addr<decltype(Q)::value>(lane)];
         });
@@ -406,11 +422,11 @@ template <typename T, bool PRE_TW, bool TRANSPOSE> void emulate_wave_pass(const 
                 Body::pre_twiddle(a, reinterpret_cast<const cx_t<T> *>(a.tw3), l, regs[l]);
                 Body::step1(reinterpret_cast<const cx_t<T> *>(a.twr), l, regs[l]);
             }
-            for (int l = 0; l < 64; ++l) {
+            for (int l = 0; l < 64; ++l) {  // new[lane tau'][register (g, s)] = old[lane tau = s][register (g, tau')]
                 nxt[l] = regs[l];
-                const int col = l & 15, b = l >> 4;
-                for (int q = 0; q < 16; ++q) {
-                    const int src_lane = ((q & 3) << 4) | col, src_reg = (q & 12) | b;
+                const int col = Body::col_of(l), b = Body::tau_of(l);
+                for (int q = 0; q < Body::P; ++q) {
+                    const int src_lane = ((q & (Body::TAUS - 1)) << Body::LC) | col, src_reg = (q & ~(Body::TAUS - 1)) | b;
                     nxt[l].re[q] = regs[src_lane].re[src_reg];
                     nxt[l].im[q] = regs[src_lane].im[src_reg];
                 }
@@ -418,12 +434,12 @@ template <typename T, bool PRE_TW, bool TRANSPOSE> void emulate_wave_pass(const 
             for (int l = 0; l < 64; ++l) Body::step2(nxt[l]);
             if constexpr (TRANSPOSE) {
                 for (int l = 0; l < 64; ++l)
-                    static_for<0, 16>([&](auto Q) {
+                    static_for<0, Body::P>([&](auto Q) {
                         xp[Body::template xp_write_addr<decltype(Q)::value>(l)] = nxt[l].re[Q];
                         xp[Body::XP + Body::template xp_write_addr<decltype(Q)::value>(l)] = nxt[l].im[Q];
                     });
                 for (int l = 0; l < 64; ++l) {
-                    static_for<0, 16>([&](auto Q) {
+                    static_for<0, Body::P>([&](auto Q) {
                         nxt[l].re[Q] = xp[Body::template xp_read_addr<decltype(Q)::value>(l)];
                         nxt[l].im[Q] = xp[Body::XP + Body::template xp_read_addr<decltype(Q)::value>(l)];
                     });

@@ -260,3 +260,23 @@ def test_strided_batch_geometry_vs_oracle(emu, oracle, L, s, sb):
         assert np.sqrt(np.sum((A[:, c] - r) ** 2 + (B[:, c] - m) ** 2) / np.sum(r ** 2 + m ** 2)) <= 1e-13, c
     if batch < stride:
         assert np.array_equal(A[:, batch:], R[:, batch:]) and np.array_equal(B[:, batch:], I[:, batch:])
+
+
+@pytest.mark.parametrize("L,lrs,tl", [(18, (6, 6, 6), 11), (17, (6, 6, 5), 11)])
+def test_f32_wave_tiles_vs_oracle(emu, oracle, L, lrs, tl):
+    """round 3: the f32 twin of the wave tiles (64 rows x 32 columns, 32 points per lane, ONE lane bit exchanged by
+    v_permlane32_swap; wave_fft.hpp) -- all passes of 2^18 as wave tiles, forward and inverse, against the oracle; a
+    plan whose last pass is not 64 rows long must be refused or run the generic tiles for it."""
+    n = 1 << L
+    for direction, odir in ((1, oracle.FORWARD), (-1, oracle.REVERSE)):
+        re, im = oracle.fill(n, np.float32, transform_id=L)
+        a, b = re.copy(), im.copy()
+        rc = run(emu, a, b, direction, lrs, tl, 3 | 0x10)
+        if lrs[-1] != 6:
+            assert rc != 0  # (5, 6, 3) is not a tile shape: the plan is refused, nothing runs
+            return
+        assert rc == 0
+        oracle.fft_32_dit(re, im, odir)
+        err = np.sqrt(np.sum((a.astype(np.float64) - re) ** 2 + (b.astype(np.float64) - im) ** 2) /
+                      np.sum(re.astype(np.float64) ** 2 + im.astype(np.float64) ** 2))
+        assert err <= 1e-5, err
