@@ -264,6 +264,13 @@ int phast_planner_dit32_set_plan(phast_planner_dit32 *p, const unsigned *log_row
 /* tuning hook: force the number of resident workgroups per CU the tile passes are launched with (0 = planner's own
  * residency estimate).  Process-wide; for sweeps in tools/ only. */
 void phast_debug_set_wg_per_cu(int wg_per_cu);
+/* debug hooks for the sanitizer pass (the boxes run with xnack off, so device-side ASan is not
+ * available): scratch buffers allocated AFTER phast_debug_set_guard_bytes(b) carry a b-byte guard band filled with 0xA5
+ * on either side; ..._debug_check_guards blocks until the device is idle and counts the band bytes a kernel overwrote */
+void phast_debug_set_guard_bytes(size_t bytes);
+int phast_planner_dit64_debug_check_guards(const phast_planner_dit64 *p, size_t *bad_bytes);
+int phast_planner_dit32_debug_check_guards(const phast_planner_dit32 *p, size_t *bad_bytes);
+
 /* debug hook: device buffer of [3 passes][4096 workgroups][16] s_memtime stamps written by the tile kernels while
  * set (NULL = off; adds drains, so never leave it on while measuring).  tools/trace_tile.py decodes it. */
 void phast_debug_set_trace(unsigned long long *d_trace);

@@ -200,6 +200,12 @@ class _PlannerDit:
     def device_bytes(self) -> int:
         return int(getattr(_lib.lib(), f"phast_planner_dit{self._sfx}_device_bytes")(self._h))
 
+    def check_guards(self) -> int:
+        """debug: bytes of the scratch's guard bands overwritten since allocation (see :func:`debug_set_guard_bytes`)"""
+        bad = C.c_size_t(0)
+        _check(getattr(_lib.lib(), f"phast_planner_dit{self._sfx}_debug_check_guards")(self._h, C.byref(bad)))
+        return int(bad.value)
+
     def reserve_batch(self, max_batch: int) -> None:
         _check(getattr(_lib.lib(), f"phast_planner_dit{self._sfx}_reserve_batch")(self._h, C.c_size_t(max_batch)))
 
@@ -694,6 +700,11 @@ def digest(reals, imags, n: int, probe: int = 1):
                                                          C.c_size_t(n), C.c_size_t(probe), C.c_void_p(out.data_ptr()),
                                                          _stream()))
     return out
+
+
+def debug_set_guard_bytes(nbytes: int) -> None:
+    """debug: scratch buffers allocated from now on carry `nbytes` of 0xA5 guard band on either side"""
+    _lib.lib().phast_debug_set_guard_bytes(C.c_size_t(nbytes))
 
 
 def graph_upload(graph, stream=None) -> bool:

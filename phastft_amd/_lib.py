@@ -35,6 +35,7 @@ phast_c2r_fft_f64_dev phast_c2r_fft_f32_dev
 phast_fill_f64_dev phast_fill_f32_dev phast_digest_f64_dev phast_digest_f32_dev phast_hip_graph_upload
 phast_planner_dit64_set_plan phast_planner_dit32_set_plan
 phast_planner_dit64_time_passes phast_planner_dit32_time_passes phast_debug_set_wg_per_cu phast_debug_set_trace
+phast_debug_set_guard_bytes phast_planner_dit64_debug_check_guards phast_planner_dit32_debug_check_guards
 phast_planner_r2c64_time_passes phast_planner_r2c32_time_passes phast_planner_r2c64_describe phast_planner_r2c32_describe
 phast_twiddle_grid64_new phast_twiddle_grid32_new phast_twiddle_grid64_free phast_twiddle_grid32_free
 phast_twiddle_grid64_apply_dev phast_twiddle_grid32_apply_dev
@@ -76,6 +77,8 @@ def lib() -> C.CDLL:
     l.phast_options_default.restype = None
     l.phast_debug_set_wg_per_cu.restype = None
     l.phast_debug_set_trace.restype = None
+    l.phast_debug_set_guard_bytes.restype = None
+    l.phast_debug_set_guard_bytes.argtypes = [C.c_size_t]
     for sfx in ("64", "32"):
         getattr(l, f"phast_planner_dit{sfx}_free").restype = None
         getattr(l, f"phast_planner_r2c{sfx}_free").restype = None

@@ -41,6 +41,13 @@ static PerDeviceInt g_cus_of;  // CU count per device ordinal (device_state.hpp)
 static int g_wg_per_cu_override = 0;           // tuning hook (phast_debug_set_wg_per_cu)
 static unsigned long long *g_trace = nullptr;  // tuning hook (phast_debug_set_trace)
 
+// Debug hook (phast_debug_set_guard_bytes): every scratch / workspace the planners allocate afterwards gets a guard band
+// of this many bytes on either side, filled with 0xA5; phast_planner_*_debug_check_guards counts the bytes a kernel has
+// overwritten.  The device-side half of the sanitizer pass: the boxes run gfx950 with xnack off,
+// so ASan's device instrumentation is not available -- out-of-bounds WRITES of the pass kernels are caught by the bands.
+static size_t g_guard_bytes = 0;
+static constexpr unsigned char kGuardFill = 0xA5;
+
 static int cus_of(int dev) {
     return g_cus_of.get(dev, [&] {
         hipDeviceProp_t prop;
@@ -199,6 +206,7 @@ template <typename T> struct Planner {
     void *d_small_tw = nullptr;
     mutable T *d_scratch = nullptr;  // [cap][2][n]: re plane then im plane per transform
     mutable size_t scratch_cap = 0;
+    mutable size_t scratch_guard = 0;  // bytes of guard band before and after the scratch (debug hook, normally 0)
     mutable size_t reserve = 1;
     mutable std::mutex mu;
     // One transform sequence at a time per planner: the passes of a call share the planner's scratch, so the
@@ -336,7 +344,7 @@ template <typename T> struct Planner {
         DeviceGuard on(device);
         release_passes();
         if (d_small_tw) hipFree(d_small_tw);
-        if (d_scratch) hipFree(d_scratch);
+        if (d_scratch) hipFree(reinterpret_cast<char *>(d_scratch) - scratch_guard);
         if (d_stage) hipFree(d_stage);
         if (h_pin) hipHostFree(h_pin);
         for (const Retired &r : retired) {  // hipFree waits for the device: whatever still used them is done afterwards
@@ -471,16 +479,17 @@ template <typename T> struct Planner {
         if (scratch_cap < want) {
             if (!exact && scratch_cap && want < 2 * scratch_cap) want = std::min(2 * scratch_cap, std::max(target, want));
             const size_t floor_cap = exact ? want : std::max<size_t>(std::max<size_t>(reserve, 1), scratch_cap + 1);
+            const size_t guard = g_guard_bytes;
             void *d = nullptr;
-            hipError_t e = hipMalloc(&d, want * per);
+            hipError_t e = hipMalloc(&d, want * per + 2 * guard);
             if (e == hipErrorOutOfMemory && !capturing(stream)) {
                 (void)hipGetLastError();
                 reap(stream, true);  // whatever retired buffers are idle (or become so) go first
-                e = hipMalloc(&d, want * per);
+                e = hipMalloc(&d, want * per + 2 * guard);
                 while (e == hipErrorOutOfMemory && want > floor_cap) {
                     (void)hipGetLastError();
                     want = std::max(floor_cap, want / 2);
-                    e = hipMalloc(&d, want * per);
+                    e = hipMalloc(&d, want * per + 2 * guard);
                 }
                 if (e == hipErrorOutOfMemory && !exact && scratch_cap >= std::max<size_t>(reserve, 1)) {
                     (void)hipGetLastError();  // cannot grow: keep working in the chunks the present scratch allows
@@ -489,14 +498,38 @@ template <typename T> struct Planner {
                 }
             }
             if (e != hipSuccess) return hip_fail(e, "hipMalloc(scratch)");
-            retire(d_scratch, scratch_cap * per, false);
-            d_scratch = reinterpret_cast<T *>(d);
+            if (guard) {
+                PHAST_HIP(hipMemset(d, kGuardFill, guard));
+                PHAST_HIP(hipMemset(reinterpret_cast<char *>(d) + guard + want * per, kGuardFill, guard));
+            }
+            retire(d_scratch ? reinterpret_cast<char *>(d_scratch) - scratch_guard : nullptr, scratch_cap * per + 2 * scratch_guard, false);
+            d_scratch = reinterpret_cast<T *>(reinterpret_cast<char *>(d) + guard);
+            scratch_guard = guard;
             scratch_cap = want;
         }
         *cap_out = scratch_cap;
         return PHAST_OK;
     }
 
+    // debug: bytes of the scratch's guard bands that no longer hold the fill value (blocks until the device is idle)
+    int check_guards(size_t *bad_out) const {
+        std::lock_guard<std::recursive_mutex> call_lock(call_mu);
+        PHAST_ON_DEVICE(device);
+        size_t bad = 0;
+        if (d_scratch && scratch_guard) {
+            PHAST_HIP(hipDeviceSynchronize());
+            std::vector<unsigned char> h(scratch_guard);
+            const size_t per = 2 * n * sizeof(T);
+            const char *lo = reinterpret_cast<const char *>(d_scratch) - scratch_guard;
+            const char *hi = reinterpret_cast<const char *>(d_scratch) + scratch_cap * per;
+            for (const char *band : {lo, hi}) {
+                PHAST_HIP(hipMemcpy(h.data(), band, scratch_guard, hipMemcpyDeviceToHost));
+                for (unsigned char c : h) bad += c != kGuardFill;
+            }
+        }
+        *bad_out = bad;
+        return PHAST_OK;
+    }
     // live tables and scratch plus what is retired but not yet released
     size_t device_bytes() const { return table_bytes + scratch_cap * 2 * n * sizeof(T) + stage_bytes + retired_dev_bytes; }
 
@@ -1282,6 +1315,8 @@ int phast_hip_graph_upload(void *graph_exec, void *stream) {
     return PHAST_OK;
 }
 
+void phast_debug_set_guard_bytes(size_t bytes) { g_guard_bytes = (bytes + 255) & ~(size_t)255; }
+
 void phast_debug_set_wg_per_cu(int wg_per_cu) { g_wg_per_cu_override = wg_per_cu; }
 void phast_debug_set_trace(unsigned long long *d_trace) { g_trace = d_trace; }
 
@@ -1325,6 +1360,10 @@ int phast_options_guess(size_t input_size, phast_options *out) {
     void phast_planner_dit##SFX##_free(phast_planner_dit##SFX *p) { delete p; }                                    \
     size_t phast_planner_dit##SFX##_device_bytes(const phast_planner_dit##SFX *p) {                                \
         return p ? p->device_bytes() : 0;                                                                          \
+    }                                                                                                              \
+    int phast_planner_dit##SFX##_debug_check_guards(const phast_planner_dit##SFX *p, size_t *bad_bytes) {          \
+        if (!p || !bad_bytes) return PHAST_ERR_INVALID_ARG;                                                        \
+        return p->check_guards(bad_bytes);                                                                         \
     }                                                                                                              \
     int phast_planner_dit##SFX##_describe(const phast_planner_dit##SFX *p, char *buf, size_t len) {                \
         return describe_to<T>(p, buf, len);                                                                        \

@@ -1,0 +1,40 @@
+#!/bin/bash
+# Host-side sanitizer pass: libphastft_hip.so's HOST code (planners, plan
+# tables, staging, buffer retirement, the C ABI) and the C++ host test that replays the reference's tests through it,
+# both under AddressSanitizer (-fsanitize=address -fno-gpu-sanitize: the boxes run gfx950 with xnack off, so the DEVICE
+# half is the guard-band test tests/test_gpu_sanitize.py).  Build here (no GPU needed), run on the GPU box:
+#     tools/sanitize_host.sh build            # -> phastft_amd/lib/libphastft_hip_asan.so + tests/cpp/host_api_test_asan
+#     tools/sanitize_host.sh run > log        # on the GPU box
+set -u
+R=$(cd "$(dirname "$0")/.." && pwd)
+LIB=$R/phastft_amd/lib/libphastft_hip_asan.so
+EXE=$R/tests/cpp/host_api_test_asan
+CLANG=/opt/rocm/lib/llvm/bin/clang++
+case "${1:-run}" in
+build)
+    python3 - <<PY || exit 1
+import subprocess, sys
+sys.path.insert(0, "$R")
+from phastft_amd import build as B
+import os
+os.makedirs(B.OBJ, exist_ok=True)
+flags = ("-fsanitize=address", "-fno-gpu-sanitize", "-g", "-fno-omit-frame-pointer")
+objs = [B._compile(u, False, False, flags, "_asan") for u in B.UNITS]
+r = subprocess.run([B.hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fsanitize=address", "-shared-libsan", "-o", "$LIB", *objs],
+                   capture_output=True, text=True)
+assert r.returncode == 0, r.stderr
+print("$LIB")
+PY
+    RT=$(dirname "$($CLANG -print-file-name=libclang_rt.asan-x86_64.so)")
+    $CLANG -std=c++17 -O1 -g -fsanitize=address -shared-libsan -fno-omit-frame-pointer -I "$R/include" "$R/tests/cpp/host_api_test.cpp" \
+        -o "$EXE" "$LIB" -Wl,-rpath,"$R/phastft_amd/lib" -Wl,-rpath,/opt/rocm/lib -Wl,-rpath,"$RT" || exit 1
+    echo "$EXE"
+    ;;
+run)
+    echo "# $(date -u) host-side ASan pass: $EXE gpu"
+    export ASAN_OPTIONS=detect_leaks=1:halt_on_error=0:abort_on_error=0
+    export LSAN_OPTIONS=suppressions=$R/tools/lsan.supp:print_suppressions=0
+    "$EXE" gpu
+    echo "# exit code $?"
+    ;;
+esac
