@@ -426,10 +426,10 @@ def shard_on_one_gpu(P, torch, dev, shard: int, steps: int = 5):
     used = plan_kind(P, N, shard, plan_text)
     roof, dom = roofline_of(pass_ms, BYTES_PER_SAMPLE * N * shard, plan_used=f"{used} plan {plan_of(plan_text, used)}")
     tags = kernel_tags(plan_of(plan_text, used))
-    tr = traffic_for("batch_2p20", [tags[dom]], scale=shard / 256.0) if dom < len(tags) else None  # profiled per 256-transform launch
+    tr = traffic_for("batch_2p20", [tags[dom]], scale=shard / 1024.0) if dom < len(tags) else None  # profiled per 1024-transform launch
     if tr:
         roof.update(tr)
-        roof["traffic_note"] = "PMC bytes of one 256-transform launch of the same kernel, scaled to the shard"
+        roof["traffic_note"] = "PMC bytes of one 1024-transform launch of the same kernel (scaled to the shard if it differs)"
     return {"workload": f"{shard} independent f64 forward FFTs N=2^{LOG_N} on 1 GPU, in place (one rank's shard of "
                         f"BASELINE configs[4])", "value": shard * N / (ms * 1e-3) / 1e9, "unit": "GSamples/s",
             "steps": steps, "ms_per_step": ms, "roofline": roof}
@@ -633,9 +633,9 @@ def main():
                                                  "sampled transforms vs digests of the CPU oracle's output; rank 0's numbers")
         traffic = load_profiled_traffic(2 if multi else 1, dom, len(pass_ms), kernel_tags(plan_list))
         if traffic is not None:
-            if multi:  # profiled per 256-transform launch; kernel_ms / algorithmic bytes here are per pass over the shard
-                traffic["traffic"] *= units / 256.0
-                traffic["traffic_note"] = "PMC bytes of one 256-transform launch scaled to the shard"
+            if multi:  # profiled per 1024-transform launch; kernel_ms / algorithmic bytes here are per pass over the shard
+                traffic["traffic"] *= units / 1024.0
+                traffic["traffic_note"] = "PMC bytes of one 1024-transform launch scaled to the shard"
             roofline.update(traffic)
         if not multi:
             probe = hbm_copy_probe(torch, dev)

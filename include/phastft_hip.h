@@ -132,7 +132,10 @@ int phast_fft_32_dit_dev(float *d_reals, float *d_imags, size_t n, size_t batch,
  * stride == 1 is the call above.  dist == 1 with stride, batch powers of two, batch <= stride, n >= 64 are the
  * "column FFTs" of a row-major [n][stride] array (first `batch` columns), in place, natural order in and out -- what
  * a four-step split (phastft_amd/distributed.py) and multi-dimensional transforms need.  The planner's scratch grows
- * to n*stride elements per plane.  Anything else returns PHAST_ERR_INVALID_ARG. */
+ * to n*stride elements per plane.  The kernels work on tiles of adjacent columns: batch >= 16 is always served,
+ * batch == 8 for every n except 2^6, 2^12 and 2^13, batch == 4 only for n = 2^10 and 2^20, narrower batches never --
+ * those (and anything else outside the description above) return PHAST_ERR_INVALID_ARG and nothing has run: transpose
+ * and use the contiguous batch (phastft_amd/distributed.py does, and falls back on THAT code only). */
 int phast_fft_64_dit_strided_dev(double *d_reals, double *d_imags, size_t n, size_t batch, size_t dist, size_t stride,
                                  int direction, const phast_planner_dit64 *planner, void *stream);
 int phast_fft_32_dit_strided_dev(float *d_reals, float *d_imags, size_t n, size_t batch, size_t dist, size_t stride,

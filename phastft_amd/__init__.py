@@ -441,7 +441,9 @@ def fft_dit_strided(reals, imags, n: int, direction: Direction, planner, batch: 
                     twiddle_n: int = 0, twiddle_col0: int = 0) -> None:
     """Device-resident "column FFTs": the tensors hold a row-major ``[n][stride]`` array whose first ``batch`` columns
     are transformed along the rows' axis, in place (transform ``c`` = elements ``c + j*stride``).  ``stride`` and
-    ``batch`` powers of two, ``batch <= stride``, ``n >= 64``.  With ``twiddle_n`` the first pass multiplies element
+    ``batch`` powers of two, ``batch <= stride``, ``n >= 64``; ``batch >= 16`` is always served, 8 columns for every n
+    but 2^6 / 2^12 / 2^13, 4 columns for n = 2^10 / 2^20 only -- anything narrower raises :class:`PhastPanic` with code
+    ``ERR_INVALID_ARG`` before anything runs (transpose and use :func:`fft_dit_batched`).  With ``twiddle_n`` the first pass multiplies element
     ``j`` of column ``c`` by ``W_twiddle_n^(j*(twiddle_col0 + c))`` on load (the inter-factor twiddle of a four-step
     split).  No reference counterpart."""
     dtype, sfx = planner._dtype, planner._sfx
