@@ -50,8 +50,11 @@ def test_wave_and_quad_kernels_keep_four_waves_per_simd(resources):
         if "wave_fft_kernel" in k or "quad_fft_kernel" in k:
             seen += 1
             assert v["scratch"] == 0 and v["vgpr_spill"] == 0, (k, v)
-            assert v["vgprs"] <= 128 and v["occupancy"] >= 4, (k, v)
-    assert seen >= 3
+            if "IfLb" in k:  # the f32 wave tiles hold 32 points per lane (built and parity-tested, not in a default plan)
+                assert v["vgprs"] <= 160, (k, v)
+            else:
+                assert v["vgprs"] <= 128 and v["occupancy"] >= 4, (k, v)
+    assert seen >= 5
 
 
 def test_widest_pass_kernels_do_not_spill(resources):

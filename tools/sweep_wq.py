@@ -8,11 +8,16 @@ import torch  # noqa: E402
 
 import phastft_amd as P  # noqa: E402
 
-CASES = {19: [((6, 7, 6), (10, 11, 10), 3 | 16), ((7, 6, 6), (11, 10, 10), 3 | 16)],
+CASES = {20: [((8, 6, 6), (12, 10, 10), 3 | 16), ((8, 6, 6), (12, 10, 10), 4 | 16), ((6, 8, 6), (10, 12, 10), 3 | 16), ((7, 7, 6), (11, 11, 10), 3 | 16),
+              ((7, 6, 7), (11, 10, 11), 3 | 16), ((6, 7, 7), (10, 11, 11), 3 | 16), ((6, 7, 7), (10, 11, 11), 4 | 16), ((7, 7, 6), (11, 11, 10), 4 | 16)],
+         19: [((6, 7, 6), (10, 11, 10), 3 | 16), ((7, 6, 6), (11, 10, 10), 3 | 16)],
          21: [((7, 8, 6), (11, 12, 10), 3 | 16), ((8, 7, 6), (12, 11, 10), 3 | 16), ((7, 8, 6), (12, 12, 10), 3 | 16), ((8, 7, 6), (12, 12, 10), 3 | 16)],
          22: [((8, 8, 6), (12, 12, 10), 3 | 16), ((8, 8, 6), (13, 12, 10), 4 | 16)],
          23: [((8, 8, 7), (12, 12, 11), 3 | 16), ((8, 8, 7), (12, 12, 12), 3 | 16), ((7, 8, 8), (12, 12, 12), 3 | 16), ((8, 7, 8), (12, 12, 12), 3 | 16)]}
+ONLY = [int(a) for a in sys.argv[1:]]
 for L, plans in CASES.items():
+    if ONLY and L not in ONLY:
+        continue
     n = 1 << L
     ring = max(4, min(40, (1 << 30) // (16 * n)))
     re = torch.empty(ring * n, dtype=torch.float64, device="cuda")
