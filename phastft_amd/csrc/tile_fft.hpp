@@ -165,6 +165,13 @@ template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool 
     // per pass, and the strided-copy microbenchmark gains 5-10 % (profiles/r01_strided_copy_nt.log).  Narrower
     // rows share their line with the neighbouring tile and NEED the L2 (nt loads cost 25 % there).
     static constexpr bool NT_HINT = COLS * sizeof(T) >= 128;
+#ifndef PHAST_TILE_NT_LOADS  // tools only: the two halves of the hint separately (profiles/r03_nt_halves.log)
+#define PHAST_TILE_NT_LOADS 1
+#endif
+#ifndef PHAST_TILE_NT_STORES
+#define PHAST_TILE_NT_STORES 1
+#endif
+    static constexpr bool NT_LD = NT_HINT && PHAST_TILE_NT_LOADS, NT_ST = NT_HINT && PHAST_TILE_NT_STORES;
     static_assert(LR >= 1 && LR <= 13, "tile FFT length 2..8192 (the multi-pass plans use 64..1024)");
     static_assert(LP >= 1 && LP <= 5 && LP <= LR, "2..32 points per thread");
     static_assert(NT <= 1024 && NT >= 64, "64..1024 threads per workgroup");
@@ -244,7 +251,7 @@ template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool 
 #else
                 const size_t urow = (size_t)(decltype(j)::value * M) << a.log_s_in;
 #endif
-                if constexpr (NT_HINT) {
+                if constexpr (NT_LD) {
                     r.re[j] = __builtin_nontemporal_load(pr + urow + voff);
                     r.im[j] = __builtin_nontemporal_load(pi + urow + voff);
                 } else {
@@ -408,7 +415,7 @@ template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool 
     PHAST_HD static void put(const TileArgs &a, size_t ubase, unsigned voff, T re, T im) {
         const T scale = (T)a.scale;
         if (TRANSPOSE || !a.out_interleaved) {
-            if constexpr (NT_HINT) {
+            if constexpr (NT_ST) {
                 __builtin_nontemporal_store(re * scale, reinterpret_cast<T *>(a.out_re) + ubase + voff);
                 __builtin_nontemporal_store(im * scale, reinterpret_cast<T *>(a.out_im) + ubase + voff);
             } else {
