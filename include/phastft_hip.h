@@ -128,6 +128,13 @@ int phast_fft_64_dit_dev(double *d_reals, double *d_imags, size_t n, size_t batc
                          const phast_planner_dit64 *planner, void *stream);
 int phast_fft_32_dit_dev(float *d_reals, float *d_imags, size_t n, size_t batch, size_t dist, int direction,
                          const phast_planner_dit32 *planner, void *stream);
+/* `count` independent transforms of n points at arbitrary device addresses (HOST arrays of device pointers), each run
+ * exactly as a single-transform call, enqueued back to back by ONE host call -- a caller with many separate signals
+ * (the Rust API takes one pair of slices per call, lib.rs:143) pays its FFI / interpreter overhead once. */
+int phast_fft_64_dit_many_dev(double *const *d_reals, double *const *d_imags, size_t count, size_t n, int direction,
+                              const phast_planner_dit64 *planner, void *stream);
+int phast_fft_32_dit_many_dev(float *const *d_reals, float *const *d_imags, size_t count, size_t n, int direction,
+                              const phast_planner_dit32 *planner, void *stream);
 /* Strided batches (no reference counterpart): transform b occupies elements b*dist + j*stride, j < n.
  * stride == 1 is the call above.  dist == 1 with stride, batch powers of two, batch <= stride, n >= 64 are the
  * "column FFTs" of a row-major [n][stride] array (first `batch` columns), in place, natural order in and out -- what

@@ -437,6 +437,31 @@ def fft_dit_batched(reals, imags, n: int, direction: Direction, planner, dist: i
                                                            _stream()))
 
 
+class TransformList:
+    """`count` independent transforms at arbitrary device addresses, prepared once (the pointer arrays) and enqueued by
+    ONE call into the library -- each runs exactly as a single-transform call (``phast_fft_*_dit_many_dev``)."""
+
+    def __init__(self, pairs, n: int, planner):
+        dtype = planner._dtype
+        self._keep = [(_Slice(r, dtype, "reals"), _Slice(m, dtype, "imags")) for r, m in pairs]
+        for r, m in self._keep:
+            if not (r.dev and m.dev) or r.len != n or m.len != n:
+                raise TypeError("TransformList needs device tensors of n elements each")
+        k = len(self._keep)
+        self._re = (C.c_void_p * k)(*[r.ptr.value for r, _ in self._keep])
+        self._im = (C.c_void_p * k)(*[m.ptr.value for _, m in self._keep])
+        self.n, self.count, self.planner = n, k, planner
+
+    def run(self, direction: Direction, first: int = 0, count: int | None = None) -> None:
+        k = self.count - first if count is None else count
+        if first < 0 or k < 0 or first + k > self.count:
+            raise ValueError("range outside the list")
+        off = first * C.sizeof(C.c_void_p)
+        _check(getattr(_lib.lib(), f"phast_fft_{self.planner._sfx}_dit_many_dev")(
+            C.c_void_p(C.addressof(self._re) + off), C.c_void_p(C.addressof(self._im) + off), C.c_size_t(k),
+            C.c_size_t(self.n), C.c_int(int(direction)), self.planner._h, _stream()))
+
+
 def fft_dit_strided(reals, imags, n: int, direction: Direction, planner, batch: int, stride: int,
                     twiddle_n: int = 0, twiddle_col0: int = 0) -> None:
     """Device-resident "column FFTs": the tensors hold a row-major ``[n][stride]`` array whose first ``batch`` columns

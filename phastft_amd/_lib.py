@@ -22,7 +22,7 @@ phast_planner_dit64_reserve_batch phast_planner_dit32_reserve_batch
 phast_planner_r2c64_new phast_planner_r2c64_free phast_planner_r2c32_new phast_planner_r2c32_free
 phast_fft_64_dit phast_fft_32_dit phast_fft_64_dit_with_planner phast_fft_32_dit_with_planner
 phast_fft_64_dit_with_planner_and_opts phast_fft_32_dit_with_planner_and_opts
-phast_fft_64_dit_dev phast_fft_32_dit_dev phast_fft_64_dit_strided_dev phast_fft_32_dit_strided_dev phast_fft_64_dit_strided_tw_dev phast_fft_32_dit_strided_tw_dev
+phast_fft_64_dit_dev phast_fft_32_dit_dev phast_fft_64_dit_many_dev phast_fft_32_dit_many_dev phast_fft_64_dit_strided_dev phast_fft_32_dit_strided_dev phast_fft_64_dit_strided_tw_dev phast_fft_32_dit_strided_tw_dev
 phast_fft_64_interleaved phast_fft_32_interleaved phast_fft_64_interleaved_with_planner
 phast_fft_32_interleaved_with_planner phast_fft_64_interleaved_with_planner_and_opts
 phast_fft_32_interleaved_with_planner_and_opts phast_fft_64_interleaved_dev phast_fft_32_interleaved_dev

@@ -940,6 +940,21 @@ static int fft_dev(T *d_re, T *d_im, size_t n, size_t batch, size_t dist, int di
     return pl->exec(d_re, d_im, dist, 0, d_re, d_im, dist, 0, batch, 1.0, s);
 }
 
+// `count` independent transforms at arbitrary addresses, each run exactly as a single-transform call (the plan for ONE
+// transform), enqueued back to back by one host call: the host-side cost per transform drops to the kernel launches
+// themselves (a Python / FFI caller pays its call overhead once).
+template <typename T>
+static int fft_dev_many(T *const *d_re, T *const *d_im, size_t count, size_t n, int direction, const Planner<T> *pl,
+                        hipStream_t s) {
+    if (!pl || (!d_re && count) || (!d_im && count)) return PHAST_ERR_INVALID_ARG;
+    std::lock_guard<std::recursive_mutex> call_lock(pl->call_mu);
+    for (size_t i = 0; i < count; ++i) {
+        int rc = fft_dev<T>(d_re[i], d_im[i], n, 1, n, direction, pl, s);
+        if (rc) return rc;
+    }
+    return PHAST_OK;
+}
+
 // Strided batches on device pointers: transform b occupies elements b*dist + j*stride, j < n.
 //   stride == 1: contiguous transforms `dist` apart (the plain batched path above);
 //   dist == 1:   "column FFTs" of a row-major [n][stride] array -- stride and batch powers of two, batch <= stride,
@@ -1418,6 +1433,10 @@ PHAST_PLANNER_API(32, float)
     int phast_fft_##SFX##_dit_dev(T *d_re, T *d_im, size_t n, size_t batch, size_t dist, int direction,             \
                                   const phast_planner_dit##SFX *pl, void *stream) {                                 \
         return fft_dev<T>(d_re, d_im, n, batch, dist, direction, pl, static_cast<hipStream_t>(stream));             \
+    }                                                                                                               \
+    int phast_fft_##SFX##_dit_many_dev(T *const *d_re, T *const *d_im, size_t count, size_t n, int direction,       \
+                                       const phast_planner_dit##SFX *pl, void *stream) {                            \
+        return fft_dev_many<T>(d_re, d_im, count, n, direction, pl, static_cast<hipStream_t>(stream));              \
     }                                                                                                               \
     int phast_fft_##SFX##_dit_strided_dev(T *d_re, T *d_im, size_t n, size_t batch, size_t dist, size_t stride,     \
                                           int direction, const phast_planner_dit##SFX *pl, void *stream) {          \

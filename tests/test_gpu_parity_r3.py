@@ -379,3 +379,88 @@ def test_f32_wave_tiles_all_passes_batched_inverse_and_interleaved(gpu, oracle):
     gpu.fft_32_dit_with_planner(d_re, d_im, gpu.Direction.Forward, planner)
     oracle.fft_32_dit(r, m, oracle.FORWARD)
     assert rel_l2(d_re.cpu().numpy(), d_im.cpu().numpy(), r, m) <= F32_REL
+
+
+def test_transform_list_one_call_many_single_transforms(gpu, oracle):
+    """phast_fft_*_dit_many_dev: `count` separate signals enqueued by one call, each run as a single-transform call --
+    bit-identical to calling fft_64_dit_with_planner on each of them (same plan, same kernels)."""
+    import torch
+
+    n, k = 1 << 20, 5
+    planner = gpu.PlannerDit64(n)
+    pairs, singles = [], []
+    for i in range(k):
+        r, m = oracle.fill(n, np.float64, seed=0xAB, transform_id=i)
+        pairs.append((dev(r.copy()), dev(m.copy())))
+        singles.append((dev(r.copy()), dev(m.copy())))
+    tl = gpu.TransformList(pairs, n, planner)
+    tl.run(gpu.Direction.Forward)
+    for a, b in singles:
+        gpu.fft_64_dit_with_planner(a, b, gpu.Direction.Forward, planner)
+    for (a, b), (c, d) in zip(pairs, singles):
+        assert torch.equal(a, c) and torch.equal(b, d)
+    r, m = oracle.fill(n, np.float64, seed=0xAB, transform_id=k - 1)
+    oracle.fft_64_dit(r, m, oracle.FORWARD)
+    assert rel_l2(pairs[-1][0].cpu().numpy(), pairs[-1][1].cpu().numpy(), r, m) <= F64_REL
+    tl.run(gpu.Direction.Reverse, 1, 2)  # a sub-range: transforms 1 and 2 go back to their inputs
+    r1, _ = oracle.fill(n, np.float64, seed=0xAB, transform_id=1)
+    assert float(np.max(np.abs(pairs[1][0].cpu().numpy() - r1))) < 1e-12
+    assert torch.equal(pairs[3][0], singles[3][0])  # untouched by the sub-range call
+    with pytest.raises(ValueError):
+        tl.run(gpu.Direction.Forward, 4, 3)
+
+
+def test_every_dev_entry_point_is_capture_safe(gpu, oracle):
+    """The _dev entry points issue nothing but kernel launches once their buffers exist (no allocation, no
+    synchronisation, no attribute call): a sequence of C2C (single / batched / strided / interleaved), R2C, C2R and bit
+    reversal is captured into ONE HIP graph after a warm-up call each, replayed twice, and the results equal the eager
+    ones bit for bit."""
+    import torch
+
+    n = 1 << 16
+    p64, p32, r64, p10 = gpu.PlannerDit64(n), gpu.PlannerDit32(n), gpu.PlannerR2c64(n), gpu.PlannerDit64(1 << 10)
+    h_re, h_im = oracle.fill(4 * n, np.float64, seed=5, transform_id=0)
+    bufs = {}
+
+    def fresh():
+        bufs["re"], bufs["im"] = dev(h_re.copy()), dev(h_im.copy())
+        bufs["re32"], bufs["im32"] = dev(h_re.astype(np.float32)), dev(h_im.astype(np.float32))
+        bufs["z"] = torch.view_as_complex(torch.stack([bufs["re"][:n], bufs["im"][:n]], dim=1).contiguous())
+        bufs["x"] = dev(h_re[:n].copy())
+        bufs["a"] = torch.zeros(n // 2 + 1, dtype=torch.float64, device="cuda")
+        bufs["b"] = torch.zeros_like(bufs["a"])
+        bufs["y"] = torch.zeros(n, dtype=torch.float64, device="cuda")
+        bufs["v"] = dev(h_im[:n].copy())
+        bufs["sre"], bufs["sim"] = dev(h_re[:16384].copy()), dev(h_im[:16384].copy())
+
+    def work():
+        b = bufs
+        gpu.fft_64_dit_with_planner(b["re"][:n], b["im"][:n], gpu.Direction.Forward, p64)
+        gpu.fft_dit_batched(b["re"], b["im"], n, gpu.Direction.Forward, p64)
+        gpu.fft_dit_batched(b["re32"], b["im32"], n, gpu.Direction.Reverse, p32)
+        gpu.fft_dit_strided(b["sre"], b["sim"], 1 << 10, gpu.Direction.Forward, p10, batch=16, stride=16)
+        gpu.fft_64_interleaved_with_planner(b["z"], gpu.Direction.Forward, p64)
+        gpu.r2c_fft_f64_with_planner(b["x"], b["a"], b["b"], r64)
+        gpu.c2r_fft_f64_with_planner(b["a"], b["b"], b["y"], r64)
+        gpu.bit_rev_bravo_f64(b["v"], 16)
+
+    fresh()
+    work()  # eager: allocates every scratch / workspace, raises every LDS limit
+    torch.cuda.synchronize()
+    eager = {k: v.clone() for k, v in bufs.items()}
+    fresh()
+    keep = dict(bufs)  # the graph refers to THESE buffers
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            work()
+    torch.cuda.current_stream().wait_stream(side)
+    g.replay()
+    torch.cuda.synchronize()
+    for k in eager:
+        got, want = keep[k], eager[k]
+        if got.is_complex():
+            got, want = torch.view_as_real(got), torch.view_as_real(want)
+        assert torch.equal(got, want), k

@@ -37,6 +37,19 @@ with torch.cuda.stream(side):
     step(0)
 torch.cuda.synchronize()
 
+tl = P.TransformList(views, N, planner)
+for steps in (20, 200):
+    res = []
+    for rep in range(7):
+        P.fill_uniform(re, im, N)
+        tl.run(P.Direction.Forward, 5, steps)  # warm
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        tl.run(P.Direction.Forward, 5, steps)
+        torch.cuda.synchronize()
+        res.append((time.perf_counter() - t0) / steps * 1e6)
+    res.sort()
+    print(f"K={steps:4d} eager-C: us/step min {res[0]:.2f} median {res[len(res)//2]:.2f} max {res[-1]:.2f}  (one call into the library enqueues the K transforms)", flush=True)
 for steps in (20, 200):
     for mode in ("cold", "upload", "warm"):
         res = []
