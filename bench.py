@@ -467,6 +467,9 @@ def check_shard(P, torch, re, im, refill, step, first: int, shard: int, samples:
 
 def main():
     args = parse()
+    # the host driver of this pool only supports dmabuf IPC: without this RCCL / device-tensor sharing across the ranks
+    # fails with `hipIpcGetMemHandle: invalid argument` (already exported on the boxes; kept here for any other launcher)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
