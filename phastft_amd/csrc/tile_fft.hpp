@@ -523,6 +523,9 @@ __global__ void __launch_bounds__(1 << (LR + LC - LP), PHAST_MIN_WAVES(LR, LC)) 
     // the first tile's global loads are issued before the table loads so the two latencies overlap
     typename Body::Regs r;
     unsigned t = blockIdx.x;
+#ifdef PHAST_TILE_STAGGER  // tools only: the workgroups' first loads PHAST_TILE_STAGGER x 64 cycles apart, 8 groups
+    for (unsigned k = ((blockIdx.x >> 3) & 7u) * PHAST_TILE_STAGGER; k > 0; --k) __builtin_amdgcn_s_sleep(1);
+#endif
     if (t < a.tiles_total) {
         Body::locate(a, t, r);
         Body::load_raw(a, tid, r);
