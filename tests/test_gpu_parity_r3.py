@@ -464,3 +464,55 @@ def test_every_dev_entry_point_is_capture_safe(gpu, oracle):
         if got.is_complex():
             got, want = torch.view_as_real(got), torch.view_as_real(want)
         assert torch.equal(got, want), k
+
+
+_FIRST_LAUNCH_RACE = r"""
+import sys, threading
+import numpy as np
+import torch
+sys.path.insert(0, sys.argv[1])
+import phastft_amd as P
+from oracle import oracle as O
+
+torch.cuda.set_device(0)
+torch.zeros(1, device="cuda")
+errs, lock, start = [], threading.Lock(), threading.Barrier(8)
+
+def work(i):
+    # every thread: its own planner(s) and stream, the FIRST launches of this process -- the dynamic-LDS limits of the
+    # kernels are raised concurrently (ADVICE r02: unsynchronised statics let one thread launch before the raise)
+    k = (14, 16, 18, 20)[i % 4]
+    n = 1 << k
+    h_re, h_im = O.fill(n, np.float64, seed=7, transform_id=i)
+    s = torch.cuda.Stream()
+    start.wait()
+    with torch.cuda.stream(s):
+        pl = P.PlannerDit64(n)
+        re, im = torch.from_numpy(h_re.copy()).cuda(), torch.from_numpy(h_im.copy()).cuda()
+        for _ in range(3):
+            P.fft_64_dit_with_planner(re, im, P.Direction.Forward, pl)
+            P.fft_64_dit_with_planner(re, im, P.Direction.Reverse, pl)
+        P.fft_64_dit_with_planner(re, im, P.Direction.Forward, pl)
+        s.synchronize()
+    O.fft_64_dit(h_re, h_im, O.FORWARD)
+    e = float(np.sqrt(np.sum((re.cpu().numpy() - h_re) ** 2 + (im.cpu().numpy() - h_im) ** 2) / np.sum(h_re ** 2 + h_im ** 2)))
+    with lock:
+        errs.append(e)
+
+ts = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+[t.start() for t in ts]
+[t.join() for t in ts]
+assert len(errs) == 8 and max(errs) < 1e-12, errs
+print("RACE_OK", max(errs))
+"""
+
+
+def test_first_launches_of_eight_host_threads_race_free(gpu, tmp_path):
+    """Eight host threads, each with its own planner and stream, issue the FIRST launches of a fresh process at the same
+    moment (a barrier releases them): the per-kernel dynamic-LDS limits are raised under a lock per instantiation
+    (device_state.hpp), so no thread can launch before the raise; planners of different threads share nothing and run
+    concurrently on their streams.  Results against the oracle."""
+    script = tmp_path / "race.py"
+    script.write_text(_FIRST_LAUNCH_RACE)
+    r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RACE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
