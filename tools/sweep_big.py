@@ -9,7 +9,9 @@ for L in [int(x) for x in sys.argv[1:]] or [28]:
     n = 1 << L
     re = torch.empty(n, dtype=torch.float64, device="cuda"); im = torch.empty_like(re)
     plans = [((), 0, 0)]
-    for lrs in ((10, 9, 9), (9, 10, 9), (9, 9, 10), (10, 10, 8), (10, 8, 10), (8, 10, 10), (9, 9, 9, ), (10, 10, 7), (10, 9, 8)):
+    for lrs in ((10, 9, 9), (9, 10, 9), (9, 9, 10), (10, 10, 8), (10, 8, 10), (8, 10, 10), (9, 9, 9, ), (10, 10, 7), (10, 9, 8),
+                (9, 9, 8), (9, 8, 9), (8, 9, 9), (8, 10, 8), (10, 8, 8), (8, 8, 10), (9, 10, 7), (7, 10, 9), (10, 6, 10), (9, 7, 10), (10, 7, 9),
+                (8, 8, 8), (9, 8, 8), (8, 9, 8), (8, 8, 9), (9, 9, 7), (9, 7, 9), (7, 9, 9)):
         if sum(lrs) != L:
             continue
         for tl, lp in ((14, 5), (13, 4), (13, 5)):
