@@ -207,6 +207,10 @@ template <typename T> struct Planner {
     mutable T *d_scratch = nullptr;  // [cap][2][n]: re plane then im plane per transform
     mutable size_t scratch_cap = 0;
     mutable size_t scratch_guard = 0;  // bytes of guard band before and after the scratch (debug hook, normally 0)
+    // elements per transform and plane in the scratch: n plus the padding of the intermediate layouts (plan.hpp:
+    // scratch_pad_bytes); the largest over this planner's plans, fixed before the first allocation grows past it
+    size_t scratch_stride = 0;
+    size_t sstride() const { return scratch_stride ? scratch_stride : n; }
     mutable size_t reserve = 1;
     mutable std::mutex mu;
     // One transform sequence at a time per planner: the passes of a call share the planner's scratch, so the
@@ -390,6 +394,7 @@ template <typename T> struct Planner {
             int rc = prepare_passes(ps, &tb);
             if (rc) return rc;
         }
+        const size_t need = (size_t)scratch_elems(geo, log_n);
         // exec() reads the pass vectors while holding call_mu: take it, so a plan is never swapped under a launch
         // sequence; kernels already enqueued keep reading the old tables, which are therefore retired, not freed
         std::lock_guard<std::recursive_mutex> call_lock(call_mu);
@@ -413,6 +418,16 @@ template <typename T> struct Planner {
             }
         }
         table_bytes = tb;
+        if (need > sstride()) {  // a plan with wider pitches than the scratch was cut for: the scratch is re-cut on next use
+            const size_t old_per = 2 * sstride() * sizeof(T);
+            scratch_stride = need;
+            if (d_scratch) {
+                retire(reinterpret_cast<char *>(d_scratch) - scratch_guard, scratch_cap * old_per + 2 * scratch_guard, false);
+                d_scratch = nullptr;
+                scratch_cap = 0;
+                scratch_guard = 0;
+            }
+        }
         return PHAST_OK;
     }
 
@@ -469,7 +484,7 @@ template <typename T> struct Planner {
         }
         std::lock_guard<std::mutex> lk(mu);
         reap(stream);
-        const size_t per = 2 * n * sizeof(T);
+        const size_t per = 2 * sstride() * sizeof(T);
         size_t target = scratch_target_bytes() / per;
         if (target < 1) target = 1;
         if (target < reserve) target = reserve;
@@ -519,7 +534,7 @@ template <typename T> struct Planner {
         if (d_scratch && scratch_guard) {
             PHAST_HIP(hipDeviceSynchronize());
             std::vector<unsigned char> h(scratch_guard);
-            const size_t per = 2 * n * sizeof(T);
+            const size_t per = 2 * sstride() * sizeof(T);
             const char *lo = reinterpret_cast<const char *>(d_scratch) - scratch_guard;
             const char *hi = reinterpret_cast<const char *>(d_scratch) + scratch_cap * per;
             for (const char *band : {lo, hi}) {
@@ -531,7 +546,7 @@ template <typename T> struct Planner {
         return PHAST_OK;
     }
     // live tables and scratch plus what is retired but not yet released
-    size_t device_bytes() const { return table_bytes + scratch_cap * 2 * n * sizeof(T) + stage_bytes + retired_dev_bytes; }
+    size_t device_bytes() const { return table_bytes + scratch_cap * 2 * sstride() * sizeof(T) + stage_bytes + retired_dev_bytes; }
 
     // tables + launch parameters of a pass list (shared by set_plan and the strided plans)
     int prepare_passes(std::vector<PassDesc> &ps, size_t *table_bytes_out) const {
@@ -724,8 +739,9 @@ template <typename T> struct Planner {
         int rc = ensure_scratch(batch, &cap, false, stream);
         if (rc) return rc;
         last_stream = stream;
+        const size_t sd = sstride();       // elements per transform and plane in the (padded) scratch
         T *s_re = d_scratch;               // plane layout: all re planes, then all im planes
-        T *s_im = d_scratch + cap * n;
+        T *s_im = d_scratch + cap * sd;
         const std::vector<PassDesc> &passes = plan_for(batch);
         const size_t np = passes.size();
         for (size_t b0 = 0; b0 < batch; b0 += cap) {
@@ -743,7 +759,7 @@ template <typename T> struct Planner {
                 } else {
                     ta.in_re = s_re;
                     ta.in_im = s_im;
-                    ta.in_dist = n;
+                    ta.in_dist = sd;
                 }
                 if (last) {
                     const size_t osz = out_mode ? 2 * sizeof(T) : sizeof(T);
@@ -755,7 +771,7 @@ template <typename T> struct Planner {
                 } else {
                     ta.out_re = s_re;
                     ta.out_im = s_im;
-                    ta.out_dist = n;
+                    ta.out_dist = sd;
                     ta.scale = 1.0;
                 }
                 ta.tw3 = p.d_tw3;

@@ -122,10 +122,14 @@ __host__ __device__ inline double uniform_pm1(unsigned long long seed, unsigned 
 
 // ---- launch arguments of one tiled FFT pass (tile_fft.hpp) ----
 // A pass does ROWS-point FFTs along a strided axis of a 2^L array, COLS adjacent columns per tile.
-//   input  element (row n, column g): in  + xform*in_dist  + in_col(g)  + n*2^log_s_in
+//   input  element (row n, column g): in  + xform*in_dist  + in_col(g)  + n*in_row_stride
 //   output element (row k, column g): out + xform*out_dist + out_col(g) + k*out_row_stride
-//   in_col(g)  = ((g >> log_s_in) << (log_s_in + LR)) | (g & (2^log_s_in - 1))
+//   in_col(g)  = (g >> log_s_in) * in_hi_stride + ((g >> in_lo_bits) & (2^(log_s_in - in_lo_bits) - 1)) * in_mid_stride
+//                + (g & (2^in_lo_bits - 1))
 //   out_col(g) = (g & (2^out_lo_bits - 1)) * out_s1 + (g >> out_lo_bits) * out_s2
+// In the caller's arrays every stride is a power of two (in_row_stride = 2^log_s_in, in_hi_stride = 2^(log_s_in + LR), no
+// middle part).  In the planner's SCRATCH the strides are padded (plan.hpp: scratch_pad_bytes): rows a power of two apart
+// land on the same HBM channels, and a 128-byte pad per row is worth 5-10 % of a pass (profiles/r03_pad_stride_probe.log).
 struct TileArgs {
     const void *in_re;
     const void *in_im;   // unused when in_interleaved
@@ -135,12 +139,16 @@ struct TileArgs {
     const void *twr;     // [2][32] complex: W_ROWS^e two-level (e = e1*32 + e0)
     unsigned long long in_dist;
     unsigned long long out_dist;
+    unsigned long long in_row_stride;  // elements between consecutive rows of the input
+    unsigned long long in_hi_stride;   // weight of the column bits at and above log_s_in
+    unsigned long long in_mid_stride;  // weight of the column bits [in_lo_bits, log_s_in) (0 bits wide unless padded)
     unsigned long long out_s1;
     unsigned long long out_s2;
     unsigned long long out_row_stride;
     unsigned tiles_per_xform;
     unsigned tiles_total;
     unsigned log_s_in;
+    unsigned in_lo_bits;       // contiguous low column bits of the input (= log_s_in unless the layout is padded)
     unsigned out_lo_bits;
     unsigned tw_bits;
     unsigned in_interleaved;   // 1: input is one array of (re, im) pairs (R2C deinterleave fused into the load); 2: read as (im, re)
@@ -164,6 +172,14 @@ struct TileArgs {
     unsigned long long *trace; // tools/trace_tile.py only: [workgroup][16] s_memtime stamps of the first tile's phases
 };
 
+// input side of a tile whose first column is g0 (the tile's COLS columns are adjacent low bits): element offset of
+// (row 0, column g0) of transform `xform`
+PHAST_HD size_t in_tile_base(const TileArgs &a, unsigned xform, unsigned g0) {
+    const unsigned lo = g0 & ((1u << a.in_lo_bits) - 1u);
+    const unsigned mid = (g0 >> a.in_lo_bits) & ((1u << (a.log_s_in - a.in_lo_bits)) - 1u);
+    return (size_t)xform * a.in_dist + (size_t)(g0 >> a.log_s_in) * a.in_hi_stride + (size_t)mid * a.in_mid_stride + lo;
+}
+
 // Kernel arguments are fetched with scalar loads where the compiler first needs them -- behind every branch of a kernel's
 // prologue another round trip to the kernarg segment before the first global load can be issued (three of them in the
 // wave-tile kernel: 1.4 us of a 7 us pass).  Naming every field as an input of an empty asm statement at kernel entry
@@ -171,7 +187,8 @@ struct TileArgs {
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ void pin_tile_args(const TileArgs &a) {
     asm volatile("" ::"s"(a.in_re), "s"(a.in_im), "s"(a.out_re), "s"(a.out_im), "s"(a.tw3), "s"(a.twr), "s"(a.in_dist), "s"(a.out_dist),
-                 "s"(a.out_s1), "s"(a.out_s2), "s"(a.out_row_stride));
+                 "s"(a.out_s1), "s"(a.out_s2), "s"(a.out_row_stride), "s"(a.in_row_stride), "s"(a.in_hi_stride), "s"(a.in_mid_stride),
+                 "s"(a.in_lo_bits));
     asm volatile("" ::"s"(a.tiles_per_xform), "s"(a.tiles_total), "s"(a.log_s_in), "s"(a.out_lo_bits), "s"(a.tw_bits),
                  "s"(a.in_interleaved), "s"(a.out_interleaved), "s"(a.tw_shift), "s"(a.tw_mask), "s"(a.cs_bits), "s"(a.cb_bits),
                  "s"(a.grid_mode), "s"(a.grid_col0), "s"(a.grid_row_shift), "s"(a.grid_col_mask), "s"(a.scale));

@@ -124,6 +124,23 @@ inline bool shape_exists(unsigned lr, unsigned lc, unsigned lp, size_t elem_byte
 
 constexpr unsigned kWaveTiles = 0x10;  // flag in a plan's points-per-thread code, see make_passes
 
+// Padding of the planner's scratch.  The intermediate arrays between the passes are the one part of the data whose layout
+// is ours: S[r][q] (two passes) / S[u][r][q] (three).  With power-of-two pitches the rows a tile reads in the next pass are
+// 2^a (or 2^(a+b)) elements apart and land on the same HBM channels; a few 128-byte lines of padding per row are worth 5-10 % of the
+// pass that reads them (copy models of the three patterns, profiles/r03_pad_stride_probe.log: 1024 x 16 tiles at 8 KiB
+// row distance 4.80 -> 5.29 TB/s, 512 x 32 in place at 4 KiB 5.26 -> 5.60, 256 x 64 at 2 MiB 4.74 -> 5.00).  The caller's
+// arrays keep their natural layout: the first pass's reads and the last pass's writes cannot be helped this way.
+// On the product kernels (A/B inside one gpurun call, five fresh processes each, profiles/r03_scratch_pad_ab.log):
+// 1024 x 2^20 f64 78.4-79.0 -> 82.7-84.9 GSamples/s (pass A 6.76 -> 6.5 ms, pass B 6.85 -> 6.1-6.5), f32 140 -> 157;
+// 2^21 x 8 59 -> 66; 2^14 / 2^16 batches +2-7 %; the three-pass plans +0-3 % in f64 and +3-5 % in f32; one transform of
+// 2^20 (wave / quad tiles) unchanged.  128 ... 640 bytes of pad are equivalent within the noise except two points:
+// 256 bytes is the best f32 pad (157 against 150 on the batch), 384 bytes the best f64 pad on the small batches.
+#ifdef PHAST_SCRATCH_PAD_BYTES  // tools: one pad for both types (0 = round 2's power-of-two layout)
+constexpr unsigned scratch_pad_bytes(size_t) { return PHAST_SCRATCH_PAD_BYTES; }
+#else
+constexpr unsigned scratch_pad_bytes(size_t elem_bytes) { return elem_bytes == 8 ? 384u : 256u; }
+#endif
+
 // ---- geometry of one pass (see TileArgs in common.hpp) ----
 struct PassGeom {
     unsigned lr = 0, lc = 0;
@@ -133,6 +150,11 @@ struct PassGeom {
     bool pre_tw = false, transpose = false;
     unsigned log_s_in = 0, out_lo_bits = 0, tw_bits = 1;
     unsigned long long out_s1 = 0, out_s2 = 0, out_row_stride = 0;
+    // input strides (TileArgs): 0 = the power-of-two defaults derived from log_s_in and lr (the caller's arrays, strided
+    // batches); set by make_passes for passes that read the PADDED scratch
+    unsigned in_lo_bits = 0;
+    unsigned long long in_row_stride = 0, in_hi_stride = 0, in_mid_stride = 0;
+    unsigned long long scratch_dist = 0;  // elements per transform and plane in the scratch (0 = n)
     // strided batches (make_strided_passes): see TileArgs; tw_log_mod = log2 of the twiddle modulus when it is not lr + log_s_in
     unsigned tw_shift = 0, tw_mask_bits = 0, cs_bits = 0, cb_bits = 0, tw_log_mod = 0;
     unsigned grid_log_n = 0, grid_row_shift = 0;  // first pass with the input twiddle of a four-step split (TileArgs::grid_*)
@@ -306,10 +328,53 @@ inline bool make_passes(unsigned L, const std::vector<unsigned> &lrs, const std:
         if (p.lc > p.log_s_in) return false;    // a tile needs COLS adjacent columns sharing the row stride
         if (p.lc > p.out_lo_bits) return false;  // ... and the output column map must be linear inside a tile
     }
+    // ---- padded scratch pitches: S[r][q] with pitch PR = 2^a + pad;  S[u][r][q] with PU = 2^b PR + pad ----
+    const unsigned long long pad = elem_bytes ? scratch_pad_bytes(elem_bytes) / elem_bytes : 0;
+    bool pad_ok = pad != 0 && L + 1 <= 31;  // the per-lane offsets stay 32-bit with the padded strides
+    for (size_t i = 1; i < ps.size(); ++i) pad_ok = pad_ok && ps[i].lc <= a;  // tiles stay inside the contiguous q
+    if (pad_ok) {
+        const unsigned long long PR = (1ull << a) + pad;
+        if (lrs.size() == 2) {
+            const unsigned long long n_s = PR << b;
+            ps[0].out_s1 = PR;  // out_col(g) = g * PR
+            ps[0].scratch_dist = ps[1].scratch_dist = n_s;
+            ps[1].in_row_stride = PR;
+            ps[1].in_lo_bits = a;
+            ps[1].in_hi_stride = n_s;  // never used: g < 2^a
+        } else {
+            const unsigned long long PU = (PR << b) + pad, n_s = PU << c;
+            ps[0].out_s1 = PU;  // g = r 2^c + u  ->  u PU + r PR
+            ps[0].out_s2 = PR;
+            // pass B: columns g = (u, q), rows r; in place
+            ps[1].in_row_stride = PR;
+            ps[1].in_lo_bits = a;
+            ps[1].in_hi_stride = PU;
+            ps[1].out_s2 = PU;
+            ps[1].out_row_stride = PR;
+            // pass C: columns g = (kb, q) -> kb PR + q, rows u
+            ps[2].in_row_stride = PU;
+            ps[2].in_lo_bits = a;
+            ps[2].in_mid_stride = PR;
+            ps[2].in_hi_stride = n_s;  // never used: g < 2^(a+b)
+            ps[0].scratch_dist = ps[1].scratch_dist = ps[2].scratch_dist = n_s;
+        }
+    }
     return L <= 31;  // per-lane offsets and twiddle exponents are 32-bit element indices
 }
 
+// elements per transform and plane the scratch of a pass list needs (>= n: the padded pitches of make_passes)
+inline unsigned long long scratch_elems(const std::vector<PassGeom> &ps, unsigned log_n) {
+    unsigned long long m = 1ull << log_n;
+    for (const auto &p : ps)
+        if (p.scratch_dist > m) m = p.scratch_dist;
+    return m;
+}
+
 inline void geom_to_args(const PassGeom &p, unsigned log_n, size_t n_xforms, TileArgs &ta) {
+    ta.in_row_stride = p.in_row_stride ? p.in_row_stride : 1ull << p.log_s_in;
+    ta.in_hi_stride = p.in_hi_stride ? p.in_hi_stride : 1ull << (p.log_s_in + p.lr);
+    ta.in_mid_stride = p.in_mid_stride;
+    ta.in_lo_bits = p.in_row_stride ? p.in_lo_bits : p.log_s_in;
     ta.out_s1 = p.out_s1;
     ta.out_s2 = p.out_s2;
     ta.out_row_stride = p.out_row_stride;

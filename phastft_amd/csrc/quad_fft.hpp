@@ -79,14 +79,13 @@ template <typename T> struct QuadBody {
 
     // row of register q: 64 (q >> 2) + 16 (q & 3) + 4 w + tau
     PHAST_HD static void load_raw(const TileArgs &a, int wave, int lane, Regs &r) {
-        const unsigned lo0 = r.g0 & ((1u << a.log_s_in) - 1u);
-        const size_t ubase = (size_t)r.xform * a.in_dist + (((size_t)(r.g0 >> a.log_s_in) << (a.log_s_in + LR)) | lo0);
-        const unsigned voff = ((unsigned)(4 * wave + tau_of(lane)) << a.log_s_in) + (unsigned)col_of(lane);
+        const size_t ubase = in_tile_base(a, r.xform, r.g0);
+        const unsigned voff = (unsigned)(4 * wave + tau_of(lane)) * (unsigned)a.in_row_stride + (unsigned)col_of(lane);
         const T *pr = reinterpret_cast<const T *>(a.in_re) + ubase;
         const T *pi = reinterpret_cast<const T *>(a.in_im) + ubase;
         static_for<0, P>([&](auto q) {
             constexpr int Q = decltype(q)::value;
-            const size_t urow = (size_t)(64 * (Q >> 2) + 16 * (Q & 3)) << a.log_s_in;
+            const size_t urow = (size_t)(64 * (Q >> 2) + 16 * (Q & 3)) * a.in_row_stride;
             if constexpr (NT_LOAD) {
                 r.re[Q] = __builtin_nontemporal_load(pr + urow + voff);
                 r.im[Q] = __builtin_nontemporal_load(pi + urow + voff);

@@ -229,9 +229,8 @@ template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool 
     // only tau*2^log_s_in + col differs between lanes -- one VGPR for all P loads (saddr addressing).
     PHAST_HD static void load_raw(const TileArgs &a, int tid, Regs &r) {
         const int col = col_of(tid), tau = tau_of(tid);
-        const unsigned lo0 = r.g0 & ((1u << a.log_s_in) - 1u);
-        const size_t ubase = (size_t)r.xform * a.in_dist + (((size_t)(r.g0 >> a.log_s_in) << (a.log_s_in + LR)) | lo0);
-        const unsigned voff = ((unsigned)tau << a.log_s_in) + (unsigned)col;
+        const size_t ubase = in_tile_base(a, r.xform, r.g0);
+        const unsigned voff = (unsigned)tau * (unsigned)a.in_row_stride + (unsigned)col;
         // only a first pass (never PRE_TW) can see interleaved input, only a last pass (never TRANSPOSE) writes
         // interleaved output: the other kernels do not carry those paths (they cost registers: 4-dword loads
         // plus selects double the live state of a 32-point thread)
@@ -243,13 +242,13 @@ template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool 
             // PHAST_RUNNING_ROW_PTR=1 makes them running pointers (two scalar adds per row, no SGPR spills) -- and the
             // loads then issue one address computation apart instead of back to back: the 256 x 64 pass of 2^24 x 4 ran
             // 4 % SLOWER, nothing else moved (profiles/r03_ablation_tid_rowptr.log).  Not adopted.
-            const size_t ustep = (size_t)M << a.log_s_in;
+            const size_t ustep = (size_t)M * a.in_row_stride;
             (void)ustep;
             static_for<0, P>([&](auto j) {
 #if PHAST_RUNNING_ROW_PTR
                 const size_t urow = 0;
 #else
-                const size_t urow = (size_t)(decltype(j)::value * M) << a.log_s_in;
+                const size_t urow = (size_t)(decltype(j)::value * M) * a.in_row_stride;
 #endif
                 if constexpr (NT_LD) {
                     r.re[j] = __builtin_nontemporal_load(pr + urow + voff);
@@ -266,7 +265,7 @@ template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool 
         } else {
             const cx *pz = reinterpret_cast<const cx *>(a.in_re) + ubase;
             static_for<0, P>([&](auto j) {
-                const size_t urow = (size_t)(decltype(j)::value * M) << a.log_s_in;
+                const size_t urow = (size_t)(decltype(j)::value * M) * a.in_row_stride;
                 cx v = (pz + urow)[voff];
                 r.re[j] = a.in_interleaved == 2 ? v.y : v.x;
                 r.im[j] = a.in_interleaved == 2 ? v.x : v.y;

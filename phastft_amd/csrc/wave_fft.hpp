@@ -82,14 +82,13 @@ template <typename T, bool PRE_TW, bool TRANSPOSE> struct WaveBody {
     // rows n = 4 j + tau: one VGPR offset for all 16 loads, the row part is wave-uniform
     PHAST_HD static void load_raw(const TileArgs &a, int lane, Regs &r) {
         const int col = col_of(lane), tau = tau_of(lane);
-        const unsigned lo0 = r.g0 & ((1u << a.log_s_in) - 1u);
-        const size_t ubase = (size_t)r.xform * a.in_dist + (((size_t)(r.g0 >> a.log_s_in) << (a.log_s_in + LR)) | lo0);
-        const unsigned voff = ((unsigned)tau << a.log_s_in) + (unsigned)col;
+        const size_t ubase = in_tile_base(a, r.xform, r.g0);
+        const unsigned voff = (unsigned)tau * (unsigned)a.in_row_stride + (unsigned)col;
         if (PRE_TW || !a.in_interleaved) {
             const T *pr = reinterpret_cast<const T *>(a.in_re) + ubase;
             const T *pi = reinterpret_cast<const T *>(a.in_im) + ubase;
             static_for<0, P>([&](auto j) {
-                const size_t urow = (size_t)(decltype(j)::value * TAUS) << a.log_s_in;
+                const size_t urow = (size_t)(decltype(j)::value * TAUS) * a.in_row_stride;
                 if constexpr (NT_LOAD) {
                     r.re[j] = __builtin_nontemporal_load(pr + urow + voff);
                     r.im[j] = __builtin_nontemporal_load(pi + urow + voff);
@@ -101,7 +100,7 @@ template <typename T, bool PRE_TW, bool TRANSPOSE> struct WaveBody {
         } else {  // first pass of an interleaved / real transform: (re, im) or (im, re) pairs
             const cx *pz = reinterpret_cast<const cx *>(a.in_re) + ubase;
             static_for<0, P>([&](auto j) {
-                const size_t urow = (size_t)(decltype(j)::value * TAUS) << a.log_s_in;
+                const size_t urow = (size_t)(decltype(j)::value * TAUS) * a.in_row_stride;
                 cx v = (pz + urow)[voff];
                 r.re[j] = a.in_interleaved == 2 ? v.y : v.x;
                 r.im[j] = a.in_interleaved == 2 ? v.x : v.y;

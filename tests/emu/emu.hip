@@ -54,7 +54,8 @@ static int emu_exec(const void *in_re, const void *in_im, unsigned in_mode, void
     }
     std::vector<PassGeom> ps;
     if (!make_passes(log_n, lrs, tls, ps, lp, sizeof(T))) return 1;
-    std::vector<T> s_re(n * batch), s_im(n * batch);
+    const size_t sd = (size_t)scratch_elems(ps, log_n);  // per transform and plane: n + the padding of the intermediate layouts
+    std::vector<T> s_re(sd * batch), s_im(sd * batch);
     for (size_t i = 0; i < ps.size(); ++i) {
         const PassGeom &p = ps[i];
         std::vector<cx_t<T>> twr = p.quad ? host_twq<T>() : host_twr<T>(1u << p.lr), tw3;
@@ -63,11 +64,11 @@ static int emu_exec(const void *in_re, const void *in_im, unsigned in_mode, void
         const bool first = i == 0, last = i + 1 == ps.size();
         ta.in_re = first ? in_re : s_re.data();
         ta.in_im = first ? in_im : s_im.data();
-        ta.in_dist = first ? in_dist : n;
+        ta.in_dist = first ? in_dist : sd;
         ta.in_interleaved = first ? in_mode : 0;
         ta.out_re = last ? out_re : s_re.data();
         ta.out_im = last ? out_im : s_im.data();
-        ta.out_dist = last ? out_dist : n;
+        ta.out_dist = last ? out_dist : sd;
         ta.out_interleaved = last ? out_mode : 0;
         ta.scale = last ? scale : 1.0;
         ta.tw3 = tw3.data();
