@@ -217,6 +217,8 @@ template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool 
     // each XCD gets one contiguous run of tiles so that neighbouring column groups -- which share DRAM
     // pages and L2 lines -- meet in one L2.
     PHAST_HD static void locate(const TileArgs &a, unsigned t, Regs &r) {
+        // (starting every XCD at a different column-block phase of its run changes nothing -- the persistent workgroups
+        // drift apart within a few tiles: profiles/r03_scratch_pad_ab.log, last section)
         const unsigned tile = ((a.tiles_total & 7u) == 0u) ? (t & 7u) * (a.tiles_total >> 3) + (t >> 3) : t;
         r.xform = tile >> (unsigned)__builtin_ctz(a.tiles_per_xform);  // a power of two (plan.hpp: geom_to_args)
         const unsigned ti = tile & (a.tiles_per_xform - 1u);
