@@ -485,8 +485,8 @@ template <typename T> struct Planner {
         std::lock_guard<std::mutex> lk(mu);
         reap(stream);
         const size_t per = 2 * sstride() * sizeof(T);
-        size_t target = scratch_target_bytes() / per;
-        if (target < 1) target = 1;
+        size_t target = scratch_target_bytes() / (2 * n * sizeof(T));  // counted in transforms of the caller's size: the
+        if (target < 1) target = 1;                                   // row padding of the scratch rides on top (1.5-3 %)
         if (target < reserve) target = reserve;
         size_t want = target;
         if (want > batch && batch >= reserve) want = batch;
