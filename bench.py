@@ -378,11 +378,17 @@ def config_r2c(P, torch, dev, steps: int, cpu: bool):
         acc = t if acc is None else [a + b for a, b in zip(acc, t)]
     pass_ms = [a / ring for a in acc]
     r2c_bytes = 4 * n + 8 * (n // 2 + 1)
-    names = [f"tile_fft pass {i} of the inner 2^23-point transform" for i in range(len(pass_ms) - 1)] + ["untangle sweep"]
     plan_text = pl.describe()
+    n_inner = len(kernel_tags(plan_of(plan_text, plan_kind(P, n // 2, 1, plan_text, "f32")), "float"))
+    fused = len(pass_ms) == n_inner  # round 3: the last pass takes the untangle with it (r2c_fused.hpp): no sweep of its own
+    names = [f"tile_fft pass {i} of the inner 2^23-point transform" for i in range(n_inner)]
+    if fused:
+        names[-1] += " with the untangle fused in (r2c_last_pass_kernel)"
+    else:
+        names.append("untangle sweep")
     # per-kernel algorithmic bytes differ (first pass reads the real input, the untangle re-reads and re-writes the
     # half spectrum): the kernel fraction is quoted against the bytes THAT kernel must move
-    k_bytes = [8 * (n // 2) + 8 * (n // 2)] * (len(pass_ms) - 1) + [16 * (n // 2 + 1)]
+    k_bytes = [8 * (n // 2) + 8 * (n // 2)] * n_inner + ([] if fused else [16 * (n // 2 + 1)])
     fr = [b / (t * 1e-3) / 1e9 / HBM_PEAK_GBS for b, t in zip(k_bytes, pass_ms)]
     dom = max(range(len(pass_ms)), key=lambda i: pass_ms[i])
     roof = {"bound": "hbm", "achieved": k_bytes[dom] / (pass_ms[dom] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -393,7 +399,9 @@ def config_r2c(P, torch, dev, steps: int, cpu: bool):
            "value": n / (ms * 1e-3) / 1e9, "unit": "GSamples/s (real samples)", "steps": steps, "ms_per_step": ms,
            "dtype": "f32", "plan": plan_text, "roofline": roof}
     tags = kernel_tags(plan_of(plan_text, plan_kind(P, n // 2, 1, plan_text, "f32")), "float")
-    tr = traffic_for("r2c_f32_2p24", ["untangle_kernel"] if dom == len(pass_ms) - 1 else [tags[dom]]) if dom < len(tags) + 1 else None
+    if fused:
+        tags[-1] = tags[-1].replace("tile_fft_kernel", "r2c_last_pass_kernel").split(", true, false")[0]
+    tr = traffic_for("r2c_f32_2p24", ["untangle_kernel"] if (not fused and dom == len(pass_ms) - 1) else [tags[dom]]) if dom < len(tags) + 1 else None
     if tr:
         roof.update(tr)
     del x, ore, oim, sets, xs, ores, oims, pl

@@ -19,6 +19,7 @@
 #include "kernels.hpp"
 #include "plan.hpp"
 #include "tile_dispatch.hpp"
+#include "r2c_fused.hpp"
 
 namespace phast {
 
@@ -129,7 +130,23 @@ struct PassDesc : PassGeom {
     void *d_twr = nullptr;
     int blocks_per_cu = 1;
     size_t lds = 0;
+    // last pass only: the fused R2C form of this pass exists (r2c_fused.hpp); its W_{2 rows}^k table and residency
+    void *d_twu = nullptr;
+    int r2c_blocks = 0;
 };
+
+// what the R2C planner hands to Planner::exec so that the last pass can take the untangle with it
+struct R2cFuse {
+    const void *tw3n;  // W_N three-level table, N = 2 * (inner transform length)
+    unsigned twn_bits;
+};
+static bool r2c_fuse_enabled() {  // PHAST_R2C_FUSE=0: keep the untangle as a sweep of its own (tools, A/B)
+    static const bool v = [] {
+        const char *e = std::getenv("PHAST_R2C_FUSE");
+        return !(e && *e == '0');
+    }();
+    return v;
+}
 
 template <typename T> struct Types;
 template <> struct Types<double> {
@@ -326,6 +343,7 @@ template <typename T> struct Planner {
         for (auto &p : v) {
             if (p.d_tw3) hipFree(p.d_tw3);
             if (p.d_twr) hipFree(p.d_twr);
+            if (p.d_twu) hipFree(p.d_twu);
         }
         v.clear();
     }
@@ -333,6 +351,7 @@ template <typename T> struct Planner {
         for (auto &p : v) {
             retire(p.d_tw3, p.pre_tw ? ((size_t)3 << p.tw_bits) * sizeof(cx_t<T>) : 0, false);
             retire(p.d_twr, 64 * sizeof(cx_t<T>), false);
+            retire(p.d_twu, ((size_t)1 << p.lr) * sizeof(cx_t<T>), false);
         }
         v.clear();
     }
@@ -569,12 +588,29 @@ template <typename T> struct Planner {
                 if (e != hipSuccess) rc = hip_fail(e, "occupancy query");
                 if (ps[i].blocks_per_cu < 1) ps[i].blocks_per_cu = 1;
                 if (rc == PHAST_OK && ps[i].lds > 160 * 1024) rc = PHAST_ERR_INVALID_ARG;  // tile does not fit one CU's LDS
+                // the fused R2C form of a LAST pass: generic tiles with <= 16 points per thread whose columns span at least
+                // two tiles (r2c_fused.hpp); anything else keeps the separate untangle sweep
+                const PassDesc &q = ps[i];
+                if (rc == PHAST_OK && i + 1 == ps.size() && i > 0 && !q.wave && !q.quad && !q.strided && q.pre_tw &&
+                    q.log_s_in >= q.lc + 1 && r2c_shape_ok(q.lr, q.lc, q.lp, sizeof(T))) {
+                    std::vector<cx_t<T>> h((size_t)1 << q.lr);
+                    for (size_t k = 0; k < h.size(); ++k) h[k] = twiddle_t<T>(k, 2ull << q.lr);
+                    rc = upload<T>(h, &ps[i].d_twu);
+                    if (rc == PHAST_OK) {
+                        R2cFuseArgs fa{};
+                        int b = 0;
+                        hipError_t e2 = launch_r2c_last<T>((int)q.lr, (int)q.lc, (int)q.lp, 0, nullptr, ta, fa, true, &b);
+                        ps[i].r2c_blocks = e2 == hipSuccess ? b : 0;
+                        (void)hipGetLastError();
+                    }
+                }
             }
             if (rc != PHAST_OK) {
                 for (auto &p : ps) {
                     if (p.d_tw3) hipFree(p.d_tw3);
                     if (p.d_twr) hipFree(p.d_twr);
-                    p.d_tw3 = p.d_twr = nullptr;
+                    if (p.d_twu) hipFree(p.d_twu);
+                    p.d_tw3 = p.d_twr = p.d_twu = nullptr;
                 }
                 return rc;
             }
@@ -704,9 +740,15 @@ template <typename T> struct Planner {
 
     // One batched transform: in -> out (may alias for the planar in-place case), forward arithmetic,
     // output scaled by `scale`.  in_mode/out_mode: 0 planar, 1 interleaved (re,im), 2 interleaved (im,re).
+    // The fused R2C last pass runs HALF as many tiles, each twice as long: it pays once the tiles fill the chip -- from
+    // 2^23 complex points in flight (profiles/r03_r2c_fused_ab.log: f32 N = 2^24 108.6 -> 89.9 us; below, one transform is
+    // latency-bound and loses: N = 2^20 19.5 -> 31.6 us, 2^22 39.4 -> 42.9).
+    bool fuse_pays(size_t batch) const { return r2c_fuse_enabled() && batch * n >= ((size_t)1 << 23); }
+    // `fuse` (R2C): the last pass takes the untangle with it where its fused form exists; *fused_out says whether it did
     int exec(const void *in_re, const void *in_im, size_t in_dist, unsigned in_mode, void *out_re, void *out_im,
              size_t out_dist, unsigned out_mode, size_t batch, double scale, hipStream_t stream,
-             PassTimer *timer = nullptr) const {
+             PassTimer *timer = nullptr, const R2cFuse *fuse = nullptr, bool *fused_out = nullptr) const {
+        if (fused_out) *fused_out = false;
         if (batch == 0) return PHAST_OK;
         std::lock_guard<std::recursive_mutex> call_lock(call_mu);
         PHAST_ON_DEVICE(device);
@@ -781,6 +823,22 @@ template <typename T> struct Planner {
                 geom_to_args(p, log_n, nb, ta);
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (timer) PHAST_HIP(timer->pair((int)i, &e0, &e1));
+                if (last && fuse && p.r2c_blocks > 0 && out_mode == 0 && scale == 1.0 && fuse_pays(nb)) {
+                    R2cFuseArgs fa{};
+                    fa.tw3n = fuse->tw3n;
+                    fa.twn_bits = fuse->twn_bits;
+                    fa.twu = p.d_twu;
+                    fa.tiles_per_xform = (1u << (p.log_s_in - p.lc - 1)) + 1u;
+                    if ((unsigned long long)nb * fa.tiles_per_xform > 0xffffffffull) return PHAST_ERR_INVALID_ARG;
+                    fa.tiles_total = (unsigned)(nb * fa.tiles_per_xform);
+                    unsigned grid = (unsigned)p.r2c_blocks * (unsigned)cus_of(device);
+                    if (grid > fa.tiles_total) grid = fa.tiles_total;
+                    if (grid >= 8) grid &= ~7u;
+                    hipError_t e = launch_r2c_last<T>((int)p.lr, (int)p.lc, (int)p.lp, grid, stream, ta, fa, false, nullptr, e0, e1);
+                    if (e != hipSuccess) return hip_fail(e, "r2c_last_pass launch");
+                    if (fused_out) *fused_out = true;
+                    continue;
+                }
                 hipError_t e = launch_pass(p, ta, stream, e0, e1);
                 if (e != hipSuccess) return hip_fail(e, "tile_fft launch");
             }
@@ -844,6 +902,11 @@ template <typename T> struct PlannerR2c {
         return PHAST_OK;
     }
 
+    bool fuses(size_t batch) const {
+        if (dit.passes.empty() || !dit.fuse_pays(batch)) return false;
+        const auto &ps = dit.plan_for(batch);
+        return !ps.empty() && ps.back().r2c_blocks > 0;
+    }
     // r2c.rs:535-593 / 607-662 on device pointers
     int r2c(const T *d_in, T *d_ore, T *d_oim, size_t batch, size_t in_dist, size_t out_dist, hipStream_t s,
             PassTimer *timer = nullptr) const {
@@ -853,8 +916,11 @@ template <typename T> struct PlannerR2c {
         PHAST_ON_DEVICE(dit.device);
         if (dit.passes.empty())  // N/2 <= 8192: one kernel, the untangle is its epilogue
             return dit.exec_small_real(1, d_in, nullptr, in_dist / 2, d_ore, d_oim, out_dist, batch, 1.0, d_tw3, tw_bits, s);
-        int rc = dit.exec(d_in, nullptr, in_dist / 2, 1, d_ore, d_oim, out_dist, 0, batch, 1.0, s, timer);
+        const R2cFuse fuse{d_tw3, tw_bits};
+        bool fused = false;
+        int rc = dit.exec(d_in, nullptr, in_dist / 2, 1, d_ore, d_oim, out_dist, 0, batch, 1.0, s, timer, &fuse, &fused);
         if (rc) return rc;
+        if (fused) return PHAST_OK;  // the last pass wrote X[k] and X[h - k] itself (r2c_fused.hpp)
         const int untangle_slot = (int)dit.plan_for(batch).size();  // timer slot after the inner transform's passes
         for (size_t b0 = 0; b0 < batch; b0 += 65535) {
             UntangleArgs ua{};
@@ -1023,7 +1089,7 @@ template <typename T>
 static int time_passes_r2c(const PlannerR2c<T> *pl, const T *d_in, T *d_ore, T *d_oim, size_t batch, size_t in_dist,
                            size_t out_dist, int reps, float *pass_ms, int *n_passes, hipStream_t s) {
     if (!pl || !d_in || !d_ore || !d_oim || !pass_ms || !n_passes || reps < 1) return PHAST_ERR_INVALID_ARG;
-    const int np = pl->dit.passes.empty() ? 1 : (int)pl->dit.plan_for(batch).size() + 1;
+    const int np = pl->dit.passes.empty() ? 1 : (int)pl->dit.plan_for(batch).size() + (pl->fuses(batch) ? 0 : 1);
     PHAST_ON_DEVICE(pl->dit.device);
     double acc[4] = {0, 0, 0, 0};
     for (int r = 0; r < reps; ++r) {

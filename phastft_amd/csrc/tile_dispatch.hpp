@@ -39,6 +39,24 @@ hipError_t launch_tile_mode(int lr, int lc, int lp, unsigned grid, hipStream_t s
     return hipErrorInvalidValue;
 }
 
+// the last pass of a real transform's inner FFT with the untangle fused in (r2c_fused.hpp): the same shapes, at most 16
+// points per thread.  Included by tile_f64_r2c.hip / tile_f32_r2c.hip only (r2c_fused.hpp is not pulled in here).
+#define PHAST_R2C_DISPATCH(T_)                                                                                              \
+    template <> hipError_t launch_r2c_last<T_>(int lr, int lc, int lp, unsigned grid, hipStream_t s, const TileArgs &a,      \
+                                               const R2cFuseArgs &f, bool q, int *b, hipEvent_t e0, hipEvent_t e1) {          \
+        PHAST_TILE_SHAPES(PHAST_R2C_CASE_##T_)                                                                              \
+        return hipErrorInvalidValue;                                                                                        \
+    }
+struct R2cFuseArgs;
+template <typename T>
+hipError_t launch_r2c_last(int lr, int lc, int lp, unsigned grid, hipStream_t s, const TileArgs &a, const R2cFuseArgs &f, bool q, int *b,
+                           hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+// (two tiles' worth of f64 points do not fit the 128 registers of a 1024-thread workgroup: those shapes keep the sweep)
+constexpr bool r2c_shape_fits(int lr, int lc, int lp, size_t elem_bytes) { return lp <= 4 && !(elem_bytes == 8 && lr + lc - lp > 9); }
+inline bool r2c_shape_ok(unsigned lr, unsigned lc, unsigned lp, size_t elem_bytes) {
+    return r2c_shape_fits((int)lr, (int)lc, (int)lp, elem_bytes) && shape_exists(lr, lc, lp, elem_bytes);
+}
+
 // defined in tile_f64_a.hip, tile_f64_bc.hip, tile_f32_a.hip, tile_f32_bc.hip
 hipError_t launch_tile_f64_a(int lr, int lc, int lp, unsigned grid, hipStream_t s, const TileArgs &a, bool q, int *b, size_t *l,
                            hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);

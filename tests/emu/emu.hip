@@ -11,6 +11,8 @@
 #include "tile_fft.hpp"
 #include "wave_fft.hpp"
 #include "quad_fft.hpp"
+#include "r2c_fused.hpp"
+#include "tile_dispatch.hpp"
 
 namespace phast {
 
@@ -75,6 +77,73 @@ static int emu_exec(const void *in_re, const void *in_im, unsigned in_mode, void
         ta.twr = twr.data();
         geom_to_args(p, log_n, batch, ta);
         if (!emu_pass<T>(p, ta)) return 2;
+    }
+    return 0;
+}
+
+// real transform of 2^log_n points through the FUSED last pass (r2c_fused.hpp): the inner 2^(log_n - 1)-point transform's
+// passes as emu_exec runs them (interleaved load in the first), the last one with the untangle in it.  Returns 3 when the
+// plan's last pass has no fused form (the library then runs the separate untangle sweep).
+template <typename T> static bool emu_r2c_last(const PassGeom &p, const TileArgs &a, const R2cFuseArgs &f) {
+#define PHAST_EMU_R2C(LR_, LC_, LP_)                                                        \
+    if constexpr (r2c_shape_fits(LR_, LC_, LP_, sizeof(T))) {                               \
+        if (p.lr == LR_ && p.lc == LC_ && p.lp == LP_) {                                    \
+            emulate_r2c_last_pass<T, LR_, LC_, LP_, plane_seq_v<T, LP_>>(a, f);             \
+            return true;                                                                    \
+        }                                                                                   \
+    }
+    PHAST_TILE_SHAPES(PHAST_EMU_R2C)
+#undef PHAST_EMU_R2C
+    return false;
+}
+template <typename T>
+static int emu_r2c_fused(const T *in, unsigned log_n, T *ore, T *oim, const unsigned *lrs_in, size_t np_in, unsigned tile_log_and_lp) {
+    const unsigned L = log_n - 1;
+    const size_t h = (size_t)1 << L;
+    const unsigned tile_log = tile_log_and_lp & 0xff;
+    unsigned lp = (tile_log_and_lp >> 8) ? (tile_log_and_lp >> 8) : 4;
+    std::vector<unsigned> lrs(lrs_in, lrs_in + np_in), tls(1, tile_log);
+    if (lrs.empty()) {
+        if (tile_log != 1 || !single_plan<T>(L, lrs, tls, lp)) heuristic_plan<T>(L, tile_log <= 1, lrs, tls, lp);
+    }
+    std::vector<PassGeom> ps;
+    if (!make_passes(L, lrs, tls, ps, lp, sizeof(T))) return 1;
+    const PassGeom &q = ps.back();
+    if (q.wave || q.quad || !r2c_shape_ok(q.lr, q.lc, q.lp, sizeof(T)) || q.log_s_in < q.lc + 1) return 3;
+    const size_t sd = (size_t)scratch_elems(ps, L);
+    std::vector<T> s_re(sd), s_im(sd);
+    for (size_t i = 0; i < ps.size(); ++i) {
+        const PassGeom &p = ps[i];
+        std::vector<cx_t<T>> twr = p.quad ? host_twq<T>() : host_twr<T>(1u << p.lr), tw3;
+        if (p.pre_tw) tw3 = host_tw3<T>(p.log_mod(), p.tw_bits);
+        TileArgs ta{};
+        const bool first = i == 0, last = i + 1 == ps.size();
+        ta.in_re = first ? (const void *)in : (const void *)s_re.data();
+        ta.in_im = first ? nullptr : s_im.data();
+        ta.in_dist = first ? h : sd;
+        ta.in_interleaved = first ? 1 : 0;
+        ta.out_re = last ? ore : s_re.data();
+        ta.out_im = last ? oim : s_im.data();
+        ta.out_dist = last ? h + 1 : sd;
+        ta.scale = 1.0;
+        ta.tw3 = tw3.data();
+        ta.twr = twr.data();
+        geom_to_args(p, L, 1, ta);
+        if (!last) {
+            if (!emu_pass<T>(p, ta)) return 2;
+            continue;
+        }
+        const unsigned nb = tw3_bits_for(log_n);
+        const std::vector<cx_t<T>> tw3n = host_tw3<T>(log_n, nb);
+        std::vector<cx_t<T>> twu((size_t)1 << p.lr);
+        for (size_t k = 0; k < twu.size(); ++k) twu[k] = twiddle_t<T>(k, 2ull << p.lr);
+        R2cFuseArgs fa{};
+        fa.tw3n = tw3n.data();
+        fa.twn_bits = nb;
+        fa.twu = twu.data();
+        fa.tiles_per_xform = (1u << (p.log_s_in - p.lc - 1)) + 1u;
+        fa.tiles_total = fa.tiles_per_xform;
+        if (!emu_r2c_last<T>(p, ta, fa)) return 3;
     }
     return 0;
 }
@@ -240,6 +309,12 @@ int phast_emu_fft_f32_modes(const float *in_re, const float *in_im, unsigned in_
 }
 #endif
 #if !defined(EMU_PART) || EMU_PART == 4
+int phast_emu_r2c_fused_f32(const float *in, unsigned log_n, float *ore, float *oim, const unsigned *lrs, size_t np, unsigned tile_log) {
+    return phast::emu_r2c_fused<float>(in, log_n, ore, oim, lrs, np, tile_log);
+}
+int phast_emu_r2c_fused_f64(const double *in, unsigned log_n, double *ore, double *oim, const unsigned *lrs, size_t np, unsigned tile_log) {
+    return phast::emu_r2c_fused<double>(in, log_n, ore, oim, lrs, np, tile_log);
+}
 // batches of small transforms (N = 2..2048) through the one-pass kernel's body (row_fft.hpp); modes as above
 static int emu_small(int is_f64, const void *in_re, const void *in_im, unsigned in_mode, void *out_re, void *out_im,
                      unsigned out_mode, unsigned log_n, size_t batch, size_t in_dist, size_t out_dist, double scale,

@@ -280,3 +280,46 @@ def test_f32_wave_tiles_vs_oracle(emu, oracle, L, lrs, tl):
         err = np.sqrt(np.sum((a.astype(np.float64) - re) ** 2 + (b.astype(np.float64) - im) ** 2) /
                       np.sum(re.astype(np.float64) ** 2 + im.astype(np.float64) ** 2))
         assert err <= 1e-5, err
+
+
+def _emu_r2c(emu, x, lrs=(), tile_log=0, points_log=0):
+    n = x.size
+    L = int(np.log2(n))
+    ore, oim = np.zeros(n // 2 + 1, x.dtype), np.zeros(n // 2 + 1, x.dtype)
+    arr = (C.c_uint * max(1, len(lrs)))(*lrs)
+    fn = emu.phast_emu_r2c_fused_f64 if x.dtype == np.float64 else emu.phast_emu_r2c_fused_f32
+    rc = fn(x.ctypes.data_as(C.c_void_p), C.c_uint(L), ore.ctypes.data_as(C.c_void_p), oim.ctypes.data_as(C.c_void_p), arr,
+            C.c_size_t(len(lrs)), C.c_uint(tile_log | (points_log << 8)))
+    return rc, ore, oim
+
+
+@pytest.mark.parametrize("log_n", [15, 16, 17, 18, 19, 20, 21])
+def test_r2c_fused_last_pass_vs_oracle_and_rfft(emu, oracle, log_n):
+    """round 3 (r2c_fused.hpp): the inner transform's LAST pass computes every column twice -- once on column g, once on
+    the conjugate of the mirrored column M - g -- and untangles thread-locally; X[k] and X[h - k] both stored.  The
+    library's latency plan, its plan for one transform and forced plans (two and three passes, 8 and 16 points per
+    thread), both types: every output against the oracle's r2c and an independent real FFT, incl. X[0], X[h/2], X[h]."""
+    n = 1 << log_n
+    rng = np.random.default_rng(log_n)
+    ran = 0
+    # forced plans of the INNER 2^(log_n - 1)-point transform: (rows per pass, log2 tile points, log2 points per thread)
+    forced = {15: [((7, 7), 12, 3), ((7, 7), 13, 4)], 16: [((8, 7), 12, 3)], 17: [((8, 8), 13, 4), ((8, 8), 12, 3)],
+              18: [((9, 8), 12, 3)], 19: [((6, 6, 6), 12, 4)], 20: [((7, 6, 6), 12, 3)], 21: [((7, 7, 6), 12, 3)]}[log_n]
+    for dtype, tol_or, tol_np in ((np.float64, 1e-9, 1e-13), (np.float32, 1e-5, 1e-5)):
+        x = rng.uniform(-1, 1, n).astype(dtype)
+        o_re, o_im = np.zeros(n // 2 + 1, dtype), np.zeros(n // 2 + 1, dtype)
+        (oracle.r2c_fft_f64 if dtype == np.float64 else oracle.r2c_fft_f32)(x.copy(), o_re, o_im)
+        ref = np.fft.rfft(x.astype(np.float64))
+        for lrs, tl, lp in [((), 0, 0), ((), 1, 0)] + forced:
+            rc, ore, oim = _emu_r2c(emu, x, lrs, tl, lp)
+            if rc == 3:  # this plan's last pass has no fused form (wave / quad tiles, 32 points per thread)
+                continue
+            assert rc == 0, (rc, lrs, tl, lp)
+            ran += 1
+            got = ore.astype(np.float64) + 1j * oim.astype(np.float64)
+            den = np.sqrt(np.sum(np.abs(ref) ** 2))
+            assert np.sqrt(np.sum(np.abs(got - ref) ** 2)) / den <= tol_np, (dtype, lrs, tl, lp)
+            assert np.sqrt(np.sum(np.abs(got - (o_re.astype(np.float64) + 1j * o_im.astype(np.float64))) ** 2)) / den <= tol_or
+            assert oim[0] == 0 and oim[-1] == 0  # r2c.rs:161-166: exact zeros
+            assert np.max(np.abs(got - ref)) <= (1e-11 if dtype == np.float64 else 2e-3) * np.sqrt(n), "a single bin is off"
+    assert ran >= 4, ran

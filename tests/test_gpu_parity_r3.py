@@ -516,3 +516,45 @@ def test_first_launches_of_eight_host_threads_race_free(gpu, tmp_path):
     script.write_text(_FIRST_LAUNCH_RACE)
     r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RACE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+# ---------------------------------------------------------------- R2C with the untangle fused into the last pass
+@pytest.mark.parametrize("k,batch,dt", [(24, 1, "f32"), (20, 32, "f32"), (16, 512, "f32"), (19, 32, "f64"), (17, 128, "f64"), (22, 4, "f32")])
+def test_r2c_fused_last_pass_vs_oracle(gpu, oracle, k, batch, dt):
+    """r2c_fused.hpp: from 2^23 complex points in flight the inner transform's last pass computes every column twice (once
+    plain, once on the conjugate of the mirrored column) and stores X[k] AND X[h - k]; there is no untangle sweep.  Every
+    output of the first and the last transform of the batch against the oracle and an independent real FFT, the exact
+    zeros of X[0].im / X[h].im, the input untouched -- and the number of kernels proves which path ran."""
+    import torch
+
+    n = 1 << k
+    ndt, tdt = (np.float64, torch.float64) if dt == "f64" else (np.float32, torch.float32)
+    pl = (gpu.PlannerR2c64 if dt == "f64" else gpu.PlannerR2c32)(n)
+    x = torch.empty(n * batch, dtype=tdt, device="cuda")
+    gpu.fill_uniform(x, None, n, seed=0xF00D, first_id=3)
+    x0 = x.clone()
+    h1 = n // 2 + 1
+    ore = torch.zeros(h1 * batch, dtype=tdt, device="cuda")
+    oim = torch.zeros_like(ore)
+    gpu.r2c_fft_batched(x, ore, oim, pl, batch)
+    torch.cuda.synchronize()
+    assert torch.equal(x, x0)
+    inner = pl.describe()
+    ms = pl.time_passes(x[:n], ore[:h1], oim[:h1], reps=1) if batch == 1 else None
+    if ms is not None:  # one transform of 2^24 f32: three inner passes, no fourth kernel
+        assert len(ms) == 3, (ms, inner)
+    tol_or, tol_np = (1e-9, 1e-13) if dt == "f64" else (1e-5, 1e-5)
+    for b in (0, batch - 1):
+        h_x = x0[b * n:(b + 1) * n].cpu().numpy()
+        o_re, o_im = np.zeros(h1, ndt), np.zeros(h1, ndt)
+        (oracle.r2c_fft_f64 if dt == "f64" else oracle.r2c_fft_f32)(h_x.copy(), o_re, o_im)
+        g_re, g_im = ore[b * h1:(b + 1) * h1].cpu().numpy(), oim[b * h1:(b + 1) * h1].cpu().numpy()
+        assert rel_l2(g_re, g_im, o_re, o_im) <= tol_or, (b, inner)
+        ref = np.fft.rfft(h_x.astype(np.float64))
+        assert rel_l2(g_re, g_im, ref.real, ref.imag) <= tol_np, (b, inner)
+        assert max_bin_err(g_re, g_im, ref.real, ref.imag) <= (1e-11 if dt == "f64" else 2e-3), (b, inner)
+        assert g_im[0] == 0 and g_im[-1] == 0
+    # and the round trip through C2R gives the input back
+    y = torch.empty_like(x)
+    gpu.c2r_fft_batched(ore, oim, y, pl, batch)
+    assert float((y - x0).abs().max()) < (1e-10 if dt == "f64" else 2e-4)
