@@ -51,8 +51,11 @@ struct R2cFuseArgs;
 template <typename T>
 hipError_t launch_r2c_last(int lr, int lc, int lp, unsigned grid, hipStream_t s, const TileArgs &a, const R2cFuseArgs &f, bool q, int *b,
                            hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
-// (two tiles' worth of f64 points do not fit the 128 registers of a 1024-thread workgroup: those shapes keep the sweep)
-constexpr bool r2c_shape_fits(int lr, int lc, int lp, size_t elem_bytes) { return lp <= 4 && !(elem_bytes == 8 && lr + lc - lp > 9); }
+// (two tiles' worth of points must fit the registers: f64 up to 16 points per thread on at most 512 threads, f32 up to 32
+// points per thread on at most 512 threads; the rest keeps the sweep)
+constexpr bool r2c_shape_fits(int lr, int lc, int lp, size_t elem_bytes) {
+    return elem_bytes == 8 ? (lp <= 4 && lr + lc - lp <= 9) : (lp <= 4 || (lp == 5 && lr + lc - lp <= 9));
+}
 inline bool r2c_shape_ok(unsigned lr, unsigned lc, unsigned lp, size_t elem_bytes) {
     return r2c_shape_fits((int)lr, (int)lc, (int)lp, elem_bytes) && shape_exists(lr, lc, lp, elem_bytes);
 }

@@ -304,7 +304,8 @@ def test_r2c_fused_last_pass_vs_oracle_and_rfft(emu, oracle, log_n):
     ran = 0
     # forced plans of the INNER 2^(log_n - 1)-point transform: (rows per pass, log2 tile points, log2 points per thread)
     forced = {15: [((7, 7), 12, 3), ((7, 7), 13, 4)], 16: [((8, 7), 12, 3)], 17: [((8, 8), 13, 4), ((8, 8), 12, 3)],
-              18: [((9, 8), 12, 3)], 19: [((6, 6, 6), 12, 4)], 20: [((7, 6, 6), 12, 3)], 21: [((7, 7, 6), 12, 3)]}[log_n]
+              18: [((9, 8), 12, 3)], 19: [((6, 6, 6), 12, 4), ((9, 9), 14, 5)], 20: [((7, 6, 6), 12, 3)],
+              21: [((7, 7, 6), 12, 3), ((10, 10), 14, 5)]}[log_n]  # (.., 14, 5): 32 points per thread -- fused in f32 only
     for dtype, tol_or, tol_np in ((np.float64, 1e-9, 1e-13), (np.float32, 1e-5, 1e-5)):
         x = rng.uniform(-1, 1, n).astype(dtype)
         o_re, o_im = np.zeros(n // 2 + 1, dtype), np.zeros(n // 2 + 1, dtype)
