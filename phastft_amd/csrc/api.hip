@@ -399,6 +399,24 @@ template <typename T> struct Planner {
         return passes_lat;
     }
 
+    // R2C (with the untangle fused into the last pass): where the plan for `batch` ends in a pass that has no fused form
+    // (wave / quad tiles of the single-transform plans) but the latency plan's generic tiles do, the latency plan runs --
+    // its passes are a few per cent slower, the sweep it saves is a quarter of the transform (R2C of 2^24..2^26 f64 points:
+    // +11..15 %; beyond 2^25 inner points the latency plan's passes lose more than the sweep gives: measured, tools/r2c_f64_probe.py)
+    const std::vector<PassDesc> &plan_for_r2c(size_t batch) const {
+        const std::vector<PassDesc> &ps = plan_for(batch);
+        if (!ps.empty() && ps.back().r2c_blocks == 0 && log_n <= 25 && !passes_lat.empty() && passes_lat.back().r2c_blocks > 0 && r2c_lat_ok())
+            return passes_lat;
+        return ps;
+    }
+    static bool r2c_lat_ok() {  // PHAST_R2C_LAT=0: tools (A/B)
+        static const bool v = [] {
+            const char *e = std::getenv("PHAST_R2C_LAT");
+            return !(e && *e == '0');
+        }();
+        return v;
+    }
+
     // which: 0 = one plan for every batch size, 1 = throughput plan only, 2 = latency plan only, 3 = mid plan only,
     // 4 = the plan for one transform;
     // lp = log2(points per thread)
@@ -784,7 +802,7 @@ template <typename T> struct Planner {
         const size_t sd = sstride();       // elements per transform and plane in the (padded) scratch
         T *s_re = d_scratch;               // plane layout: all re planes, then all im planes
         T *s_im = d_scratch + cap * sd;
-        const std::vector<PassDesc> &passes = plan_for(batch);
+        const std::vector<PassDesc> &passes = (fuse && fuse_pays(batch < cap ? batch : cap)) ? plan_for_r2c(batch) : plan_for(batch);
         const size_t np = passes.size();
         for (size_t b0 = 0; b0 < batch; b0 += cap) {
             const size_t nb = batch - b0 < cap ? batch - b0 : cap;
@@ -904,8 +922,11 @@ template <typename T> struct PlannerR2c {
 
     bool fuses(size_t batch) const {
         if (dit.passes.empty() || !dit.fuse_pays(batch)) return false;
-        const auto &ps = dit.plan_for(batch);
+        const auto &ps = dit.plan_for_r2c(batch);
         return !ps.empty() && ps.back().r2c_blocks > 0;
+    }
+    size_t inner_passes(size_t batch) const {
+        return (dit.fuse_pays(batch) ? dit.plan_for_r2c(batch) : dit.plan_for(batch)).size();
     }
     // r2c.rs:535-593 / 607-662 on device pointers
     int r2c(const T *d_in, T *d_ore, T *d_oim, size_t batch, size_t in_dist, size_t out_dist, hipStream_t s,
@@ -921,7 +942,7 @@ template <typename T> struct PlannerR2c {
         int rc = dit.exec(d_in, nullptr, in_dist / 2, 1, d_ore, d_oim, out_dist, 0, batch, 1.0, s, timer, &fuse, &fused);
         if (rc) return rc;
         if (fused) return PHAST_OK;  // the last pass wrote X[k] and X[h - k] itself (r2c_fused.hpp)
-        const int untangle_slot = (int)dit.plan_for(batch).size();  // timer slot after the inner transform's passes
+        const int untangle_slot = (int)inner_passes(batch);  // timer slot after the inner transform's passes
         for (size_t b0 = 0; b0 < batch; b0 += 65535) {
             UntangleArgs ua{};
             ua.re = d_ore + b0 * out_dist;
@@ -1089,7 +1110,7 @@ template <typename T>
 static int time_passes_r2c(const PlannerR2c<T> *pl, const T *d_in, T *d_ore, T *d_oim, size_t batch, size_t in_dist,
                            size_t out_dist, int reps, float *pass_ms, int *n_passes, hipStream_t s) {
     if (!pl || !d_in || !d_ore || !d_oim || !pass_ms || !n_passes || reps < 1) return PHAST_ERR_INVALID_ARG;
-    const int np = pl->dit.passes.empty() ? 1 : (int)pl->dit.plan_for(batch).size() + (pl->fuses(batch) ? 0 : 1);
+    const int np = pl->dit.passes.empty() ? 1 : (int)pl->inner_passes(batch) + (pl->fuses(batch) ? 0 : 1);
     PHAST_ON_DEVICE(pl->dit.device);
     double acc[4] = {0, 0, 0, 0};
     for (int r = 0; r < reps; ++r) {
