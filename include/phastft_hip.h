@@ -302,6 +302,15 @@ int phast_planner_r2c64_time_passes(const phast_planner_r2c64 *p, const double *
 int phast_planner_r2c32_time_passes(const phast_planner_r2c32 *p, const float *d_input, float *d_output_re,
                                     float *d_output_im, size_t batch, size_t in_dist, size_t out_dist, int reps,
                                     float *pass_ms, int *n_passes, void *stream);
+/* ... and for the inverse real transform (r2c.rs:740-895): slots 0..np-1 = the passes of the inner transform -- the first
+ * of them forms z from the half-spectrum on load wherever its fused form exists (every multi-pass plan whose first pass
+ * is a generic tile; csrc/c2r_fused.hpp), slot np = the preprocess sweep (r2c.rs:263-433) otherwise. */
+int phast_planner_r2c64_time_c2r_passes(const phast_planner_r2c64 *p, const double *d_input_re, const double *d_input_im,
+                                        double *d_output, size_t batch, size_t in_dist, size_t out_dist, int reps,
+                                        float *pass_ms, int *n_passes, void *stream);
+int phast_planner_r2c32_time_c2r_passes(const phast_planner_r2c32 *p, const float *d_input_re, const float *d_input_im,
+                                        float *d_output, size_t batch, size_t in_dist, size_t out_dist, int reps,
+                                        float *pass_ms, int *n_passes, void *stream);
 /* plan of the inner N/2-point complex transform, as phast_planner_dit*_describe */
 int phast_planner_r2c64_describe(const phast_planner_r2c64 *p, char *buf, size_t buf_len);
 int phast_planner_r2c32_describe(const phast_planner_r2c32 *p, char *buf, size_t buf_len);

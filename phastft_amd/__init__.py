@@ -284,6 +284,18 @@ class _PlannerR2c:
         return [float(ms[k]) for k in range(npass.value)]
 
 
+    def time_c2r_passes(self, input_re, input_im, output, reps: int = 10):
+        """The same for one C2R transform: the passes of the inner transform (the first one forms z on load where its
+        fused form exists), then the preprocess sweep where it does not."""
+        ire, iim, out = (_Slice(x, self._dtype, w) for x, w in ((input_re, "input_re"), (input_im, "input_im"), (output, "output")))
+        ms = (C.c_float * 4)()
+        npass = C.c_int()
+        _check(getattr(_lib.lib(), f"phast_planner_r2c{self._sfx}_time_c2r_passes")(
+            self._h, ire.ptr, iim.ptr, out.ptr, C.c_size_t(1), C.c_size_t(self.n // 2 + 1), C.c_size_t(self.n),
+            C.c_int(reps), ms, C.byref(npass), _stream()))
+        return [float(ms[k]) for k in range(npass.value)]
+
+
 class PlannerR2c64(_PlannerR2c):
     """planner.rs:164-212 (f64)"""
 

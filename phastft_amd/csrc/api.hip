@@ -20,6 +20,7 @@
 #include "plan.hpp"
 #include "tile_dispatch.hpp"
 #include "r2c_fused.hpp"
+#include "c2r_fused.hpp"
 
 namespace phast {
 
@@ -133,6 +134,8 @@ struct PassDesc : PassGeom {
     // last pass only: the fused R2C form of this pass exists (r2c_fused.hpp); its W_{2 rows}^k table and residency
     void *d_twu = nullptr;
     int r2c_blocks = 0;
+    // first pass only: the fused C2R form of this pass exists (c2r_fused.hpp; d_twu is its W_{2 rows}^n table)
+    int c2r_blocks = 0;
 };
 
 // what the R2C planner hands to Planner::exec so that the last pass can take the untangle with it
@@ -140,6 +143,13 @@ struct R2cFuse {
     const void *tw3n;  // W_N three-level table, N = 2 * (inner transform length)
     unsigned twn_bits;
 };
+static bool c2r_fuse_enabled() {  // PHAST_C2R_FUSE=0: keep the C2R preprocess as a sweep of its own (tools, A/B)
+    static const bool v = [] {
+        const char *e = std::getenv("PHAST_C2R_FUSE");
+        return !(e && *e == '0');
+    }();
+    return v;
+}
 static bool r2c_fuse_enabled() {  // PHAST_R2C_FUSE=0: keep the untangle as a sweep of its own (tools, A/B)
     static const bool v = [] {
         const char *e = std::getenv("PHAST_R2C_FUSE");
@@ -409,6 +419,20 @@ template <typename T> struct Planner {
             return passes_lat;
         return ps;
     }
+    // C2R, the same on the other side: a plan whose FIRST pass is a wave tile has no fused form of it (c2r_fused.hpp)
+    const std::vector<PassDesc> &plan_for_c2r(size_t batch) const {
+        const std::vector<PassDesc> &ps = plan_for(batch);
+        if (!ps.empty() && ps.front().c2r_blocks == 0 && !passes_lat.empty() && passes_lat.front().c2r_blocks > 0 && c2r_lat_ok())
+            return passes_lat;
+        return ps;
+    }
+    static bool c2r_lat_ok() {  // PHAST_C2R_LAT=0: tools (A/B)
+        static const bool v = [] {
+            const char *e = std::getenv("PHAST_C2R_LAT");
+            return !(e && *e == '0');
+        }();
+        return v;
+    }
     static bool r2c_lat_ok() {  // PHAST_R2C_LAT=0: tools (A/B)
         static const bool v = [] {
             const char *e = std::getenv("PHAST_R2C_LAT");
@@ -623,6 +647,25 @@ template <typename T> struct Planner {
                     }
                 }
             }
+            // the fused C2R form of a FIRST pass of a contiguous transform: generic tiles, at least two of them per transform
+            if (rc == PHAST_OK) {
+                const PassDesc &q = ps[i];
+                if (i == 0 && ps.size() > 1 && !q.wave && !q.quad && !q.strided && q.transpose && !q.pre_tw &&
+                    q.log_s_in >= q.lc + 1 && c2r_shape_ok(q.lr, q.lc, q.lp, sizeof(T))) {
+                    std::vector<cx_t<T>> h((size_t)1 << q.lr);
+                    for (size_t k = 0; k < h.size(); ++k) h[k] = twiddle_t<T>(k, 2ull << q.lr);
+                    rc = upload<T>(h, &ps[i].d_twu);
+                    if (rc == PHAST_OK) {
+                        TileArgs ta{};
+                        ta.tw_bits = q.tw_bits;
+                        C2rFuseArgs fa{};
+                        int b = 0;
+                        hipError_t e2 = launch_c2r_first<T>((int)q.lr, (int)q.lc, (int)q.lp, 0, nullptr, ta, fa, true, &b);
+                        ps[i].c2r_blocks = e2 == hipSuccess ? b : 0;
+                        (void)hipGetLastError();
+                    }
+                }
+            }
             if (rc != PHAST_OK) {
                 for (auto &p : ps) {
                     if (p.d_tw3) hipFree(p.d_tw3);
@@ -802,7 +845,9 @@ template <typename T> struct Planner {
         const size_t sd = sstride();       // elements per transform and plane in the (padded) scratch
         T *s_re = d_scratch;               // plane layout: all re planes, then all im planes
         T *s_im = d_scratch + cap * sd;
-        const std::vector<PassDesc> &passes = (fuse && fuse_pays(batch < cap ? batch : cap)) ? plan_for_r2c(batch) : plan_for(batch);
+        const std::vector<PassDesc> &passes = in_mode == 3 ? plan_for_c2r(batch)
+                                              : (fuse && fuse_pays(batch < cap ? batch : cap)) ? plan_for_r2c(batch)
+                                                                                                 : plan_for(batch);
         const size_t np = passes.size();
         for (size_t b0 = 0; b0 < batch; b0 += cap) {
             const size_t nb = batch - b0 < cap ? batch - b0 : cap;
@@ -811,7 +856,7 @@ template <typename T> struct Planner {
                 TileArgs ta{};
                 const bool first = i == 0, last = i + 1 == np;
                 if (first) {
-                    const size_t isz = in_mode ? 2 * sizeof(T) : sizeof(T);
+                    const size_t isz = (in_mode == 1 || in_mode == 2) ? 2 * sizeof(T) : sizeof(T);
                     ta.in_re = (const char *)in_re + b0 * in_dist * isz;
                     ta.in_im = in_im ? (const char *)in_im + b0 * in_dist * isz : nullptr;
                     ta.in_dist = in_dist;
@@ -841,7 +886,21 @@ template <typename T> struct Planner {
                 geom_to_args(p, log_n, nb, ta);
                 hipEvent_t e0 = nullptr, e1 = nullptr;
                 if (timer) PHAST_HIP(timer->pair((int)i, &e0, &e1));
-                if (last && fuse && p.r2c_blocks > 0 && out_mode == 0 && scale == 1.0 && fuse_pays(nb)) {
+                if (first && in_mode == 3) {  // C2R: the half-spectrum planes, z formed on load (c2r_fused.hpp)
+                    if (!fuse || p.c2r_blocks <= 0) return PHAST_ERR_INVALID_ARG;
+                    ta.in_interleaved = 0;
+                    C2rFuseArgs fa{};
+                    fa.tw3n = fuse->tw3n;
+                    fa.twn_bits = fuse->twn_bits;
+                    fa.twu = p.d_twu;
+                    unsigned grid = (unsigned)p.c2r_blocks * (unsigned)cus_of(device);
+                    if (grid > ta.tiles_total) grid = ta.tiles_total;
+                    if (grid >= 8) grid &= ~7u;
+                    hipError_t e = launch_c2r_first<T>((int)p.lr, (int)p.lc, (int)p.lp, grid, stream, ta, fa, false, nullptr, e0, e1);
+                    if (e != hipSuccess) return hip_fail(e, "c2r_first_pass launch");
+                    continue;
+                }
+                if (last && fuse && in_mode != 3 && p.r2c_blocks > 0 && out_mode == 0 && scale == 1.0 && fuse_pays(nb)) {
                     R2cFuseArgs fa{};
                     fa.tw3n = fuse->tw3n;
                     fa.twn_bits = fuse->twn_bits;
@@ -925,6 +984,11 @@ template <typename T> struct PlannerR2c {
         const auto &ps = dit.plan_for_r2c(batch);
         return !ps.empty() && ps.back().r2c_blocks > 0;
     }
+    bool c2r_fuses(size_t batch) const {
+        if (dit.passes.empty() || !c2r_fuse_enabled()) return false;
+        const auto &ps = dit.plan_for_c2r(batch);
+        return !ps.empty() && ps.front().c2r_blocks > 0;
+    }
     size_t inner_passes(size_t batch) const {
         return (dit.fuse_pays(batch) ? dit.plan_for_r2c(batch) : dit.plan_for(batch)).size();
     }
@@ -961,7 +1025,7 @@ template <typename T> struct PlannerR2c {
 
     // r2c.rs:740-790 / 836-895 on device pointers
     int c2r(const T *d_ire, const T *d_iim, T *d_out, size_t batch, size_t in_dist, size_t out_dist,
-            hipStream_t s) const {
+            hipStream_t s, PassTimer *timer = nullptr) const {
         const size_t half = n / 2;
         if (out_dist & 1) return PHAST_ERR_INVALID_ARG;
         std::lock_guard<std::recursive_mutex> call_lock(dit.call_mu);
@@ -969,6 +1033,10 @@ template <typename T> struct PlannerR2c {
         if (dit.passes.empty())  // N/2 <= 8192: one kernel, the preprocess is its prologue
             return dit.exec_small_real(2, d_ire, d_iim, in_dist, d_out, nullptr, out_dist / 2, batch, 1.0 / (double)half,
                                        d_tw3, tw_bits, s);
+        if (c2r_fuses(batch)) {  // the first pass forms z on load: no preprocess sweep, no workspace (c2r_fused.hpp)
+            const R2cFuse fuse{d_tw3, tw_bits};
+            return dit.exec(d_ire, d_iim, in_dist, 3, d_out, nullptr, out_dist / 2, 2, batch, 1.0 / (double)half, s, timer, &fuse);
+        }
         size_t cap = 0;
         int rc = ensure_z(batch, &cap, s);
         if (rc) return rc;
@@ -986,11 +1054,13 @@ template <typename T> struct PlannerR2c {
             pa.half = (unsigned)half;
             pa.tw_bits = tw_bits;
             pa.batch = (unsigned)nb;
-            PHAST_HIP(launch_c2r_preprocess<T>(pa, s));
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (timer) PHAST_HIP(timer->pair((int)dit.plan_for(batch).size(), &e0, &e1));  // slot after the inner passes
+            PHAST_HIP(launch_c2r_preprocess<T>(pa, s, e0, e1));
             // inverse by the swap trick (algorithms/dit.rs:297-300): forward FFT of (z_im, z_re), 1/half scale,
             // and the (positional re, positional im) = (caller im, caller re) pair is stored as (im, re)
             rc = dit.exec(z_im, z_re, half, 0, d_out + b0 * out_dist, nullptr, out_dist / 2, 2, nb,
-                          1.0 / (double)half, s);
+                          1.0 / (double)half, s, timer);
             if (rc) return rc;
         }
         return PHAST_OK;
@@ -1117,6 +1187,32 @@ static int time_passes_r2c(const PlannerR2c<T> *pl, const T *d_in, T *d_ore, T *
         PassTimer tm;
         int rc = pl->dit.passes.empty() ? pl->r2c(d_in, d_ore, d_oim, batch, in_dist, out_dist, s)
                                         : pl->r2c(d_in, d_ore, d_oim, batch, in_dist, out_dist, s, &tm);
+        if (rc) return rc;
+        PHAST_HIP(hipStreamSynchronize(s));
+        for (size_t i = 0; i < tm.pass_of.size(); ++i) {
+            float ms = 0;
+            PHAST_HIP(hipEventElapsedTime(&ms, tm.ev[2 * i], tm.ev[2 * i + 1]));
+            acc[tm.pass_of[i]] += ms;
+        }
+    }
+    for (int i = 0; i < np; ++i) pass_ms[i] = (float)(acc[i] / reps);
+    *n_passes = np;
+    return PHAST_OK;
+}
+
+// ... and for the inverse real transform: slots 0..np-1 = passes of the inner transform (the first one forms z on load
+// when its fused form exists, c2r_fused.hpp), slot np = the preprocess sweep otherwise
+template <typename T>
+static int time_passes_c2r(const PlannerR2c<T> *pl, const T *d_ire, const T *d_iim, T *d_out, size_t batch, size_t in_dist,
+                           size_t out_dist, int reps, float *pass_ms, int *n_passes, hipStream_t s) {
+    if (!pl || !d_ire || !d_iim || !d_out || !pass_ms || !n_passes || reps < 1) return PHAST_ERR_INVALID_ARG;
+    const int np = pl->dit.passes.empty() ? 1 : pl->c2r_fuses(batch) ? (int)pl->dit.plan_for_c2r(batch).size() : (int)pl->dit.plan_for(batch).size() + 1;
+    PHAST_ON_DEVICE(pl->dit.device);
+    double acc[4] = {0, 0, 0, 0};
+    for (int r = 0; r < reps; ++r) {
+        PassTimer tm;
+        int rc = pl->dit.passes.empty() ? pl->c2r(d_ire, d_iim, d_out, batch, in_dist, out_dist, s)
+                                        : pl->c2r(d_ire, d_iim, d_out, batch, in_dist, out_dist, s, &tm);
         if (rc) return rc;
         PHAST_HIP(hipStreamSynchronize(s));
         for (size_t i = 0; i < tm.pass_of.size(); ++i) {
@@ -1511,6 +1607,12 @@ int phast_options_guess(size_t input_size, phast_options *out) {
                                              size_t batch, size_t in_dist, size_t out_dist, int reps,              \
                                              float *pass_ms, int *n_passes, void *stream) {                        \
         return time_passes_r2c<T>(p, d_in, d_ore, d_oim, batch, in_dist, out_dist, reps, pass_ms, n_passes,        \
+                                  static_cast<hipStream_t>(stream));                                               \
+    }                                                                                                              \
+    int phast_planner_r2c##SFX##_time_c2r_passes(const phast_planner_r2c##SFX *p, const T *d_ire, const T *d_iim,   \
+                                                 T *d_out, size_t batch, size_t in_dist, size_t out_dist, int reps, \
+                                                 float *pass_ms, int *n_passes, void *stream) {                     \
+        return time_passes_c2r<T>(p, d_ire, d_iim, d_out, batch, in_dist, out_dist, reps, pass_ms, n_passes,        \
                                   static_cast<hipStream_t>(stream));                                               \
     }                                                                                                              \
     int phast_planner_r2c##SFX##_describe(const phast_planner_r2c##SFX *p, char *buf, size_t len) {                \

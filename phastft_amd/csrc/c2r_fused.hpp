@@ -1,0 +1,245 @@
+// c2r_fused.hpp -- the FIRST pass of the inner N/2-point transform of an inverse real FFT with the preprocess fused into
+// its load (algorithms/r2c.rs:263-433: simd_c2r_preprocess_*; round 3).  Until now the preprocess ran as a sweep of its
+// own: half-spectrum in, z out into a workspace of N values per transform, which the first pass read back -- a quarter of
+// a C2R of 2^24 points (three passes + the preprocess).
+//
+// z[k] needs X[k] and X[h - k], h = N/2.  A first-pass tile holds ALL rows n of its columns g (k = n M + g, M = 2^log_s_in
+// columns, R = 2^LR rows) and h - k = (R - 1 - n) M + (M - g): the partner lives in the MIRRORED column, rows reversed.
+// Unlike the store side (r2c_fused.hpp) nothing has to be computed twice here -- the partner is INPUT: a thread simply
+// loads it next to its own element (four loads per point instead of two) and forms z in registers:
+//
+//   * every element is then read twice per pass, once as itself and once as the partner of its mirror.  The tile order
+//     makes the second read an L2 hit instead of HBM traffic: tiles are taken in PAIRS (q, tiles - 1 - q) at consecutive
+//     positions of the XCD-aware order, i.e. by neighbouring workgroups of one XCD at the same time -- each is (up to the
+//     one-element shift of the mirror: columns (M - g0 - C, M - g0]) the other's partner;
+//   * twiddle 0.5 W_N^k, N = 2h: W_N^(n M + g) = W_N^g W_2R^n -- one three-level look-up per thread and tile and one entry of
+//     a small table (R entries, read through the L1) per element, as in r2c_fused.hpp; no rotation recurrence, no drift;
+//   * k = 0 pairs with X[h] (row R, column 0: one past the R x M block, the half-spectrum has h + 1 entries), k = h/2 with
+//     itself: both fall out of the address arithmetic, no special cases;
+//   * the inverse runs as a forward transform of (z_im, z_re) (algorithms/dit.rs:297-300): the thread hands (z_im, z_re)
+//     to the radix chain; the last pass stores (im, re) pairs scaled by 1/h as before.
+//
+// No workspace any more, and the half-spectrum is read-only as the reference's (r2c.rs:740-790 takes `&[T]`).
+#pragma once
+
+#include "tile_fft.hpp"
+
+namespace phast {
+
+struct C2rFuseArgs {
+    const void *tw3n;   // [3][1 << twn_bits] complex: W_N^e, N = 2 h (the R2C planner's table)
+    const void *twu;    // [R] complex: W_{2R}^n
+    unsigned twn_bits;
+};
+
+template <typename T, int LR, int LC, int LP, bool SEQ> struct C2rFirstBody {
+    using Body = TileBody<T, LR, LC, LP, false, true, SEQ>;
+    using Regs = typename Body::Regs;
+    using cx = cx_t<T>;
+    static constexpr int P = Body::P, M = Body::M, COLS = Body::COLS, ROWS = Body::ROWS;
+    // rows loaded at a time (load_pre): registers per lane the shape may use, minus the 2 P values of z and ~40 of
+    // addresses and twiddles, over the 4 values a row brings
+    static constexpr int W = (int)sizeof(T) / 4, BUDGET = Body::NT > 512 ? 128 : 256, FREE = BUDGET - 2 * P * W - 40;
+    static constexpr int chunk_rows() {
+        int ch = 1;
+        while (2 * ch <= P && 4 * W * 2 * ch <= FREE) ch *= 2;
+        return ch;
+    }
+    static constexpr int CH = chunk_rows();
+
+    // position t of the launch -> (transform, first column): XCD-aware as TileBody::locate (workgroup b runs on XCD b % 8
+    // and gets one contiguous run of positions); inside a transform positions 2q and 2q + 1 are tile q and its mirror
+    PHAST_HD static void locate(const TileArgs &a, unsigned t, Regs &r) {
+        const unsigned pos = ((a.tiles_total & 7u) == 0u) ? (t & 7u) * (a.tiles_total >> 3) + (t >> 3) : t;
+        r.xform = pos >> (unsigned)__builtin_ctz(a.tiles_per_xform);
+        const unsigned ti = pos & (a.tiles_per_xform - 1u), q = ti >> 1;
+        r.g0 = ((ti & 1u) ? a.tiles_per_xform - 1u - q : q) << LC;
+    }
+
+    // rows n = j M + tau of column g = g0 + col: X[k] from (row n, column g), X[h - k] from (row R - 1 - n, column M - g)
+    //   = row (P - 1 - j) M + (M - 1 - tau), column (M - g0 - COLS) + (COLS - col): uniform base + non-negative lane offset
+    PHAST_HD static void load_pre(const TileArgs &a, const C2rFuseArgs &f, int tid, Regs &r) {
+        const int col = Body::col_of(tid), tau = Body::tau_of(tid);
+        const unsigned mcols = 1u << a.log_s_in;
+        const size_t xbase = (size_t)r.xform * a.in_dist;
+        const T *pr = reinterpret_cast<const T *>(a.in_re) + xbase + r.g0;
+        const T *pi = reinterpret_cast<const T *>(a.in_im) + xbase + r.g0;
+        const T *qr = reinterpret_cast<const T *>(a.in_re) + xbase + (mcols - r.g0 - (unsigned)COLS);
+        const T *qi = reinterpret_cast<const T *>(a.in_im) + xbase + (mcols - r.g0 - (unsigned)COLS);
+        const unsigned voff = (unsigned)tau * mcols + (unsigned)col;
+        const unsigned moff = (unsigned)(M - 1 - tau) * mcols + (unsigned)(COLS - col);
+        T gr, gi;  // 0.5 W_N^g
+        tw3_lookup<T>(reinterpret_cast<const cx *>(f.tw3n), f.twn_bits, r.g0 + (unsigned)col, gr, gi);
+        gr *= (T)0.5;
+        gi *= (T)0.5;
+        const cx *twu = reinterpret_cast<const cx *>(f.twu) + tau;
+        // CH rows at a time: the loaded values of a chunk (4 per point) live next to the 2 P values of z, so the chunk is
+        // what the register budget of the shape leaves (all P rows at once for the 8- and most 16-point shapes)
+        static_for<0, P / CH>([&](auto c) {
+            constexpr int C0 = decltype(c)::value * CH;
+            T x_re[CH], x_im[CH], m_re[CH], m_im[CH];
+            static_for<0, CH>([&](auto i) {
+                constexpr int I = decltype(i)::value, J = C0 + I;
+                const size_t urow = (size_t)(J * M) << a.log_s_in, mrow = (size_t)((P - 1 - J) * M) << a.log_s_in;
+                x_re[I] = (pr + urow)[voff];
+                x_im[I] = (pi + urow)[voff];
+                m_re[I] = (qr + mrow)[moff];
+                m_im[I] = (qi + mrow)[moff];
+            });
+            static_for<0, CH>([&](auto i) {
+                constexpr int I = decltype(i)::value, J = C0 + I;
+                const cx u = twu[J * M];
+                const T c_h = gr * u.x - gi * u.y, s_h = gr * u.y + gi * u.x;  // 0.5 W_N^(n M + g)
+                // algorithms/r2c.rs:263-433 (the arithmetic of r2c.hip: c2r_preprocess_kernel)
+                const T re_first = x_re[I], im_first = x_im[I], re_second = m_re[I], im_second = -m_im[I];
+                const T zx_re = (T)0.5 * (re_first + re_second), zx_im = (T)0.5 * (im_first + im_second);
+                const T dr = re_first - re_second, di = im_first - im_second;
+                const T zy_re = c_h * dr + s_h * di, zy_im = c_h * di - s_h * dr;
+                r.re[J] = zx_im + zy_re;  // positional re = z_im, positional im = z_re: the swap-trick inverse
+                r.im[J] = zx_re - zy_im;
+            });
+        });
+    }
+};
+
+template <typename T, int LR, int LC, int LP, bool SEQ>
+__global__ void __launch_bounds__(1 << (LR + LC - LP)) c2r_first_pass_kernel(const TileArgs a, const C2rFuseArgs f) {
+    using CB = C2rFirstBody<T, LR, LC, LP, SEQ>;
+    using Body = typename CB::Body;
+    using cx = cx_t<T>;
+    constexpr int NT = Body::NT;
+    pin_tile_args(a);
+
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T *ex_re = reinterpret_cast<T *>(smem);
+    cx *l_twr = reinterpret_cast<cx *>(smem + (size_t)Body::EXCH * sizeof(T) * (Body::PLANE_SEQ ? 1 : 2));
+    const typename Body::Shared sh{ex_re, Body::PLANE_SEQ ? ex_re : ex_re + Body::EXCH, l_twr, l_twr};
+
+    int tid = threadIdx.x;
+    unsigned wave_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
+    auto fresh_tid = [&]() {  // see tile_fft_kernel
+        asm volatile("" : "+s"(wave_base));
+        return (int)(wave_base | __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
+    };
+    typename Body::Regs r;
+    unsigned t = blockIdx.x;
+    if (t < a.tiles_total) {  // the first tile's loads go out before the table is staged
+        CB::locate(a, t, r);
+        CB::load_pre(a, f, tid, r);
+    }
+    for (int i = tid; i < Body::TWR; i += NT) l_twr[i] = reinterpret_cast<const cx *>(a.twr)[i];
+    __syncthreads();
+
+    auto exchange = [&](auto e) {
+        constexpr int E = decltype(e)::value;
+        tid = fresh_tid();
+        if constexpr (!Body::PLANE_SEQ) {
+            __syncthreads();
+            Body::template ex_write<E>(sh, tid, r, 0);
+            Body::template ex_write<E>(sh, tid, r, 1);
+            __syncthreads();
+            Body::template ex_read<E>(sh, tid, r, 0);
+            Body::template ex_read<E>(sh, tid, r, 1);
+        } else {
+            __syncthreads();
+            Body::template ex_write<E>(sh, tid, r, 0);
+            __syncthreads();
+            Body::template ex_read<E>(sh, tid, r, 0);
+            __syncthreads();
+            Body::template ex_write<E>(sh, tid, r, 1);
+            __syncthreads();
+            Body::template ex_read<E>(sh, tid, r, 1);
+        }
+    };
+    auto do_step = [&](auto i) {
+        tid = fresh_tid();
+        Body::template step<decltype(i)::value>(sh, tid, r);
+    };
+    while (t < a.tiles_total) {
+        Body::chain(do_step, exchange);
+        tid = fresh_tid();
+        Body::store(a, tid, r);
+        t += gridDim.x;
+        if (t < a.tiles_total) {
+            tid = fresh_tid();
+            CB::locate(a, t, r);
+            CB::load_pre(a, f, tid, r);
+        }
+    }
+}
+
+template <typename T, int LR, int LC, int LP, bool SEQ>
+hipError_t launch_c2r_first_inst(unsigned grid, hipStream_t stream, const TileArgs &a, const C2rFuseArgs &f, bool query_only,
+                                 int *blocks_per_cu, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    using Body = TileBody<T, LR, LC, LP, false, true, SEQ>;
+    auto kern = c2r_first_pass_kernel<T, LR, LC, LP, SEQ>;
+    const size_t lds = Body::lds_bytes(a.tw_bits);
+    if (lds > (size_t)160 * 1024) {
+        if (query_only && blocks_per_cu) *blocks_per_cu = 0;
+        return query_only ? hipSuccess : hipErrorInvalidValue;
+    }
+    static PerDeviceLimit lds_limit;
+    if (hipError_t e = raise_lds_limit(lds_limit, reinterpret_cast<const void *>(kern), lds); e != hipSuccess) return e;
+    if (query_only) {
+        hipFuncAttributes fa;
+        hipError_t e = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(kern));
+        if (e != hipSuccess) return e;
+        const int alloc = ((fa.numRegs + 7) / 8) * 8, waves_per_wg = Body::NT / 64;
+        int waves_per_simd = alloc > 0 ? 512 / alloc : 8;
+        if (waves_per_simd > 8) waves_per_simd = 8;
+        int b = waves_per_simd * 4 / waves_per_wg;
+        const int by_lds = (int)((160 * 1024) / lds), by_waves = 32 / waves_per_wg;
+        if (by_lds < b) b = by_lds;
+        if (by_waves < b) b = by_waves;
+        *blocks_per_cu = b < 1 ? 1 : b;
+        return hipSuccess;
+    }
+    if (ev_start && ev_stop)
+        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(Body::NT), (uint32_t)lds, stream, ev_start, ev_stop, 0, a, f);
+    else
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(Body::NT), lds, stream, a, f);
+    return hipGetLastError();
+}
+
+// thread-by-thread host execution (tests/emu): the same phase functions
+template <typename T, int LR, int LC, int LP, bool SEQ> void emulate_c2r_first_pass(const TileArgs &a, const C2rFuseArgs &f) {
+    using CB = C2rFirstBody<T, LR, LC, LP, SEQ>;
+    using Body = typename CB::Body;
+    using Regs = typename Body::Regs;
+    constexpr int NT = Body::NT;
+    std::vector<T> ex((size_t)Body::EXCH * 2);
+    const typename Body::Shared sh{ex.data(), Body::PLANE_SEQ ? ex.data() : ex.data() + Body::EXCH,
+                                   reinterpret_cast<const cx_t<T> *>(a.twr), reinterpret_cast<const cx_t<T> *>(a.twr)};
+    std::vector<Regs> regs(NT);
+    auto exchange = [&](auto e) {
+        constexpr int E = decltype(e)::value;
+        if constexpr (!Body::PLANE_SEQ) {
+            for (int t = 0; t < NT; ++t) {
+                Body::template ex_write<E>(sh, t, regs[t], 0);
+                Body::template ex_write<E>(sh, t, regs[t], 1);
+            }
+            for (int t = 0; t < NT; ++t) {
+                Body::template ex_read<E>(sh, t, regs[t], 0);
+                Body::template ex_read<E>(sh, t, regs[t], 1);
+            }
+        } else {
+            for (int plane = 0; plane < 2; ++plane) {
+                for (int t = 0; t < NT; ++t) Body::template ex_write<E>(sh, t, regs[t], plane);
+                for (int t = 0; t < NT; ++t) Body::template ex_read<E>(sh, t, regs[t], plane);
+            }
+        }
+    };
+    auto do_step = [&](auto i) {
+        for (int t = 0; t < NT; ++t) Body::template step<decltype(i)::value>(sh, t, regs[t]);
+    };
+    for (unsigned tile = 0; tile < a.tiles_total; ++tile) {
+        for (int t = 0; t < NT; ++t) {
+            CB::locate(a, tile, regs[t]);
+            CB::load_pre(a, f, t, regs[t]);
+        }
+        Body::chain(do_step, exchange);
+        for (int t = 0; t < NT; ++t) Body::store(a, t, regs[t]);
+    }
+}
+
+}  // namespace phast

@@ -58,7 +58,8 @@ struct C2rPreArgs {
     unsigned tw_bits;
     unsigned batch;
 };
-template <typename T> hipError_t launch_c2r_preprocess(const C2rPreArgs &a, hipStream_t stream);
+template <typename T>
+hipError_t launch_c2r_preprocess(const C2rPreArgs &a, hipStream_t stream, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 
 // ---- twiddle.hip: block (r, c) *= W_N^((row0 + r) * (col0 + c)), N = 2^log_n (four-step inter-factor twiddle) ----
 struct TwiddleGridArgs {

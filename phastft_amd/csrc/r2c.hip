@@ -102,14 +102,17 @@ template <typename T> hipError_t launch_untangle(const UntangleArgs &a, hipStrea
         hipLaunchKernelGGL(untangle_kernel<T>, grid_for(a.half / 2 + 1, a.batch), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
-template <typename T> hipError_t launch_c2r_preprocess(const C2rPreArgs &a, hipStream_t stream) {
-    hipLaunchKernelGGL(c2r_preprocess_kernel<T>, grid_for(a.half, a.batch), dim3(256), 0, stream, a);
+template <typename T> hipError_t launch_c2r_preprocess(const C2rPreArgs &a, hipStream_t stream, hipEvent_t e0, hipEvent_t e1) {
+    if (e0 && e1)
+        hipExtLaunchKernelGGL(c2r_preprocess_kernel<T>, grid_for(a.half, a.batch), dim3(256), 0, stream, e0, e1, 0, a);
+    else
+        hipLaunchKernelGGL(c2r_preprocess_kernel<T>, grid_for(a.half, a.batch), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 
 template hipError_t launch_untangle<float>(const UntangleArgs &, hipStream_t, hipEvent_t, hipEvent_t);
 template hipError_t launch_untangle<double>(const UntangleArgs &, hipStream_t, hipEvent_t, hipEvent_t);
-template hipError_t launch_c2r_preprocess<float>(const C2rPreArgs &, hipStream_t);
-template hipError_t launch_c2r_preprocess<double>(const C2rPreArgs &, hipStream_t);
+template hipError_t launch_c2r_preprocess<float>(const C2rPreArgs &, hipStream_t, hipEvent_t, hipEvent_t);
+template hipError_t launch_c2r_preprocess<double>(const C2rPreArgs &, hipStream_t, hipEvent_t, hipEvent_t);
 
 }  // namespace phast

@@ -60,6 +60,29 @@ inline bool r2c_shape_ok(unsigned lr, unsigned lc, unsigned lp, size_t elem_byte
     return r2c_shape_fits((int)lr, (int)lc, (int)lp, elem_bytes) && shape_exists(lr, lc, lp, elem_bytes);
 }
 
+// the first pass of an inverse real transform's inner FFT with the preprocess fused into its load (c2r_fused.hpp).
+// Included by tile_f64_c2r.hip / tile_f32_c2r.hip only.
+#define PHAST_C2R_DISPATCH(T_)                                                                                              \
+    template <> hipError_t launch_c2r_first<T_>(int lr, int lc, int lp, unsigned grid, hipStream_t s, const TileArgs &a,     \
+                                                const C2rFuseArgs &f, bool q, int *b, hipEvent_t e0, hipEvent_t e1) {         \
+        PHAST_TILE_SHAPES(PHAST_C2R_CASE_##T_)                                                                              \
+        if constexpr (sizeof(T_) == 4) {                                                                                    \
+            PHAST_TILE_SHAPES_F32(PHAST_C2R_CASE_##T_)                                                                      \
+        }                                                                                                                   \
+        return hipErrorInvalidValue;                                                                                        \
+    }
+struct C2rFuseArgs;
+template <typename T>
+hipError_t launch_c2r_first(int lr, int lc, int lp, unsigned grid, hipStream_t s, const TileArgs &a, const C2rFuseArgs &f, bool q, int *b,
+                            hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+// (a thread holds its own points and their partners while z is formed: shapes whose budget that exceeds keep the sweep)
+constexpr bool c2r_shape_fits(int lr, int lc, int lp, size_t elem_bytes) {
+    return !(elem_bytes == 8 && lr == 10 && lc == 4 && lp == 4);  // 1024 threads x 16 f64 points: 2 spilled registers
+}
+inline bool c2r_shape_ok(unsigned lr, unsigned lc, unsigned lp, size_t elem_bytes) {
+    return c2r_shape_fits((int)lr, (int)lc, (int)lp, elem_bytes) && shape_exists(lr, lc, lp, elem_bytes);
+}
+
 // defined in tile_f64_a.hip, tile_f64_bc.hip, tile_f32_a.hip, tile_f32_bc.hip
 hipError_t launch_tile_f64_a(int lr, int lc, int lp, unsigned grid, hipStream_t s, const TileArgs &a, bool q, int *b, size_t *l,
                            hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);

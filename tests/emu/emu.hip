@@ -12,6 +12,7 @@
 #include "wave_fft.hpp"
 #include "quad_fft.hpp"
 #include "r2c_fused.hpp"
+#include "c2r_fused.hpp"
 #include "tile_dispatch.hpp"
 
 namespace phast {
@@ -144,6 +145,75 @@ static int emu_r2c_fused(const T *in, unsigned log_n, T *ore, T *oim, const unsi
         fa.tiles_per_xform = (1u << (p.log_s_in - p.lc - 1)) + 1u;
         fa.tiles_total = fa.tiles_per_xform;
         if (!emu_r2c_last<T>(p, ta, fa)) return 3;
+    }
+    return 0;
+}
+
+// inverse real transform (half-spectrum of 2^(log_n - 1) + 1 bins -> 2^log_n reals) through the FUSED first pass
+// (c2r_fused.hpp): the inner transform's passes as emu_exec runs them, the first one forming z on load, the last one storing
+// (im, re) pairs scaled by 1/h.  Returns 3 when the plan's first pass has no fused form.
+template <typename T> static bool emu_c2r_first(const PassGeom &p, const TileArgs &a, const C2rFuseArgs &f) {
+#define PHAST_EMU_C2R(LR_, LC_, LP_)                                                        \
+    if constexpr (c2r_shape_fits(LR_, LC_, LP_, sizeof(T))) {                               \
+        if (p.lr == LR_ && p.lc == LC_ && p.lp == LP_) {                                    \
+            emulate_c2r_first_pass<T, LR_, LC_, LP_, plane_seq_v<T, LP_>>(a, f);            \
+            return true;                                                                    \
+        }                                                                                   \
+    }
+    PHAST_TILE_SHAPES(PHAST_EMU_C2R)
+    if constexpr (sizeof(T) == 4) {
+        PHAST_TILE_SHAPES_F32(PHAST_EMU_C2R)
+    }
+#undef PHAST_EMU_C2R
+    return false;
+}
+template <typename T>
+static int emu_c2r_fused(const T *ire, const T *iim, unsigned log_n, T *out, size_t batch, size_t in_dist, const unsigned *lrs_in,
+                         size_t np_in, unsigned tile_log_and_lp) {
+    const unsigned L = log_n - 1;
+    const size_t h = (size_t)1 << L;
+    const unsigned tile_log = tile_log_and_lp & 0xff;
+    unsigned lp = (tile_log_and_lp >> 8) ? (tile_log_and_lp >> 8) : 4;
+    std::vector<unsigned> lrs(lrs_in, lrs_in + np_in), tls(1, tile_log);
+    if (lrs.empty()) {
+        if (tile_log != 1 || !single_plan<T>(L, lrs, tls, lp)) heuristic_plan<T>(L, tile_log <= 1, lrs, tls, lp);
+    }
+    std::vector<PassGeom> ps;
+    if (!make_passes(L, lrs, tls, ps, lp, sizeof(T))) return 1;
+    const PassGeom &q = ps.front();
+    if (ps.size() < 2 || q.wave || q.quad || !q.transpose || !c2r_shape_ok(q.lr, q.lc, q.lp, sizeof(T)) || q.log_s_in < q.lc + 1) return 3;
+    const size_t sd = (size_t)scratch_elems(ps, L);
+    std::vector<T> s_re(sd * batch), s_im(sd * batch);
+    for (size_t i = 0; i < ps.size(); ++i) {
+        const PassGeom &p = ps[i];
+        std::vector<cx_t<T>> twr = p.quad ? host_twq<T>() : host_twr<T>(1u << p.lr), tw3;
+        if (p.pre_tw) tw3 = host_tw3<T>(p.log_mod(), p.tw_bits);
+        TileArgs ta{};
+        const bool first = i == 0, last = i + 1 == ps.size();
+        ta.in_re = first ? (const void *)ire : (const void *)s_re.data();
+        ta.in_im = first ? (const void *)iim : (const void *)s_im.data();
+        ta.in_dist = first ? in_dist : sd;
+        ta.out_re = last ? out : s_re.data();
+        ta.out_im = last ? nullptr : s_im.data();
+        ta.out_dist = last ? h : sd;  // in (im, re) pairs
+        ta.out_interleaved = last ? 2 : 0;
+        ta.scale = last ? 1.0 / (double)h : 1.0;
+        ta.tw3 = tw3.data();
+        ta.twr = twr.data();
+        geom_to_args(p, L, batch, ta);
+        if (!first) {
+            if (!emu_pass<T>(p, ta)) return 2;
+            continue;
+        }
+        const unsigned nb = tw3_bits_for(log_n);
+        const std::vector<cx_t<T>> tw3n = host_tw3<T>(log_n, nb);
+        std::vector<cx_t<T>> twu((size_t)1 << p.lr);
+        for (size_t k = 0; k < twu.size(); ++k) twu[k] = twiddle_t<T>(k, 2ull << p.lr);
+        C2rFuseArgs fa{};
+        fa.tw3n = tw3n.data();
+        fa.twn_bits = nb;
+        fa.twu = twu.data();
+        if (!emu_c2r_first<T>(p, ta, fa)) return 3;
     }
     return 0;
 }
@@ -311,6 +381,14 @@ int phast_emu_fft_f32_modes(const float *in_re, const float *in_im, unsigned in_
 #if !defined(EMU_PART) || EMU_PART == 4
 int phast_emu_r2c_fused_f32(const float *in, unsigned log_n, float *ore, float *oim, const unsigned *lrs, size_t np, unsigned tile_log) {
     return phast::emu_r2c_fused<float>(in, log_n, ore, oim, lrs, np, tile_log);
+}
+int phast_emu_c2r_fused_f32(const float *ire, const float *iim, unsigned log_n, float *out, size_t batch, size_t in_dist,
+                            const unsigned *lrs, size_t np, unsigned tile_log) {
+    return phast::emu_c2r_fused<float>(ire, iim, log_n, out, batch, in_dist, lrs, np, tile_log);
+}
+int phast_emu_c2r_fused_f64(const double *ire, const double *iim, unsigned log_n, double *out, size_t batch, size_t in_dist,
+                            const unsigned *lrs, size_t np, unsigned tile_log) {
+    return phast::emu_c2r_fused<double>(ire, iim, log_n, out, batch, in_dist, lrs, np, tile_log);
 }
 int phast_emu_r2c_fused_f64(const double *in, unsigned log_n, double *ore, double *oim, const unsigned *lrs, size_t np, unsigned tile_log) {
     return phast::emu_r2c_fused<double>(in, log_n, ore, oim, lrs, np, tile_log);

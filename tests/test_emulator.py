@@ -324,3 +324,59 @@ def test_r2c_fused_last_pass_vs_oracle_and_rfft(emu, oracle, log_n):
             assert oim[0] == 0 and oim[-1] == 0  # r2c.rs:161-166: exact zeros
             assert np.max(np.abs(got - ref)) <= (1e-11 if dtype == np.float64 else 2e-3) * np.sqrt(n), "a single bin is off"
     assert ran >= 4, ran
+
+
+def _emu_c2r(emu, ire, iim, n, batch=1, in_dist=None, lrs=(), tile_log=0, points_log=0):
+    L = int(np.log2(n))
+    out = np.zeros(n * batch, ire.dtype)
+    arr = (C.c_uint * max(1, len(lrs)))(*lrs)
+    fn = emu.phast_emu_c2r_fused_f64 if ire.dtype == np.float64 else emu.phast_emu_c2r_fused_f32
+    rc = fn(ire.ctypes.data_as(C.c_void_p), iim.ctypes.data_as(C.c_void_p), C.c_uint(L), out.ctypes.data_as(C.c_void_p),
+            C.c_size_t(batch), C.c_size_t(in_dist or n // 2 + 1), arr, C.c_size_t(len(lrs)), C.c_uint(tile_log | (points_log << 8)))
+    return rc, out
+
+
+@pytest.mark.parametrize("log_n", [15, 16, 17, 18, 19, 20, 21])
+def test_c2r_fused_first_pass_vs_oracle_and_irfft(emu, oracle, log_n):
+    """round 3 (c2r_fused.hpp): the inner transform's FIRST pass loads X[k] and its partner X[h - k] (mirrored column, rows
+    reversed; X[h] for k = 0) and forms z in registers -- no preprocess sweep, no workspace.  The library's plans and
+    forced ones (two and three passes; 8, 16 and 32 points per thread -- incl. the chunked loads of the wide shapes),
+    both types: every output against the oracle's c2r and numpy's irfft; a ragged batch of two (in_dist > h + 1)."""
+    n = 1 << log_n
+    h1 = n // 2 + 1
+    rng = np.random.default_rng(100 + log_n)
+    ran = 0
+    forced = {15: [((7, 7), 12, 3), ((7, 7), 13, 4)], 16: [((8, 7), 12, 3), ((8, 7), 13, 5)], 17: [((8, 8), 13, 4), ((8, 8), 12, 3)],
+              18: [((9, 8), 12, 3), ((9, 8), 14, 4)], 19: [((6, 6, 6), 12, 4), ((9, 9), 14, 5)], 20: [((7, 6, 6), 12, 3), ((10, 9), 14, 4)],
+              21: [((7, 7, 6), 12, 3), ((10, 10), 14, 5), ((10, 10), 15, 5)]}[log_n]
+    for dtype, tol_or, tol_np in ((np.float64, 1e-9, 1e-13), (np.float32, 1e-5, 1e-5)):
+        x = rng.uniform(-1, 1, n)
+        spec = np.fft.rfft(x)
+        spec.imag[0] = spec.imag[-1] = 0.0
+        ire, iim = spec.real.astype(dtype), spec.imag.astype(dtype)
+        want = np.zeros(n, dtype)
+        (oracle.c2r_fft_f64 if dtype == np.float64 else oracle.c2r_fft_f32)(ire.copy(), iim.copy(), want)
+        ref = np.fft.irfft(ire.astype(np.float64) + 1j * iim.astype(np.float64), n)
+        for lrs, tl, lp in [((), 0, 0), ((), 1, 0), ((), 14, 0)] + forced:
+            rc, out = _emu_c2r(emu, ire, iim, n, lrs=lrs, tile_log=tl, points_log=lp)
+            if rc in (1, 3):  # not a plan of this type (32768-point tiles are f32 only) / first pass without a fused form
+                continue
+            assert rc == 0, (rc, lrs, tl, lp)
+            ran += 1
+            den = np.sqrt(np.sum(ref ** 2))
+            assert np.sqrt(np.sum((out - ref) ** 2)) / den <= tol_np, (dtype, lrs, tl, lp)
+            assert np.sqrt(np.sum((out.astype(np.float64) - want) ** 2)) / den <= tol_or, (dtype, lrs, tl, lp)
+            assert np.max(np.abs(out - ref)) <= (1e-13 if dtype == np.float64 else 1e-5) * np.sqrt(n), "a single sample is off"
+        if log_n == 16:  # two transforms, spectra 7 elements further apart than they are long
+            dist = h1 + 7
+            bre, bim = np.zeros(2 * dist, dtype), np.zeros(2 * dist, dtype)
+            spec2 = np.fft.rfft(rng.uniform(-1, 1, n))
+            spec2.imag[0] = spec2.imag[-1] = 0.0
+            bre[:h1], bim[:h1] = ire, iim
+            bre[dist:dist + h1], bim[dist:dist + h1] = spec2.real.astype(dtype), spec2.imag.astype(dtype)
+            rc, out = _emu_c2r(emu, bre, bim, n, batch=2, in_dist=dist)
+            assert rc == 0
+            ref2 = np.fft.irfft(bre[dist:dist + h1].astype(np.float64) + 1j * bim[dist:dist + h1].astype(np.float64), n)
+            for got, r in ((out[:n], ref), (out[n:], ref2)):
+                assert np.sqrt(np.sum((got - r) ** 2)) / np.sqrt(np.sum(r ** 2)) <= tol_np
+    assert ran >= 6, ran

@@ -559,3 +559,82 @@ def test_r2c_fused_last_pass_vs_oracle(gpu, oracle, k, batch, dt):
     y = torch.empty_like(x)
     gpu.c2r_fft_batched(ore, oim, y, pl, batch)
     assert float((y - x0).abs().max()) < (1e-10 if dt == "f64" else 2e-4)
+
+
+# ---------------------------------------------------------------- C2R with the preprocess fused into the first pass
+@pytest.mark.parametrize("k,batch,dt", [(24, 1, "f32"), (24, 1, "f64"), (26, 1, "f32"), (25, 1, "f64"), (20, 32, "f32"), (16, 512, "f32"),
+                                        (19, 32, "f64"), (17, 128, "f64"), (22, 4, "f32"), (21, 1, "f64"), (15, 3, "f64"), (15, 5, "f32")])
+def test_c2r_fused_first_pass_vs_oracle(gpu, oracle, k, batch, dt):
+    """c2r_fused.hpp: the inner transform's first pass loads X[k] and its partner X[h - k] and forms z in registers; there is
+    no preprocess sweep and no workspace.  Every output of the first and the last transform of the batch against the
+    oracle's c2r and numpy's irfft, the half-spectrum untouched (r2c.rs:740 takes `&[T]`) -- and the number of kernels
+    proves which path ran."""
+    import torch
+
+    n = 1 << k
+    h1 = n // 2 + 1
+    ndt, tdt = (np.float64, torch.float64) if dt == "f64" else (np.float32, torch.float32)
+    pl = (gpu.PlannerR2c64 if dt == "f64" else gpu.PlannerR2c32)(n)
+    # spectra of real signals (any half-spectrum with real X[0], X[h] would do): the library's own forward transform
+    x = torch.empty(n * batch, dtype=tdt, device="cuda")
+    gpu.fill_uniform(x, None, n, seed=0xC2C2, first_id=5)
+    ire = torch.zeros(h1 * batch, dtype=tdt, device="cuda")
+    iim = torch.zeros_like(ire)
+    gpu.r2c_fft_batched(x, ire, iim, pl, batch)
+    ire0, iim0 = ire.clone(), iim.clone()
+    y = torch.full((n * batch,), float("nan"), dtype=tdt, device="cuda")
+    gpu.c2r_fft_batched(ire, iim, y, pl, batch)
+    torch.cuda.synchronize()
+    assert torch.equal(ire, ire0) and torch.equal(iim, iim0)
+    inner = pl.describe()
+    ms = pl.time_c2r_passes(ire[:h1], iim[:h1], torch.empty(n, dtype=tdt, device="cuda"), reps=1)
+    # the inner plans have two or three passes; a fourth (third) kernel would be the preprocess sweep
+    assert len(ms) <= 3 and (len(ms) == 2 or "3p[" in inner), (ms, inner)
+    tol_or, tol_np = (1e-9, 1e-13) if dt == "f64" else (1e-5, 1e-5)
+    for b in (0, batch - 1):
+        h_re, h_im = ire0[b * h1:(b + 1) * h1].cpu().numpy(), iim0[b * h1:(b + 1) * h1].cpu().numpy()
+        want = np.zeros(n, ndt)
+        (oracle.c2r_fft_f64 if dt == "f64" else oracle.c2r_fft_f32)(h_re.copy(), h_im.copy(), want)
+        got = y[b * n:(b + 1) * n].cpu().numpy().astype(np.float64)
+        ref = np.fft.irfft(h_re.astype(np.float64) + 1j * h_im.astype(np.float64), n)
+        den = np.sqrt(np.sum(ref ** 2))
+        assert np.sqrt(np.sum((got - want) ** 2)) / den <= tol_or, (b, inner)
+        assert np.sqrt(np.sum((got - ref) ** 2)) / den <= tol_np, (b, inner)
+        assert np.max(np.abs(got - ref)) <= (1e-13 if dt == "f64" else 1e-5) * np.sqrt(n) * max(1.0, np.max(np.abs(ref))), (b, inner)
+    # the round trip gives the signal back
+    assert float((y - x).abs().max()) < (1e-10 if dt == "f64" else 2e-4)
+
+
+def test_c2r_fused_ragged_batch_and_no_workspace(gpu, oracle):
+    """Half-spectra further apart than they are long (in_dist > h + 1) through the C ABI, and the planner allocates nothing
+    for the call beyond the inner transform's scratch (the preprocess workspace of N values per transform is gone)."""
+    import ctypes as C
+
+    import torch
+
+    from phastft_amd import _lib
+
+    n, batch = 1 << 18, 6
+    h1 = n // 2 + 1
+    dist = h1 + 61
+    pl = gpu.PlannerR2c64(n)
+    x = torch.empty(n * batch, dtype=torch.float64, device="cuda")
+    gpu.fill_uniform(x, None, n, seed=7, first_id=0)
+    ore = torch.zeros(h1 * batch, dtype=torch.float64, device="cuda")
+    oim = torch.zeros_like(ore)
+    gpu.r2c_fft_batched(x, ore, oim, pl, batch)
+    ire = torch.full((dist * batch,), 3.25, dtype=torch.float64, device="cuda")
+    iim = torch.full((dist * batch,), -1.5, dtype=torch.float64, device="cuda")
+    ire.view(batch, dist)[:, :h1] = ore.view(batch, h1)
+    iim.view(batch, dist)[:, :h1] = oim.view(batch, h1)
+    y = torch.zeros(n * batch, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    rc = _lib.lib().phast_c2r_fft_f64_dev(C.c_void_p(ire.data_ptr()), C.c_void_p(iim.data_ptr()), C.c_void_p(y.data_ptr()),
+                                          C.c_size_t(batch), C.c_size_t(dist), C.c_size_t(n), pl._h, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    grown = free0 - torch.cuda.mem_get_info()[0]
+    assert grown < batch * n * 8, grown  # no [batch][2][n/2] workspace (12 MiB here); the scratch existed already
+    assert float((y - x).abs().max()) < 1e-10
+    assert bool((ire.view(batch, dist)[:, h1:] == 3.25).all()) and bool((iim.view(batch, dist)[:, h1:] == -1.5).all())
