@@ -17,6 +17,7 @@ complex samples transformed per second over the whole job, inputs resident in HB
       n2p26_forward   (the second half of BASELINE's metric: N=2^26, 1 GiB per transform, three 2 GiB-traffic passes)
       n2p26_roundtrip (configs[2]: forward + inverse on the same buffers, error against the input checked)
       r2c_f32_2p24    (configs[3]: r2c_fft_f32, N=2^24)
+      c2r_f32_2p24    (its inverse, c2r_fft_f32 -- SURVEY.md 8f-1)
     and "weak_scaling_reference": one rank's shard of the N > 1 workload on this one GPU.
   * N > 1  -> configs[4]: 8192 independent N=2^20 transforms per 8 GPUs = 1024 per GPU, fixed per-GPU work
     ("scaling": "weak"); one step = every rank transforms its 1024-transform shard in place.  The path has no
@@ -411,6 +412,42 @@ def config_r2c(P, torch, dev, steps: int, cpu: bool):
     return out
 
 
+def config_c2r(P, torch, dev, steps: int):
+    """The inverse of configs[3] (the first NEXT row): c2r_fft_f32 at N = 2^24 on a cold ring, per-kernel
+    times from the library's event hook.  Algorithmic bytes 8(N/2+1) in + 4N out."""
+    n = 1 << 24
+    pl = P.PlannerR2c32(n)
+    ring = 9
+    half1 = n // 2 + 1
+    pitch = (half1 + 63) // 64 * 64
+    ires = torch.empty(ring * pitch, dtype=torch.float32, device=dev).uniform_(-1, 1)
+    iims = torch.empty(ring * pitch, dtype=torch.float32, device=dev).uniform_(-1, 1)
+    ys = torch.empty(ring * n, dtype=torch.float32, device=dev)
+    sets = [(ires[i * pitch:i * pitch + half1], iims[i * pitch:i * pitch + half1], ys[i * n:(i + 1) * n]) for i in range(ring)]
+    P.c2r_fft_f32_with_planner(*sets[0], pl)
+
+    def run():
+        for i in range(steps):
+            P.c2r_fft_f32_with_planner(*sets[i % ring], pl)  # the half-spectrum is read-only (r2c.rs:740): no refill needed
+
+    run()
+    ms = event_ms(torch, run) / steps
+    acc = None
+    for i in range(ring):
+        t = pl.time_c2r_passes(*sets[i], reps=1)
+        acc = t if acc is None else [a + b for a, b in zip(acc, t)]
+    pass_ms = [a / ring for a in acc]
+    c2r_bytes = 4 * n + 8 * half1
+    out = {"workload": "c2r_fft_f32 N=2^24, N/2+1 planar inputs -> real output (inverse of BASELINE configs[3])",
+           "value": n / (ms * 1e-3) / 1e9, "unit": "GSamples/s (real samples)", "steps": steps, "ms_per_step": ms, "dtype": "f32",
+           "plan": pl.describe(), "pass_ms": pass_ms, "passes": len(pass_ms),
+           "note": "first pass forms z from the half-spectrum on load (c2r_first_pass_kernel): no preprocess sweep",
+           "algorithmic_bytes_per_transform": c2r_bytes, "transform_frac": c2r_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    del sets, ires, iims, ys, pl
+    torch.cuda.empty_cache()
+    return out
+
+
 def shard_on_one_gpu(P, torch, dev, shard: int, steps: int = 5):
     """The per-GPU workload of the --gpus N > 1 runs (BASELINE configs[4]: `shard` transforms of 2^20 per GPU,
     transformed in place per step) timed on this one GPU with HIP events: the denominator for weak-scaling
@@ -659,6 +696,7 @@ def main():
         if not multi and not args.no_configs:
             fwd, rt = config_n2p26(P, torch, dev, 5, cpu)
             out["configs"] = {"n2p26_forward": fwd, "n2p26_roundtrip": rt, "r2c_f32_2p24": config_r2c(P, torch, dev, 20, cpu),
+                              "c2r_f32_2p24": config_c2r(P, torch, dev, 20),
                               "f32_2p20": config_f32(P, torch, dev, 20, 20, cpu),
                               "f32_2p26": config_f32(P, torch, dev, 26, 5, cpu)}
             t26 = load_profiled_traffic_key("single_2p26", fwd["roofline"])

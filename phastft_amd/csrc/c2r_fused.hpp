@@ -24,6 +24,10 @@
 
 #include "tile_fft.hpp"
 
+#ifndef PHAST_C2R_PAIRS
+#define PHAST_C2R_PAIRS 1
+#endif
+
 namespace phast {
 
 struct C2rFuseArgs {
@@ -53,7 +57,12 @@ template <typename T, int LR, int LC, int LP, bool SEQ> struct C2rFirstBody {
         const unsigned pos = ((a.tiles_total & 7u) == 0u) ? (t & 7u) * (a.tiles_total >> 3) + (t >> 3) : t;
         r.xform = pos >> (unsigned)__builtin_ctz(a.tiles_per_xform);
         const unsigned ti = pos & (a.tiles_per_xform - 1u), q = ti >> 1;
+#if PHAST_C2R_PAIRS
         r.g0 = ((ti & 1u) ? a.tiles_per_xform - 1u - q : q) << LC;
+#else  // tools only: plain column order, the partner tile runs on another XCD at another time
+        (void)q;
+        r.g0 = ti << LC;
+#endif
     }
 
     // rows n = j M + tau of column g = g0 + col: X[k] from (row n, column g), X[h - k] from (row R - 1 - n, column M - g)
