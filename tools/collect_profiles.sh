@@ -26,6 +26,7 @@ pmc() {  # key, algorithmic bytes, out name, command...
 pmc single_2p20 33554432 single2p20 python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-graph --no-scaling-reference --no-configs
 pmc single_2p26 2147483648 single2p26 python $R/tools/prof_workloads.py big --iters 4
 pmc r2c_f32_2p24 134217728 r2c_f32_2p24 python $R/tools/prof_workloads.py r2c --iters 10
+pmc c2r_f32_2p24 134217728 c2r_f32_2p24 python $R/tools/prof_workloads.py c2r --iters 10
 pmc batch_2p20 34359738368 batch1024_2p20 python $R/tools/prof_workloads.py batch --batch 1024 --iters 3
 # 3. where the wave cycles go (SQ counters, one pass of 8)
 for w in single big; do

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Small fixed workloads for `rocprofv3 --kernel-trace --stats` / `--pmc` runs (profiles/).
 
-    python tools/prof_workloads.py single|batch|big|r2c|bitrev [--plan 10,10 --tile-log 13] [--iters K]
+    python tools/prof_workloads.py single|batch|big|r2c|c2r|bitrev [--plan 10,10 --tile-log 13] [--iters K]
 """
 import argparse
 import os
@@ -13,7 +13,7 @@ import torch  # noqa: E402
 import phastft_amd as P  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("what", choices=["single", "batch", "big", "r2c", "bitrev"])
+ap.add_argument("what", choices=["single", "batch", "big", "r2c", "c2r", "bitrev"])
 ap.add_argument("--plan", default="")
 ap.add_argument("--tile-log", type=int, default=12)
 ap.add_argument("--iters", type=int, default=20)
@@ -52,6 +52,15 @@ elif a.what == "r2c":
     oim = torch.empty_like(ore)
     for i in range(a.iters):
         P.r2c_fft_f32_with_planner(x, ore, oim, pl)
+    torch.cuda.synchronize()
+elif a.what == "c2r":
+    n = 1 << 24
+    pl = P.PlannerR2c32(n)
+    ire = torch.empty(n // 2 + 1, dtype=torch.float32, device="cuda").uniform_(-1, 1)
+    iim = torch.empty_like(ire).uniform_(-1, 1)
+    y = torch.empty(n, dtype=torch.float32, device="cuda")
+    for i in range(a.iters):
+        P.c2r_fft_f32_with_planner(ire, iim, y, pl)
     torch.cuda.synchronize()
 else:
     n = 26

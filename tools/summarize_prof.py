@@ -30,7 +30,7 @@ def counter(d, name):
     with open(find(d, "*counter_collection.csv")) as f:
         for row in csv.DictReader(f):
             kn = row.get("Kernel_Name", "")
-            if row.get("Counter_Name") != name or not any(t in kn for t in ("tile_fft_kernel", "wave_fft_kernel", "quad_fft_kernel", "untangle_kernel", "r2c_last_pass_kernel")):
+            if row.get("Counter_Name") != name or not any(t in kn for t in ("tile_fft_kernel", "wave_fft_kernel", "quad_fft_kernel", "untangle_kernel", "r2c_last_pass_kernel", "c2r_first_pass_kernel", "c2r_preprocess_kernel")):
                 continue
             per.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
     return per
