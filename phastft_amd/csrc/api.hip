@@ -845,9 +845,10 @@ template <typename T> struct Planner {
         const size_t sd = sstride();       // elements per transform and plane in the (padded) scratch
         T *s_re = d_scratch;               // plane layout: all re planes, then all im planes
         T *s_im = d_scratch + cap * sd;
-        const std::vector<PassDesc> &passes = in_mode == 3 ? plan_for_c2r(batch)
-                                              : (fuse && fuse_pays(batch < cap ? batch : cap)) ? plan_for_r2c(batch)
-                                                                                                 : plan_for(batch);
+        // R2C: fused or not is decided ONCE per call, from the size of a full chunk -- a smaller tail chunk follows the others
+        // (the caller runs the untangle sweep over the whole batch or not at all)
+        const bool r2c_fuse = fuse && in_mode != 3 && fuse_pays(batch < cap ? batch : cap);
+        const std::vector<PassDesc> &passes = in_mode == 3 ? plan_for_c2r(batch) : r2c_fuse ? plan_for_r2c(batch) : plan_for(batch);
         const size_t np = passes.size();
         for (size_t b0 = 0; b0 < batch; b0 += cap) {
             const size_t nb = batch - b0 < cap ? batch - b0 : cap;
@@ -900,7 +901,7 @@ template <typename T> struct Planner {
                     if (e != hipSuccess) return hip_fail(e, "c2r_first_pass launch");
                     continue;
                 }
-                if (last && fuse && in_mode != 3 && p.r2c_blocks > 0 && out_mode == 0 && scale == 1.0 && fuse_pays(nb)) {
+                if (last && r2c_fuse && p.r2c_blocks > 0 && out_mode == 0 && scale == 1.0) {
                     R2cFuseArgs fa{};
                     fa.tw3n = fuse->tw3n;
                     fa.twn_bits = fuse->twn_bits;

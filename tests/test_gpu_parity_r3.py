@@ -638,3 +638,42 @@ def test_c2r_fused_ragged_batch_and_no_workspace(gpu, oracle):
     assert grown < batch * n * 8, grown  # no [batch][2][n/2] workspace (12 MiB here); the scratch existed already
     assert float((y - x).abs().max()) < 1e-10
     assert bool((ire.view(batch, dist)[:, h1:] == 3.25).all()) and bool((iim.view(batch, dist)[:, h1:] == -1.5).all())
+
+
+def test_real_transforms_fused_passes_across_scratch_chunks(gpu, oracle):
+    """The chunk loop of Planner::exec under the fused real-transform passes: PHAST_SCRATCH_MB=128 holds 64 inner
+    transforms of 2^17 f64 points, a batch of 160 runs as 64 + 64 + 32.  R2C (last pass with the untangle: 64 x 2^17 points
+    are at the fusion threshold) and C2R (first pass with the preprocess) at the chunk boundaries against the oracle;
+    the round trip on every transform."""
+    import torch
+
+    n, batch = 1 << 18, 160
+    h1 = n // 2 + 1
+    old = os.environ.get("PHAST_SCRATCH_MB")
+    os.environ["PHAST_SCRATCH_MB"] = "128"
+    try:
+        pl = gpu.PlannerR2c64(n)
+        x = torch.empty(n * batch, dtype=torch.float64, device="cuda")
+        gpu.fill_uniform(x, None, n, seed=0x5EED, first_id=11)
+        ore = torch.zeros(h1 * batch, dtype=torch.float64, device="cuda")
+        oim = torch.zeros_like(ore)
+        gpu.r2c_fft_batched(x, ore, oim, pl, batch)
+        y = torch.zeros_like(x)
+        gpu.c2r_fft_batched(ore, oim, y, pl, batch)
+        torch.cuda.synchronize()
+    finally:
+        if old is None:
+            del os.environ["PHAST_SCRATCH_MB"]
+        else:
+            os.environ["PHAST_SCRATCH_MB"] = old
+    assert float((y - x).abs().max()) < 1e-10
+    for b in (0, 63, 64, 127, 128, 159):
+        h_x = x[b * n:(b + 1) * n].cpu().numpy()
+        o_re, o_im = np.zeros(h1), np.zeros(h1)
+        oracle.r2c_fft_f64(h_x.copy(), o_re, o_im)
+        g_re, g_im = ore[b * h1:(b + 1) * h1].cpu().numpy(), oim[b * h1:(b + 1) * h1].cpu().numpy()
+        assert rel_l2(g_re, g_im, o_re, o_im) <= 1e-9, b
+        want = np.zeros(n)
+        oracle.c2r_fft_f64(g_re.copy(), g_im.copy(), want)
+        got = y[b * n:(b + 1) * n].cpu().numpy()
+        assert np.sqrt(np.sum((got - want) ** 2) / np.sum(want ** 2)) <= 1e-9, b
