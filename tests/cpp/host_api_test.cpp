@@ -1,7 +1,9 @@
 // host_api_test.cpp -- the reference's own tests (lib.rs:238-461, r2c.rs:914-1540), re-read through the C++ host
 // side (include/phastft.hpp) over libphastft_hip.so.  Built by tests/test_cpp_host.py; with a GPU it runs the
 // numerical checks, without one it checks that argument asserts still panic and compute calls fail loudly.
+#include <algorithm>
 #include <cmath>
+#include <cstdint>
 #include <complex>
 #include <cstdio>
 #include <cstring>
@@ -190,6 +192,23 @@ int main(int argc, char **argv) {
         r2c_fft_f32(xf, fre, fim);
         c2r_fft_f32(fre, fim, fback);
         for (size_t i = 0; i < n; ++i) EXPECT(std::fabs(fback[i] - xf[i]) < 1e-2f * (1.0f + std::fabs(xf[i])));
+    }
+    // ---- the fused passes of the large real transforms (round 3: untangle in the last pass from 2^23 points, preprocess in
+    // the first pass's load): host slices in, host slices out, bounded pseudo-random signal ----
+    for (int k : {20, 24}) {
+        const size_t n = size_t(1) << k;
+        std::vector<float> xf(n), fre(n / 2 + 1), fim(n / 2 + 1), fback(n);
+        for (size_t i = 0; i < n; ++i) xf[i] = float((uint32_t(i) * 2654435761u >> 8) & 0xffffu) / 65536.0f - 0.5f;
+        PlannerR2c32 planner(n);
+        r2c_fft_f32_with_planner(xf, fre, fim, planner);
+        EXPECT(fim[0] == 0.0f && fim[n / 2] == 0.0f);
+        double dc = 0;
+        for (size_t i = 0; i < n; ++i) dc += xf[i];
+        EXPECT(std::fabs(fre[0] - dc) < 1e-3 * std::sqrt(double(n)));
+        c2r_fft_f32_with_planner(fre, fim, fback, planner);
+        float worst = 0;
+        for (size_t i = 0; i < n; ++i) worst = std::max(worst, std::fabs(fback[i] - xf[i]));
+        EXPECT(worst < 1e-4f);
     }
     // ---- bit reversal exact (bravo.rs:373-407) ----
     for (unsigned nb = 2; nb <= 18; ++nb) {
