@@ -804,7 +804,17 @@ template <typename T> struct Planner {
     // The fused R2C last pass runs HALF as many tiles, each twice as long: it pays once the tiles fill the chip -- from
     // 2^23 complex points in flight (profiles/r03_r2c_fused_ab.log: f32 N = 2^24 108.6 -> 89.9 us; below, one transform is
     // latency-bound and loses: N = 2^20 19.5 -> 31.6 us, 2^22 39.4 -> 42.9).
-    bool fuse_pays(size_t batch) const { return r2c_fuse_enabled() && batch * n >= ((size_t)1 << 23); }
+    static unsigned fuse_min_log() {  // PHAST_R2C_FUSE_MIN_LOG: tools (A/B of the threshold)
+        static const unsigned v = [] {
+            const char *e = std::getenv("PHAST_R2C_FUSE_MIN_LOG");
+            return (e && *e) ? (unsigned)std::atoi(e) : 0u;
+        }();
+        return v;
+    }
+    bool fuse_pays(size_t batch) const {
+        const unsigned min_log = fuse_min_log() ? fuse_min_log() : 23u;
+        return r2c_fuse_enabled() && batch * n >= ((size_t)1 << min_log);
+    }
     // `fuse` (R2C): the last pass takes the untangle with it where its fused form exists; *fused_out says whether it did
     int exec(const void *in_re, const void *in_im, size_t in_dist, unsigned in_mode, void *out_re, void *out_im,
              size_t out_dist, unsigned out_mode, size_t batch, double scale, hipStream_t stream,
