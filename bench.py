@@ -18,7 +18,9 @@ complex samples transformed per second over the whole job, inputs resident in HB
       n2p26_roundtrip (configs[2]: forward + inverse on the same buffers, error against the input checked)
       r2c_f32_2p24    (configs[3]: r2c_fft_f32, N=2^24)
       c2r_f32_2p24    (its inverse, c2r_fft_f32 -- SURVEY.md 8f-1)
-    and "weak_scaling_reference": one rank's shard of the N > 1 workload on this one GPU.
+    and "weak_scaling_reference": one rank's shard of the N > 1 workload on this one GPU; "host_slice_api": the same
+    transform called with HOST slices as the reference's callers hold them (H2D + kernels + D2H, PCIe-bound: the drop-in
+    cost, never `value`).
   * N > 1  -> configs[4]: 8192 independent N=2^20 transforms per 8 GPUs = 1024 per GPU, fixed per-GPU work
     ("scaling": "weak"); one step = every rank transforms its 1024-transform shard in place.  The path has no
     exchange step, so there is no data-path collective; RCCL (torch.distributed "nccl") only carries the barrier,
@@ -100,6 +102,27 @@ def cpu_baseline(budget_s: float = 8.0):
                                        f"({avail} schedulable); rayon::join emulated with OpenMP tasks (2-way bit "
                                        f"reversal, recursive join while size > 16384, spanning stages serial)"},
     }
+
+
+def host_slice_api(P, calls: int = 5):
+    """The drop-in cost: fft_64_dit_with_planner on HOST slices, as the reference's callers hold them --
+    H2D of 16 MiB, the transform, D2H, blocking.  PCIe-bound; reported beside `value`, never as it."""
+    import time
+
+    import numpy as np
+
+    rng = np.random.default_rng(0xCAFE)
+    re, im = rng.uniform(-1, 1, N), rng.uniform(-1, 1, N)
+    pl = P.PlannerDit64(N)
+    for _ in range(2):
+        P.fft_64_dit_with_planner(re, im, P.Direction.Forward, pl)
+    t0 = time.perf_counter()
+    for _ in range(calls):
+        P.fft_64_dit_with_planner(re, im, P.Direction.Forward, pl)
+    dt = (time.perf_counter() - t0) / calls
+    return {"ms_per_call": 1e3 * dt, "value": N / dt / 1e9, "unit": "GSamples/s", "calls": calls,
+            "bytes_over_pcie_per_s_GB": 32.0 * N / dt / 1e9,  # 16 MiB in + 16 MiB out, one after the other
+            "what": f"fft_64_dit_with_planner(host slices) N=2^{LOG_N}: H2D + 3 kernels + D2H, blocking (pageable numpy arrays)"}
 
 
 def cpu_leg(kind: str, n: int, iters: int):
@@ -693,6 +716,7 @@ def main():
         cpu = not multi and not args.no_cpu_baseline
         if cpu:
             out["cpu_baseline"] = cpu_baseline()
+            out["host_slice_api"] = host_slice_api(P)
         if not multi and not args.no_configs:
             fwd, rt = config_n2p26(P, torch, dev, 5, cpu)
             out["configs"] = {"n2p26_forward": fwd, "n2p26_roundtrip": rt, "r2c_f32_2p24": config_r2c(P, torch, dev, 20, cpu),
