@@ -109,7 +109,11 @@ void phast_planner_r2c64_free(phast_planner_r2c64 *p);
 int phast_planner_r2c32_new(size_t n, phast_planner_r2c32 **out);
 void phast_planner_r2c32_free(phast_planner_r2c32 *p);
 
-/* ---- C2C, host slices: lib.rs:143-226, algorithms/dit.rs:263,338 ---- */
+/* ---- C2C, host slices: lib.rs:143-226, algorithms/dit.rs:263,338 ----
+ * The forms without a planner argument make one per call in the reference (lib.rs:181,224).  Here a planner owns device
+ * memory, so the library keeps the few most recently used ones (per type, size, device; planes up to 64 MiB) and the
+ * second call of a size costs what the _with_planner form costs.  Same results, same errors; PHAST_PLANNER_CACHE=0 turns
+ * it off.  The same holds for the real-transform and interleaved forms below. */
 int phast_fft_64_dit(double *reals, size_t reals_len, double *imags, size_t imags_len, int direction); /* lib.rs:180 */
 int phast_fft_32_dit(float *reals, size_t reals_len, float *imags, size_t imags_len, int direction);   /* lib.rs:223 */
 int phast_fft_64_dit_with_planner(double *reals, size_t reals_len, double *imags, size_t imags_len,

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -1353,14 +1354,77 @@ template <typename T> static int fft_interleaved_host(T *signal, size_t n, int d
     return rc;
 }
 
+// The planner-less entry points (lib.rs:121,181,224; r2c.rs:522,599,696) make a planner per call in the reference.  Here a
+// planner owns device tables, a staging buffer and a scratch -- 0.2-0.8 ms to make plus the allocations, 1.2 ms of a 1.9 ms
+// call at N = 2^20 (tools/planner_cost.py) -- so the few most recently used ones are kept per type, size and device.
+// Invisible to the caller: same results, same errors (a failed construction is never cached), and a planner is immutable to
+// its users (planner.rs:38-39).  Large planners (planes above 64 MiB: the call is PCIe time, not planner time) are made and
+// dropped per call as before; PHAST_PLANNER_CACHE=0 turns the cache off.  The cache itself is never destroyed: at process
+// exit the HIP runtime may be gone before static destructors run.
+template <typename P> struct PlannerCache {
+    struct Entry {
+        size_t n;
+        int device;
+        std::shared_ptr<P> pl;
+        unsigned long long stamp;
+    };
+    static constexpr size_t kMaxEntries = 4;
+    std::mutex mu;
+    std::vector<Entry> entries;
+    unsigned long long clock = 0;
+
+    static bool enabled() {
+        static const bool v = [] {
+            const char *e = std::getenv("PHAST_PLANNER_CACHE");
+            return !(e && *e == '0');
+        }();
+        return v;
+    }
+    template <typename Make> int get(size_t n, size_t elem_bytes, Make &&make, std::shared_ptr<P> *out) {
+        int dev = -1;
+        const bool cacheable = enabled() && n != 0 && n <= ((size_t)64 << 20) / elem_bytes && hipGetDevice(&dev) == hipSuccess;
+        if (!cacheable) (void)hipGetLastError();
+        if (cacheable) {
+            std::lock_guard<std::mutex> lk(mu);
+            for (Entry &e : entries)
+                if (e.n == n && e.device == dev) {
+                    e.stamp = ++clock;
+                    *out = e.pl;
+                    return PHAST_OK;
+                }
+        }
+        P *raw = nullptr;
+        int rc = make(n, &raw);
+        if (rc) return rc;
+        out->reset(raw);
+        if (cacheable) {
+            std::shared_ptr<P> evicted;  // released outside the lock (frees device memory)
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (entries.size() >= kMaxEntries) {
+                    size_t lru = 0;
+                    for (size_t i = 1; i < entries.size(); ++i)
+                        if (entries[i].stamp < entries[lru].stamp) lru = i;
+                    evicted = std::move(entries[lru].pl);
+                    entries.erase(entries.begin() + (long)lru);
+                }
+                entries.push_back(Entry{n, dev, *out, ++clock});
+            }
+        }
+        return PHAST_OK;
+    }
+    static PlannerCache &instance() {
+        static PlannerCache *c = new PlannerCache();  // see above: deliberately not destroyed
+        return *c;
+    }
+};
+
 template <typename T> static int fft_host_noplanner(T *re, size_t re_len, T *im, size_t im_len, int direction) {
     // lib.rs:180-183: the planner is built from reals.len() first, so a bad length panics in the planner
-    Planner<T> *pl = nullptr;
-    int rc = planner_new(re_len, &pl);
+    std::shared_ptr<Planner<T>> pl;
+    int rc = PlannerCache<Planner<T>>::instance().get(re_len, sizeof(T), [](size_t n, Planner<T> **o) { return planner_new(n, o); }, &pl);
     if (rc) return rc;
-    rc = fft_host<T>(re, re_len, im, im_len, direction, pl);
-    delete pl;
-    return rc;
+    return fft_host<T>(re, re_len, im, im_len, direction, pl.get());
 }
 
 template <typename T>
@@ -1667,12 +1731,11 @@ PHAST_PLANNER_API(32, float)
                                   static_cast<hipStream_t>(stream), tw_n, tw_col0);                                 \
     }                                                                                                               \
     int phast_fft_##SFX##_interleaved(T *signal, size_t n, int direction) {                                         \
-        Planner<T> *pl = nullptr;                                                                                   \
-        int rc = planner_new(n, &pl); /* lib.rs:121 */                                                              \
+        std::shared_ptr<Planner<T>> pl; /* lib.rs:121: a planner per call -- kept, see PlannerCache */             \
+        int rc = PlannerCache<Planner<T>>::instance().get(                                                          \
+            n, sizeof(T), [](size_t m, Planner<T> **o) { return planner_new(m, o); }, &pl);                         \
         if (rc) return rc;                                                                                          \
-        rc = fft_interleaved_host<T>(signal, n, direction, pl);                                                     \
-        delete pl;                                                                                                  \
-        return rc;                                                                                                  \
+        return fft_interleaved_host<T>(signal, n, direction, pl.get());                                             \
     }                                                                                                               \
     int phast_fft_##SFX##_interleaved_with_planner(T *signal, size_t n, int direction,                              \
                                                    const phast_planner_dit##SFX *pl) {                              \
@@ -1697,12 +1760,11 @@ PHAST_PLANNER_API(32, float)
         return PHAST_OK;                                                                                            \
     }                                                                                                               \
     int phast_r2c_fft_##FS(const T *in, size_t in_len, T *ore, size_t ore_len, T *oim, size_t oim_len) {            \
-        PlannerR2c<T> *pl = nullptr;                                                                                \
-        int rc = r2c_planner_new(in_len, &pl);   /* r2c.rs:522: planner from input_re.len() */                     \
+        std::shared_ptr<PlannerR2c<T>> pl; /* r2c.rs:522: planner from input_re.len() */                           \
+        int rc = PlannerCache<PlannerR2c<T>>::instance().get(                                                       \
+            in_len, sizeof(T), [](size_t m, PlannerR2c<T> **o) { return r2c_planner_new(m, o); }, &pl);             \
         if (rc) return rc;                                                                                          \
-        rc = r2c_host<T>(in, in_len, ore, ore_len, oim, oim_len, pl);                                               \
-        delete pl;                                                                                                  \
-        return rc;                                                                                                  \
+        return r2c_host<T>(in, in_len, ore, ore_len, oim, oim_len, pl.get());                                       \
     }                                                                                                               \
     int phast_r2c_fft_##FS##_with_planner(const T *in, size_t in_len, T *ore, size_t ore_len, T *oim,               \
                                           size_t oim_len, const phast_planner_r2c##SFX *pl) {                       \
@@ -1715,12 +1777,11 @@ PHAST_PLANNER_API(32, float)
         return pl->r2c(d_in, d_ore, d_oim, batch, in_dist, out_dist, static_cast<hipStream_t>(stream));             \
     }                                                                                                               \
     int phast_c2r_fft_##FS(const T *ire, size_t ire_len, const T *iim, size_t iim_len, T *out, size_t out_len) {    \
-        PlannerR2c<T> *pl = nullptr;                                                                                \
-        int rc = r2c_planner_new(out_len, &pl);   /* r2c.rs:696: planner from output.len() */                      \
+        std::shared_ptr<PlannerR2c<T>> pl; /* r2c.rs:696: planner from output.len() */                             \
+        int rc = PlannerCache<PlannerR2c<T>>::instance().get(                                                       \
+            out_len, sizeof(T), [](size_t m, PlannerR2c<T> **o) { return r2c_planner_new(m, o); }, &pl);            \
         if (rc) return rc;                                                                                          \
-        rc = c2r_host<T>(ire, ire_len, iim, iim_len, out, out_len, pl, false, 0, 0);                                \
-        delete pl;                                                                                                  \
-        return rc;                                                                                                  \
+        return c2r_host<T>(ire, ire_len, iim, iim_len, out, out_len, pl.get(), false, 0, 0);                        \
     }                                                                                                               \
     int phast_c2r_fft_##FS##_with_planner(const T *ire, size_t ire_len, const T *iim, size_t iim_len, T *out,       \
                                           size_t out_len, const phast_planner_r2c##SFX *pl) {                       \

@@ -677,3 +677,74 @@ def test_real_transforms_fused_passes_across_scratch_chunks(gpu, oracle):
         oracle.c2r_fft_f64(g_re.copy(), g_im.copy(), want)
         got = y[b * n:(b + 1) * n].cpu().numpy()
         assert np.sqrt(np.sum((got - want) ** 2) / np.sum(want ** 2)) <= 1e-9, b
+
+
+# ---------------------------------------------------------------- planner-less entry points keep their planners
+_PLANNER_CACHE = r"""
+import os, sys, time
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import phastft_amd as P
+
+def call(n, seed):
+    rng = np.random.default_rng(seed)
+    re, im = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+    r0, i0 = re.copy(), im.copy()
+    P.fft_64_dit(re, im, P.Direction.Forward)
+    ref = np.fft.fft(r0 + 1j * i0)
+    err = np.sqrt(np.sum(np.abs(re + 1j * im - ref) ** 2) / np.sum(np.abs(ref) ** 2))
+    assert err < 1e-13, (n, err)
+    return re, im
+
+# six sizes through a cache of four entries (evictions), each size twice in a row and once again later: same bits every time
+first = {}
+for n in (1 << 10, 1 << 12, 1 << 14, 1 << 16, 1 << 18, 1 << 20):
+    a = call(n, n)
+    b = call(n, n)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    first[n] = a
+for n in (1 << 10, 1 << 20, 1 << 14):
+    c = call(n, n)
+    assert np.array_equal(c[0], first[n][0]) and np.array_equal(c[1], first[n][1])
+# errors are not cached and do not poison the cache
+for bad in (3, 0, 1000):
+    try:
+        P.fft_64_dit(np.zeros(bad), np.zeros(bad), P.Direction.Forward)
+        raise SystemExit("no error for n = %d" % bad)
+    except P.PhastPanic:
+        pass
+call(1 << 12, 5)
+# the real transforms and the f32 / interleaved forms go through their own caches
+x = np.random.default_rng(1).uniform(-1, 1, 1 << 15)
+for _ in range(2):
+    ore, oim = np.zeros((1 << 14) + 1), np.zeros((1 << 14) + 1)
+    P.r2c_fft_f64(x, ore, oim)
+    back = np.zeros(1 << 15)
+    P.c2r_fft_f64(ore, oim, back)
+    assert np.max(np.abs(back - x)) < 1e-12
+    xf = x.astype(np.float32)
+    fre, fim = np.zeros((1 << 14) + 1, np.float32), np.zeros((1 << 14) + 1, np.float32)
+    P.r2c_fft_f32(xf, fre, fim)
+    assert np.max(np.abs(fre - ore)) < 1e-2
+# timing: the second call of a size does not pay for a planner (informational, printed)
+n = 1 << 20
+re, im = np.zeros(n), np.zeros(n)
+P.fft_64_dit(re, im, P.Direction.Forward)
+t0 = time.perf_counter()
+for _ in range(5):
+    P.fft_64_dit(re, im, P.Direction.Forward)
+print("CACHE_OK %.3f ms per planner-less call at 2^20" % (1e3 * (time.perf_counter() - t0) / 5))
+"""
+
+
+@pytest.mark.parametrize("cache", ["1", "0"])
+def test_planner_less_calls_keep_their_planners(gpu, tmp_path, cache):
+    """lib.rs:181 / r2c.rs:522,696 make a planner per call; here the most recently used planners are kept per type, size and
+    device (api.hip: PlannerCache) -- invisible to the caller: bit-identical results call after call and across
+    evictions, errors neither cached nor poisoning; PHAST_PLANNER_CACHE=0 is the per-call behaviour."""
+    script = tmp_path / "cache.py"
+    script.write_text(_PLANNER_CACHE)
+    r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, PHAST_PLANNER_CACHE=cache))
+    assert r.returncode == 0 and "CACHE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    print(cache, r.stdout.strip().splitlines()[-1])
