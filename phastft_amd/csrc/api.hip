@@ -1311,6 +1311,14 @@ static int host_out(const Planner<T> *pl, void *d_stage, const HostPart *parts, 
     return PHAST_OK;
 }
 
+static bool zero_copy_small() {  // PHAST_ZERO_COPY=0: small host-slice calls stage through device memory as the large ones do
+    static const bool v = [] {
+        const char *e = std::getenv("PHAST_ZERO_COPY");
+        return !(e && *e == '0');
+    }();
+    return v;
+}
+
 // lib.rs:143-226 on host slices: validate as the reference asserts, stage through device memory
 template <typename T>
 static int fft_host(T *re, size_t re_len, T *im, size_t im_len, int direction, const Planner<T> *pl) {
@@ -1328,6 +1336,22 @@ static int fft_host(T *re, size_t re_len, T *im, size_t im_len, int direction, c
     if (rc) return rc;
     const bool small = total <= Planner<T>::pinned_max_bytes();
     const HostPart parts[2] = {{re, 0, bytes}, {im, bytes, bytes}};
+    if (small && pl->passes.empty() && zero_copy_small()) {
+        // One-kernel transforms (N <= 8192): the kernel reads and writes the pinned mirror itself over PCIe (pinned host
+        // memory is device-accessible) -- no DMA copy either way, one launch and one wait per call.
+        void *pin = nullptr;
+        rc = pl->pinned(total, &pin);
+        if (rc) return rc;
+        T *p_re = reinterpret_cast<T *>(pin), *p_im = p_re + n;
+        std::memcpy(p_re, re, bytes);
+        std::memcpy(p_im, im, bytes);
+        rc = fft_dev<T>(p_re, p_im, n, 1, n, direction, pl, nullptr);
+        if (rc) return rc;
+        PHAST_HIP(hipStreamSynchronize(nullptr));
+        std::memcpy(re, p_re, bytes);
+        std::memcpy(im, p_im, bytes);
+        return PHAST_OK;
+    }
     T *d_re = reinterpret_cast<T *>(stage), *d_im = d_re + n;
     rc = host_in(pl, stage, parts, 2, total, small);
     if (!rc) rc = fft_dev<T>(d_re, d_im, n, 1, n, direction, pl, nullptr);

@@ -748,3 +748,42 @@ def test_planner_less_calls_keep_their_planners(gpu, tmp_path, cache):
                        env=dict(os.environ, PHAST_PLANNER_CACHE=cache))
     assert r.returncode == 0 and "CACHE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
     print(cache, r.stdout.strip().splitlines()[-1])
+
+
+_ZERO_COPY = r"""
+import sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import phastft_amd as P
+out = {}
+for L in range(1, 14):
+    n = 1 << L
+    for name, dt, fn in (("f64", np.float64, P.fft_64_dit), ("f32", np.float32, P.fft_32_dit)):
+        rng = np.random.default_rng(1000 + L)
+        re, im = rng.uniform(-1, 1, n).astype(dt), rng.uniform(-1, 1, n).astype(dt)
+        r0, i0 = re.copy(), im.copy()
+        fn(re, im, P.Direction.Forward)
+        out[f"{name}_{L}_re"], out[f"{name}_{L}_im"] = re.copy(), im.copy()
+        fn(re, im, P.Direction.Reverse)
+        assert np.max(np.abs(re - r0)) < (1e-12 if dt == np.float64 else 1e-4), (name, L)
+np.savez(sys.argv[2], **out)
+print("ZC_DONE")
+"""
+
+
+def test_small_host_slice_calls_zero_copy_equals_staged(gpu, tmp_path):
+    """One-kernel transforms on host slices (N <= 8192) let the kernel read and write the planner's pinned mirror over PCIe
+    (api.hip: fft_host) instead of staging through device memory: the same kernel on the same values -- bit-identical to
+    the staged path (PHAST_ZERO_COPY=0), forward and back, both types, N = 2 ... 8192."""
+    script = tmp_path / "zc.py"
+    script.write_text(_ZERO_COPY)
+    res = {}
+    for zc in ("1", "0"):
+        path = str(tmp_path / f"zc{zc}.npz")
+        r = subprocess.run([sys.executable, str(script), ROOT, path], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, PHAST_ZERO_COPY=zc))
+        assert r.returncode == 0 and "ZC_DONE" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+        res[zc] = np.load(path)
+    assert sorted(res["1"].files) == sorted(res["0"].files) and len(res["1"].files) == 52
+    for k in res["1"].files:
+        assert np.array_equal(res["1"][k], res["0"][k]), k
