@@ -1470,6 +1470,19 @@ static int r2c_host(const T *in, size_t in_len, T *ore, size_t ore_len, T *oim, 
     T *d_in = reinterpret_cast<T *>(stage), *d_ore = d_in + n, *d_oim = d_ore + half + 1;
     const HostPart pin[1] = {{const_cast<T *>(in), 0, n * sizeof(T)}};
     const HostPart pout[2] = {{ore, n * sizeof(T), ob}, {oim, n * sizeof(T) + ob, ob}};
+    if (small && pl->dit.passes.empty() && zero_copy_small()) {  // one kernel on the pinned mirror itself, as fft_host
+        void *pm = nullptr;
+        rc = pl->dit.pinned(total, &pm);
+        if (rc) return rc;
+        T *p_in = reinterpret_cast<T *>(pm), *p_ore = p_in + n, *p_oim = p_ore + half + 1;
+        std::memcpy(p_in, in, n * sizeof(T));
+        rc = pl->r2c(p_in, p_ore, p_oim, 1, n, half + 1, nullptr);
+        if (rc) return rc;
+        PHAST_HIP(hipStreamSynchronize(nullptr));
+        std::memcpy(ore, p_ore, ob);
+        std::memcpy(oim, p_oim, ob);
+        return PHAST_OK;
+    }
     rc = host_in(&pl->dit, stage, pin, 1, total, small);
     if (!rc) rc = pl->r2c(d_in, d_ore, d_oim, 1, n, half + 1, nullptr);
     if (!rc) rc = host_out(&pl->dit, stage, pout, 2, total, small);
@@ -1497,6 +1510,19 @@ static int c2r_host(const T *ire, size_t ire_len, const T *iim, size_t iim_len, 
     T *d_out = reinterpret_cast<T *>(stage), *d_ire = d_out + n, *d_iim = d_ire + half + 1;
     const HostPart pin[2] = {{const_cast<T *>(ire), n * sizeof(T), ib}, {const_cast<T *>(iim), n * sizeof(T) + ib, ib}};
     const HostPart pout[1] = {{out, 0, n * sizeof(T)}};
+    if (small && pl->dit.passes.empty() && zero_copy_small()) {  // one kernel on the pinned mirror itself, as fft_host
+        void *pm = nullptr;
+        rc = pl->dit.pinned(total, &pm);
+        if (rc) return rc;
+        T *p_out = reinterpret_cast<T *>(pm), *p_ire = p_out + n, *p_iim = p_ire + half + 1;
+        std::memcpy(p_ire, ire, ib);
+        std::memcpy(p_iim, iim, ib);
+        rc = pl->c2r(p_ire, p_iim, p_out, 1, half + 1, n, nullptr);
+        if (rc) return rc;
+        PHAST_HIP(hipStreamSynchronize(nullptr));
+        std::memcpy(out, p_out, n * sizeof(T));
+        return PHAST_OK;
+    }
     rc = host_in(&pl->dit, stage, pin, 2, total, small);
     if (!rc) rc = pl->c2r(d_ire, d_iim, d_out, 1, half + 1, n, nullptr);
     if (!rc) rc = host_out(&pl->dit, stage, pout, 1, total, small);

@@ -766,6 +766,14 @@ for L in range(1, 14):
         out[f"{name}_{L}_re"], out[f"{name}_{L}_im"] = re.copy(), im.copy()
         fn(re, im, P.Direction.Reverse)
         assert np.max(np.abs(re - r0)) < (1e-12 if dt == np.float64 else 1e-4), (name, L)
+        if L >= 2:  # the real transforms of the same size (one kernel up to N/2 = 8192)
+            x = rng.uniform(-1, 1, 2 * n).astype(dt)
+            ore, oim = np.zeros(n + 1, dt), np.zeros(n + 1, dt)
+            (P.r2c_fft_f64 if dt == np.float64 else P.r2c_fft_f32)(x, ore, oim)
+            back = np.zeros(2 * n, dt)
+            (P.c2r_fft_f64 if dt == np.float64 else P.c2r_fft_f32)(ore, oim, back)
+            assert np.max(np.abs(back - x)) < (1e-12 if dt == np.float64 else 1e-4), (name, L)
+            out[f"{name}_{L}_ore"], out[f"{name}_{L}_oim"], out[f"{name}_{L}_back"] = ore, oim, back
 np.savez(sys.argv[2], **out)
 print("ZC_DONE")
 """
@@ -774,7 +782,7 @@ print("ZC_DONE")
 def test_small_host_slice_calls_zero_copy_equals_staged(gpu, tmp_path):
     """One-kernel transforms on host slices (N <= 8192) let the kernel read and write the planner's pinned mirror over PCIe
     (api.hip: fft_host) instead of staging through device memory: the same kernel on the same values -- bit-identical to
-    the staged path (PHAST_ZERO_COPY=0), forward and back, both types, N = 2 ... 8192."""
+    the staged path (PHAST_ZERO_COPY=0), forward and back, both types, N = 2 ... 8192; R2C / C2R of 2N points likewise."""
     script = tmp_path / "zc.py"
     script.write_text(_ZERO_COPY)
     res = {}
@@ -784,6 +792,6 @@ def test_small_host_slice_calls_zero_copy_equals_staged(gpu, tmp_path):
                            env=dict(os.environ, PHAST_ZERO_COPY=zc))
         assert r.returncode == 0 and "ZC_DONE" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
         res[zc] = np.load(path)
-    assert sorted(res["1"].files) == sorted(res["0"].files) and len(res["1"].files) == 52
+    assert sorted(res["1"].files) == sorted(res["0"].files) and len(res["1"].files) == 52 + 72
     for k in res["1"].files:
         assert np.array_equal(res["1"][k], res["0"][k]), k
