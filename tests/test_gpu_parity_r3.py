@@ -756,7 +756,7 @@ sys.path.insert(0, sys.argv[1])
 import numpy as np
 import phastft_amd as P
 out = {}
-for L in range(1, 14):
+for L in range(1, 18):
     n = 1 << L
     for name, dt, fn in (("f64", np.float64, P.fft_64_dit), ("f32", np.float32, P.fft_32_dit)):
         rng = np.random.default_rng(1000 + L)
@@ -766,7 +766,7 @@ for L in range(1, 14):
         out[f"{name}_{L}_re"], out[f"{name}_{L}_im"] = re.copy(), im.copy()
         fn(re, im, P.Direction.Reverse)
         assert np.max(np.abs(re - r0)) < (1e-12 if dt == np.float64 else 1e-4), (name, L)
-        if L >= 2:  # the real transforms of the same size (one kernel up to N/2 = 8192)
+        if 2 <= L <= 13:  # the real transforms of 2N points (one kernel up to N = 8192)
             x = rng.uniform(-1, 1, 2 * n).astype(dt)
             ore, oim = np.zeros(n + 1, dt), np.zeros(n + 1, dt)
             (P.r2c_fft_f64 if dt == np.float64 else P.r2c_fft_f32)(x, ore, oim)
@@ -780,9 +780,10 @@ print("ZC_DONE")
 
 
 def test_small_host_slice_calls_zero_copy_equals_staged(gpu, tmp_path):
-    """One-kernel transforms on host slices (N <= 8192) let the kernel read and write the planner's pinned mirror over PCIe
-    (api.hip: fft_host) instead of staging through device memory: the same kernel on the same values -- bit-identical to
-    the staged path (PHAST_ZERO_COPY=0), forward and back, both types, N = 2 ... 8192; R2C / C2R of 2N points likewise."""
+    """Host-slice calls up to the pinned limit (1 MiB of planes) let the kernels read and write the planner's pinned mirror
+    over PCIe (api.hip: fft_host) instead of staging through device memory: the same kernels on the same values --
+    bit-identical to the staged path (PHAST_ZERO_COPY=0), forward and back, both types, N = 2 ... 2^17 (one- and multi-pass
+    plans, either side of the limit); one-kernel R2C / C2R likewise."""
     script = tmp_path / "zc.py"
     script.write_text(_ZERO_COPY)
     res = {}
@@ -792,6 +793,6 @@ def test_small_host_slice_calls_zero_copy_equals_staged(gpu, tmp_path):
                            env=dict(os.environ, PHAST_ZERO_COPY=zc))
         assert r.returncode == 0 and "ZC_DONE" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
         res[zc] = np.load(path)
-    assert sorted(res["1"].files) == sorted(res["0"].files) and len(res["1"].files) == 52 + 72
+    assert sorted(res["1"].files) == sorted(res["0"].files) and len(res["1"].files) == 68 + 72
     for k in res["1"].files:
         assert np.array_equal(res["1"][k], res["0"][k]), k

@@ -2,7 +2,7 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, phastft_amd as P
-for L in (4, 8, 10, 12, 13, 14):
+for L in [int(a) for a in sys.argv[1:]] or (4, 8, 10, 12, 13, 14):
     n = 1 << L
     for name, dt, Pl, fn in (("f64", np.float64, P.PlannerDit64, P.fft_64_dit_with_planner), ("f32", np.float32, P.PlannerDit32, P.fft_32_dit_with_planner)):
         pl = Pl(n)
