@@ -1374,6 +1374,17 @@ template <typename T> static int fft_interleaved_host(T *signal, size_t n, int d
     if (rc) return rc;
     const bool small = total <= Planner<T>::pinned_max_bytes();
     const HostPart parts[1] = {{signal, 0, total}};
+    if (small && zero_copy_small()) {  // the kernels work on the pinned mirror itself, as in fft_host
+        void *pin = nullptr;
+        rc = pl->pinned(total, &pin);
+        if (rc) return rc;
+        std::memcpy(pin, signal, total);
+        rc = fft_interleaved_dev<T>(reinterpret_cast<T *>(pin), n, 1, n, direction, pl, nullptr);
+        if (rc) return rc;
+        PHAST_HIP(hipStreamSynchronize(nullptr));
+        std::memcpy(signal, pin, total);
+        return PHAST_OK;
+    }
     rc = host_in(pl, stage, parts, 1, total, small);
     if (!rc) rc = fft_interleaved_dev<T>(reinterpret_cast<T *>(stage), n, 1, n, direction, pl, nullptr);
     if (!rc) rc = host_out(pl, stage, parts, 1, total, small);

@@ -766,6 +766,11 @@ for L in range(1, 18):
         out[f"{name}_{L}_re"], out[f"{name}_{L}_im"] = re.copy(), im.copy()
         fn(re, im, P.Direction.Reverse)
         assert np.max(np.abs(re - r0)) < (1e-12 if dt == np.float64 else 1e-4), (name, L)
+        if dt == np.float64 and L in (3, 10, 14, 16):  # the interleaved wrappers (lib.rs:41-140)
+            z = (r0 + 1j * i0).astype(np.complex128)
+            P.fft_64_interleaved(z, P.Direction.Forward)
+            assert np.max(np.abs(z.real - out[f"{name}_{L}_re"])) < 1e-9 * n
+            out[f"{name}_{L}_z"] = z
         if 2 <= L <= 13:  # the real transforms of 2N points (one kernel up to N = 8192)
             x = rng.uniform(-1, 1, 2 * n).astype(dt)
             ore, oim = np.zeros(n + 1, dt), np.zeros(n + 1, dt)
@@ -793,6 +798,6 @@ def test_small_host_slice_calls_zero_copy_equals_staged(gpu, tmp_path):
                            env=dict(os.environ, PHAST_ZERO_COPY=zc))
         assert r.returncode == 0 and "ZC_DONE" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
         res[zc] = np.load(path)
-    assert sorted(res["1"].files) == sorted(res["0"].files) and len(res["1"].files) == 68 + 72
+    assert sorted(res["1"].files) == sorted(res["0"].files) and len(res["1"].files) == 68 + 72 + 4
     for k in res["1"].files:
         assert np.array_equal(res["1"][k], res["0"][k]), k
