@@ -801,3 +801,51 @@ def test_small_host_slice_calls_zero_copy_equals_staged(gpu, tmp_path):
     assert sorted(res["1"].files) == sorted(res["0"].files) and len(res["1"].files) == 68 + 72 + 4
     for k in res["1"].files:
         assert np.array_equal(res["1"][k], res["0"][k]), k
+
+
+_CACHE_THREADS = r"""
+import sys, threading
+sys.path.insert(0, sys.argv[1])
+import numpy as np
+import phastft_amd as P
+sizes = [1 << 6, 1 << 9, 1 << 11, 1 << 13, 1 << 15, 1 << 17, 1 << 19]   # seven sizes through a cache of four
+refs = {}
+for n in sizes:
+    rng = np.random.default_rng(n)
+    re, im = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+    refs[n] = (re, im, np.fft.fft(re + 1j * im))
+errs, bar = [], threading.Barrier(8)
+def work(t):
+    try:
+        bar.wait()
+        for it in range(40):
+            n = sizes[(t * 3 + it) % len(sizes)]
+            re, im, ref = refs[n]
+            a, b = re.copy(), im.copy()
+            P.fft_64_dit(a, b, P.Direction.Forward)
+            e = np.sqrt(np.sum(np.abs(a + 1j * b - ref) ** 2) / np.sum(np.abs(ref) ** 2))
+            if e > 1e-13:
+                errs.append((t, it, n, e))
+            if it % 7 == 0:  # a real transform in between: the other cache
+                x = re.copy()
+                ore, oim = np.zeros(n // 2 + 1), np.zeros(n // 2 + 1)
+                P.r2c_fft_f64(x, ore, oim)
+                if abs(ore[0] - x.sum()) > 1e-9 * n:
+                    errs.append((t, it, n, "r2c"))
+    except Exception as ex:  # noqa
+        errs.append((t, repr(ex)))
+ths = [threading.Thread(target=work, args=(t,)) for t in range(8)]
+[t.start() for t in ths]
+[t.join() for t in ths]
+assert not errs, errs[:5]
+print("CACHE_THREADS_OK")
+"""
+
+
+def test_planner_cache_under_eight_host_threads(gpu, tmp_path):
+    """Eight host threads call the planner-less forms with seven sizes at once: planners are shared while cached, evicted
+    while other threads still hold them (shared ownership), re-made on the next miss -- every result against numpy."""
+    script = tmp_path / "cache_threads.py"
+    script.write_text(_CACHE_THREADS)
+    r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0 and "CACHE_THREADS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -31,10 +31,16 @@ PY
     echo "$EXE"
     ;;
 run)
-    echo "# $(date -u) host-side ASan pass: $EXE gpu"
-    export ASAN_OPTIONS=detect_leaks=1:halt_on_error=0:abort_on_error=0
+    # Two passes, each under its own timeout.  The planner cache of the planner-less entry points (api.hip: PlannerCache)
+    # is deliberately never destroyed, so with it on, the leak checker's scan at exit walks the device mappings the cached
+    # planners still hold and does not come back (15 minutes of a GPU box were lost finding that out): leaks are checked
+    # with the cache off (every planner is freed before exit, as before round 3), the cache itself with the leak check off.
     export LSAN_OPTIONS=suppressions=$R/tools/lsan.supp:print_suppressions=0
-    "$EXE" gpu
+    echo "# $(date -u) host-side ASan pass 1 (PHAST_PLANNER_CACHE=0, leak check on): $EXE gpu"
+    ASAN_OPTIONS=detect_leaks=1:halt_on_error=0:abort_on_error=0 PHAST_PLANNER_CACHE=0 timeout 120 "$EXE" gpu
+    echo "# exit code $?"
+    echo "# $(date -u) host-side ASan pass 2 (planner cache on, leak check off): $EXE gpu"
+    ASAN_OPTIONS=detect_leaks=0:halt_on_error=0:abort_on_error=0 timeout 120 "$EXE" gpu
     echo "# exit code $?"
     ;;
 esac
