@@ -93,3 +93,21 @@ def test_product_never_imports_the_oracle():
                 assert "oracle" not in text.replace("oracle/", "").replace("the oracle", "").replace("host oracle", "") \
                     or "import oracle" not in text, f
                 assert "from oracle" not in text and "import oracle" not in text, f
+
+
+def test_every_environment_variable_the_library_reads_is_documented():
+    """INTEGRATION.md lists the environment variables; a getenv("PHAST...") in the sources that is not in that table is a
+    behaviour switch a maintainer cannot find."""
+    import glob
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    names = set()
+    for path in glob.glob(os.path.join(root, "phastft_amd", "csrc", "*")) + glob.glob(os.path.join(root, "phastft_amd", "*.py")):
+        if os.path.isfile(path) and path.endswith((".hip", ".hpp", ".py")):
+            names |= set(re.findall(r'getenv\("(PHAST[A-Z0-9_]*)"\)', open(path).read()))
+            names |= set(re.findall(r'environ(?:\.get)?[\[(]\s*["\'](PHAST[A-Z0-9_]*)', open(path).read()))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    assert names, "no environment variables found: the pattern no longer matches the sources"
+    missing = sorted(n for n in names if n not in doc)
+    assert not missing, missing
