@@ -1,4 +1,5 @@
-R=/root/repo; O=$R/gpurun_out/profiles_new; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
+# PMC traffic + kernel statistics of the C2R workload, fused and unfused (runs on the GPU box; profiles/README.md)
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/profiles_new; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 pmc() {
     local key=$1 alg=$2 name=$3; shift 3
     rm -rf /tmp/prof_fetch /tmp/prof_write
