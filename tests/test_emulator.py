@@ -380,3 +380,58 @@ def test_c2r_fused_first_pass_vs_oracle_and_irfft(emu, oracle, log_n):
             for got, r in ((out[:n], ref), (out[n:], ref2)):
                 assert np.sqrt(np.sum((got - r) ** 2)) / np.sqrt(np.sum(r ** 2)) <= tol_np
     assert ran >= 6, ran
+
+
+def _two_pass_plans_through(shape, shapes, first):
+    """A forced two-pass plan (rows of pass A, rows of pass B) of the inner transform whose first (or last) pass is `shape`:
+    both passes share the tile size and the points per thread, so the other pass's shape must exist too."""
+    lr, lc, lp = shape
+    tl = lr + lc
+    for other in (8, 7, 9, 6, 10, 11):
+        if (other, tl - other, lp) in shapes and tl - other >= 2:
+            lrs = (lr, other) if first else (other, lr)
+            if lrs[1] + 1 <= 12 and lr + other <= 21:  # (columns of the last pass = rows of the first: keep the sizes testable)
+                return lrs, tl, lp
+    return None
+
+
+@pytest.mark.parametrize("is_f64", [1, 0])
+def test_every_instantiated_shape_as_fused_first_pass_of_c2r_and_last_pass_of_r2c(emu, oracle, is_f64):
+    """GPU tests reach the shapes the default plans use; the fused real-transform passes are instantiated for every tile
+    shape (tile_f*_c2r.hip, tile_f*_r2c.hip).  Each of them as the first pass of a forced two-pass C2R and as the last pass
+    of a forced two-pass R2C, thread by thread: every output against numpy (and the C2R's chunked partner loads -- 2, 4, 8
+    rows at a time depending on the shape's register budget -- with it)."""
+    dtype = np.float64 if is_f64 else np.float32
+    shapes = set(SHAPES + ([] if is_f64 else SHAPES_F32_ONLY))
+    tol = 1e-13 if is_f64 else 1e-5
+    ran_c2r = ran_r2c = 0
+    for shape in sorted(shapes):
+        for first in (True, False):
+            plan = _two_pass_plans_through(shape, shapes, first)
+            if plan is None:
+                continue
+            lrs, tl, lp = plan
+            n = 2 << (lrs[0] + lrs[1])
+            rng = np.random.default_rng(sum(shape) * 7 + first)
+            x = rng.uniform(-1, 1, n)
+            if first:
+                spec = np.fft.rfft(x)
+                spec.imag[0] = spec.imag[-1] = 0.0
+                ire, iim = spec.real.astype(dtype), spec.imag.astype(dtype)
+                rc, out = _emu_c2r(emu, ire, iim, n, lrs=lrs, tile_log=tl, points_log=lp)
+                if rc == 3:  # no fused form of this shape (c2r_shape_fits)
+                    continue
+                assert rc == 0, (rc, shape, plan)
+                ref = np.fft.irfft(ire.astype(np.float64) + 1j * iim.astype(np.float64), n)
+                assert np.sqrt(np.sum((out - ref) ** 2) / np.sum(ref ** 2)) <= tol, (shape, plan)
+                ran_c2r += 1
+            else:
+                rc, ore, oim = _emu_r2c(emu, x.astype(dtype), lrs, tl, lp)
+                if rc == 3:  # r2c_shape_fits: 32 points per thread on 1024 threads, f64 above 16 points
+                    continue
+                assert rc == 0, (rc, shape, plan)
+                ref = np.fft.rfft(x.astype(dtype).astype(np.float64))
+                got = ore.astype(np.float64) + 1j * oim.astype(np.float64)
+                assert np.sqrt(np.sum(np.abs(got - ref) ** 2) / np.sum(np.abs(ref) ** 2)) <= tol, (shape, plan)
+                ran_r2c += 1
+    assert ran_c2r >= (35 if is_f64 else 40) and ran_r2c >= (24 if is_f64 else 36), (ran_c2r, ran_r2c)
