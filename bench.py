@@ -533,6 +533,48 @@ def check_shard(P, torch, re, im, refill, step, first: int, shard: int, samples:
     return ok, {"parseval_max_rel_dev": parseval, "oracle_digest_max_dev": worst, "oracle_checked_ids": len(ids)}, after_t
 
 
+def fail(msg: str, rc: int = 2):
+    """bench.py never prints a number for a job other than the one it was asked to measure: refuse, loudly, rc != 0"""
+    print(f"bench.py: error: {msg}", file=sys.stderr, flush=True)
+    sys.exit(rc)
+
+
+def free_port() -> int:
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_command(n: int, argv) -> list:
+    """the driver's own N > 1 command line (one rank per GPU on 127.0.0.1), with a free rendezvous port"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(args, torch) -> int:
+    """`python bench.py --gpus N` without a launcher: re-exec this script under torch.distributed.run with N ranks on
+    127.0.0.1 (one per GPU), stream rank 0's JSON line through, return the job's exit code.  Refuses (rc 2) when the
+    node does not have N GPUs -- unless --same-gpu (dry run of the N-rank code path on one device over gloo)."""
+    import subprocess
+
+    have = torch.cuda.device_count()
+    if args.same_gpu:
+        if args.backend == "nccl":
+            fail("--same-gpu needs --backend gloo (RCCL refuses two ranks on one device)")
+        if have < 1:
+            fail("no GPU visible")
+    elif have < args.gpus:
+        fail(f"--gpus {args.gpus} but this node has {have} GPU(s) visible; nothing measured "
+             f"(use --same-gpu --backend gloo for a one-GPU dry run of the {args.gpus}-rank path)")
+    cmd = launch_command(args.gpus, sys.argv[1:])
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
     # the host driver of this pool only supports dmabuf IPC: without this RCCL / device-tensor sharing across the ranks
@@ -540,9 +582,26 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
 
+    if args.gpus < 1:
+        fail(f"--gpus {args.gpus}: need at least one GPU")
+    launched = "WORLD_SIZE" in os.environ            # started by torch.distributed.run (the driver's N > 1 command)
+    if args.gpus > 1 and not launched:
+        # plain `python bench.py --gpus N`: this process becomes the launcher of N ranks (one per GPU) and passes the
+        # one JSON line of rank 0 through; it never measures fewer GPUs than it was asked for
+        sys.exit(self_launch(args, torch))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        fail(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher started {world} rank(s); refusing to report a "
+             f"{world}-GPU number as a {args.gpus}-GPU one")
+    if args.same_gpu and args.backend == "nccl" and world > 1:
+        fail("--same-gpu needs --backend gloo (RCCL refuses two ranks on one device)")
+    have = torch.cuda.device_count()
+    need = 1 if args.same_gpu else int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if have < need:
+        fail(f"{need} GPU(s) needed on this node, {have} visible"
+             + ("" if need == 1 else " (use --same-gpu --backend gloo for a one-GPU dry run)"))
     multi = world > 1 or args.sharded
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -558,11 +617,12 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.backend)
+        n_gpus = dist.get_world_size()                # the number of ranks the process group actually has
+        if n_gpus != args.gpus:
+            fail(f"process group has {n_gpus} rank(s), --gpus {args.gpus}")
     else:
         torch.cuda.set_device(0)
-    if args.gpus != world and rank == 0 and (args.gpus > 1 or world > 1):
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    n_gpus = world
+        n_gpus = 1
 
     import phastft_amd as P
 

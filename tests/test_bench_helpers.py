@@ -61,3 +61,44 @@ def test_roofline_arithmetic():
     assert dom == 1 and abs(roof["achieved"] - 33554432 / 0.010e-3 / 1e9) < 1e-6
     assert abs(roof["frac"] - roof["achieved"] / 8000.0) < 1e-12
     assert abs(roof["transform_frac"] - 33554432 / 0.026e-3 / 1e9 / 8000.0) < 1e-9 and roof["passes"] == 3
+
+
+# ---------------------------------------------------------------- round 4: `bench.py --gpus N` cannot mis-measure
+def _run_bench(argv, env_extra=None, drop=("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE")):
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, env=env,
+                          timeout=300, cwd=ROOT)
+
+
+def test_bench_refuses_gpus_it_does_not_have():
+    """A plain `python bench.py --gpus 8` on a box with fewer GPUs (none here) must exit non-zero with the reason and
+    print NO JSON line -- round 3 printed a warning and measured one GPU (missing #1)."""
+    import torch
+
+    if torch.cuda.device_count() >= 8:
+        import pytest
+
+        pytest.skip("this box really has 8 GPUs")
+    r = _run_bench(["--gpus", "8", "--steps", "1"])
+    assert r.returncode != 0
+    assert "GPU(s) visible" in r.stderr and "nothing measured" in r.stderr
+    assert not any(ln.startswith("{") for ln in r.stdout.splitlines())
+
+
+def test_bench_refuses_world_size_mismatch():
+    """--gpus must equal the number of ranks the launcher started: never a 2-rank number labelled n_gpus 1 or vice versa"""
+    r = _run_bench(["--gpus", "1", "--steps", "1"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+    assert not any(ln.startswith("{") for ln in r.stdout.splitlines())
+    r = _run_bench(["--gpus", "2", "--same-gpu", "--steps", "1"])          # RCCL cannot put two ranks on one device
+    assert r.returncode != 0 and "gloo" in r.stderr
+
+
+def test_bench_self_launch_command_is_the_drivers():
+    cmd = bench.launch_command(4, ["--gpus", "4", "--steps", "3"])
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-5].endswith("bench.py") and cmd[-4:] == ["--gpus", "4", "--steps", "3"]

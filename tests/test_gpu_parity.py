@@ -20,6 +20,18 @@ def rel_l2(got_re, got_im, ref_re, ref_im):
     return num / den if den else num
 
 
+def max_bin_err(got_re, got_im, ref_re, ref_im):
+    """largest single-bin error relative to the rms bin magnitude (round 4): a few wrong bins move
+    the rel-L2 by ~sqrt(bins/N) only -- this bound catches them outright"""
+    e = np.maximum(np.abs(got_re.astype(np.float64) - ref_re), np.abs(got_im.astype(np.float64) - ref_im))
+    rms = np.sqrt(np.mean(np.asarray(ref_re, np.float64) ** 2 + np.asarray(ref_im, np.float64) ** 2))
+    return float(e.max()) / rms if rms else float(e.max())
+
+
+BIN_F64 = 1e-11   # per-bin bounds, relative to the rms bin (as tests/test_gpu_parity_r3.py)
+BIN_F32 = 2e-3
+
+
 def dev(x):
     import torch
 
@@ -284,6 +296,9 @@ def test_r2c_f64_vs_oracle_and_c2c(gpu, oracle, k):
     assert rel_l2(ore, oim, ref_re, ref_im) <= 1e-9
     ind = np.fft.rfft(x)
     assert rel_l2(ore, oim, ind.real, ind.imag) <= F64_REL
+    assert max_bin_err(ore, oim, ind.real, ind.imag) <= BIN_F64, k     # no single bin off (exact twiddles on both sides)
+    assert max_bin_err(ore, oim, ref_re, ref_im) <= 1e-7, k            # vs the oracle: its recurrence drift, bin by bin
+    assert oim[0] == 0 and oim[-1] == 0                                # r2c.rs:161-166: exact zeros
     out = np.zeros(n)
     gpu.c2r_fft_f64(ore, oim, out)
     assert np.max(np.abs(out - x)) < 1e-6  # r2c.rs:958-976
@@ -298,6 +313,10 @@ def test_r2c_f32_vs_oracle(gpu, oracle, k):
     ref_re, ref_im = np.zeros(n // 2 + 1, np.float32), np.zeros(n // 2 + 1, np.float32)
     oracle.r2c_fft_f32(x, ref_re, ref_im)
     assert rel_l2(ore, oim, ref_re, ref_im) <= F32_REL
+    ind = np.fft.rfft(x.astype(np.float64))
+    assert max_bin_err(ore, oim, ind.real, ind.imag) <= BIN_F32, k
+    assert max_bin_err(ore, oim, ref_re.astype(np.float64), ref_im.astype(np.float64)) <= BIN_F32, k
+    assert oim[0] == 0 and oim[-1] == 0
     out = np.zeros(n, np.float32)
     gpu.c2r_fft_f32(ore, oim, out)
     assert np.max(np.abs(out - x)) < 1e-5
@@ -318,7 +337,13 @@ def test_config4_r2c_f32_2p24(gpu, oracle):
     assert np.array_equal(hx, x.cpu().numpy())  # the two generators are bit-identical
     ref_re, ref_im = np.zeros(n // 2 + 1, np.float32), np.zeros(n // 2 + 1, np.float32)
     oracle.r2c_fft_f32(hx, ref_re, ref_im)
-    assert rel_l2(ore.cpu().numpy(), oim.cpu().numpy(), ref_re, ref_im) <= F32_REL
+    g_re, g_im = ore.cpu().numpy(), oim.cpu().numpy()
+    assert rel_l2(g_re, g_im, ref_re, ref_im) <= F32_REL
+    ind = np.fft.rfft(hx.astype(np.float64))
+    assert rel_l2(g_re, g_im, ind.real, ind.imag) <= F32_REL
+    assert max_bin_err(g_re, g_im, ind.real, ind.imag) <= BIN_F32      # every bin of the 2^23 + 1
+    assert max_bin_err(g_re, g_im, ref_re.astype(np.float64), ref_im.astype(np.float64)) <= BIN_F32
+    assert g_im[0] == 0 and g_im[-1] == 0
     back = torch.empty(n, dtype=torch.float32, device="cuda")
     gpu.c2r_fft_f32_with_planner(ore, oim, back, planner)
     assert float((back - x).abs().max()) < 1e-4

@@ -123,6 +123,13 @@ def c2r_model(x_re, x_im, n):
     return out
 
 
+def max_abs_real(got, ref):
+    """largest single-sample error of a real output, relative to the rms sample (round 4, VERDICT r03 weak #3)"""
+    ref = np.asarray(ref, np.float64)
+    rms = np.sqrt(np.mean(ref ** 2))
+    return float(np.max(np.abs(np.asarray(got, np.float64) - ref))) / (rms if rms else 1.0)
+
+
 def _spectrum(n, dtype, seed):
     """An arbitrary half spectrum: NOT Hermitian-consistent (non-zero imaginary parts at DC and Nyquist), as the
     reference's formulas are defined for any input."""
@@ -140,6 +147,8 @@ def test_c2r_f64_vs_oracle(gpu, oracle, k):
     gpu.c2r_fft_f64(x_re, x_im, got)          # host slices, planner-less (r2c.rs:695)
     assert rel_l2_real(got, want) <= 1e-9, k
     assert rel_l2_real(got, c2r_model(x_re, x_im, n)) <= F64_REL, k
+    assert max_abs_real(got, c2r_model(x_re, x_im, n)) <= 1e-11, k       # no single sample off
+    assert max_abs_real(got, want) <= 1e-7, k                            # vs the oracle: its twiddle drift only
     planner = gpu.PlannerR2c64(n)
     d_out = dev(np.zeros(n))
     gpu.c2r_fft_f64_with_planner(dev(x_re), dev(x_im), d_out, planner)   # device tensors
@@ -155,7 +164,10 @@ def test_c2r_f32_vs_oracle(gpu, oracle, k):
     got = np.zeros(n, np.float32)
     gpu.c2r_fft_f32(x_re, x_im, got)
     assert rel_l2_real(got, want) <= F32_REL, k
-    assert rel_l2_real(got, c2r_model(x_re.astype(np.float64), x_im.astype(np.float64), n)) <= F32_REL, k
+    model = c2r_model(x_re.astype(np.float64), x_im.astype(np.float64), n)
+    assert rel_l2_real(got, model) <= F32_REL, k
+    assert max_abs_real(got, model) <= 2e-3, k
+    assert max_abs_real(got, want) <= 2e-3, k
 
 
 def dev(x):
