@@ -16,10 +16,17 @@
  *     stream; they are what bench.py measures.  `batch` independent transforms, transform b at
  *     pointer + b*dist elements.
  *
- * Planners may be shared by concurrent host threads (planner.rs:38-39): a planner owns one device scratch
- * buffer, so an internal lock makes every call's launch sequence atomic -- the blocking host-slice calls hold it
- * for the whole call, the _dev calls while they enqueue.  _dev calls on one planner must therefore be issued on
- * ONE stream (or be ordered by the caller across streams); use one planner per stream for concurrent streams.
+ * Planners may be shared by concurrent host threads AND streams (planner.rs:38-39: the reference's planner is an
+ * immutable value borrowed by `&`).  What a call mutates -- the inter-pass scratch, the staging buffer and pinned mirror of
+ * the host-slice calls -- lives in a WORKSPACE, and a planner keeps a small pool of them (up to PHAST_MAX_WORKSPACES = 8,
+ * made on demand): a call checks one out while it enqueues (a blocking host-slice call: for the whole call, on the
+ * workspace's own non-blocking stream, never the NULL stream), calls on one stream come back to the same workspace, calls
+ * on other streams get another one, and only when the pool is exhausted does a stream wait -- on the device, behind an
+ * event -- for another stream's work.  N threads x N streams on one planner run side by side.
+ * Graphs: a workspace used under stream capture belongs to the captured graph(s) until the planner is freed -- eager
+ * calls never touch it again and none of its buffers is ever released early, so replays stay valid whatever the planner
+ * is used for afterwards.  Replays of several graphs captured from ONE planner on ONE capture stream share that workspace:
+ * order them among themselves (or capture them on different streams).
  *
  * Devices: a planner belongs to the HIP device that is current when it is created (its tables and scratch live
  * there).  One process may hold planners on several devices (one host thread per GPU, or one thread switching):

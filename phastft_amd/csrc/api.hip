@@ -11,8 +11,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <condition_variable>
 #include <memory>
 #include <mutex>
+#include <shared_mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -224,62 +226,76 @@ struct PassTimer {
     }
 };
 
-template <typename T> struct Planner {
-    size_t n = 0;
-    unsigned log_n = 0;
-    std::vector<PassDesc> passes;      // throughput plan; empty => small path
-    std::vector<PassDesc> passes_lat;  // latency plan (one small transform); may equal `passes`
-    std::vector<PassDesc> passes_mid;  // a few transforms in flight, where that wants a plan of its own (plan.hpp)
-    std::vector<PassDesc> passes_one;  // ONE (or two) transforms: wave / quad tiles etc. (plan.hpp: single_plan)
-    void *d_small_tw = nullptr;
-    mutable T *d_scratch = nullptr;  // [cap][2][n]: re plane then im plane per transform
-    mutable size_t scratch_cap = 0;
-    mutable size_t scratch_guard = 0;  // bytes of guard band before and after the scratch (debug hook, normally 0)
-    // elements per transform and plane in the scratch: n plus the padding of the intermediate layouts (plan.hpp:
-    // scratch_pad_bytes); the largest over this planner's plans, fixed before the first allocation grows past it
-    size_t scratch_stride = 0;
-    size_t sstride() const { return scratch_stride ? scratch_stride : n; }
-    mutable size_t reserve = 1;
-    mutable std::mutex mu;
-    // One transform sequence at a time per planner: the passes of a call share the planner's scratch, so the
-    // enqueue of a call (and, on the host-slice path, the whole blocking call) holds this lock.  Recursive: the
-    // host-slice entry points call exec() while holding it.
-    mutable std::recursive_mutex call_mu;
-    mutable void *d_stage = nullptr;  // device staging of the host-slice entry points (grow-only)
-    mutable size_t stage_bytes = 0;
-    mutable void *h_pin = nullptr;    // pinned host mirror of the staging buffer for SMALL host-slice calls
-    mutable size_t pin_bytes = 0;
-    mutable size_t table_bytes = 0;
-    int device = -1;  // the device this planner's tables and scratch live on (current at creation); calls run there
+// ------------------------------------------------------------------------------------------------
+// Workspaces: what ONE call sequence works in.  The reference's planner is an immutable value shared by `&`
+// (planner.rs:38-39; algorithms/dit.rs:263 takes `&PlannerDit64`): N host threads transform N buffers at once with one
+// planner.  Here the immutable part is the tables and plans; everything a call mutates -- the inter-pass scratch, the
+// staging buffer and pinned mirror of the host-slice calls, the C2R workspace -- lives in a Workspace, and a planner
+// keeps a small pool of them.  A call checks one out for the time it ENQUEUES (a blocking host-slice call: for the whole
+// call), so concurrent callers of one planner run side by side instead of one behind the other.
+//   * a workspace is bound to the stream its last work went to: calls on that stream come back to it (stream order makes
+//     the reuse of its scratch safe without any synchronisation);
+//   * a call on another stream takes a workspace whose stream has drained, or makes a new one (up to
+//     PHAST_MAX_WORKSPACES, default 8), or -- pool exhausted -- takes a busy one's buffers BEHIND an event: the new stream
+//     waits on the device for the old stream's work, the host never blocks;
+//   * host-slice calls run on the workspace's own non-blocking stream, never on the NULL stream;
+//   * a workspace that was used under stream capture belongs to the captured graph(s) from then on: replays may run at any
+//     time on streams this library never sees, so eager calls never take it and none of its buffers is ever freed before
+//     the planner is (a graph replayed after an outgrown scratch had been released read freed memory).
+// ------------------------------------------------------------------------------------------------
+static bool stream_capturing(hipStream_t s) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess) {
+        (void)hipGetLastError();
+        return true;  // cannot tell: behave as if it were
+    }
+    return st != hipStreamCaptureStatusNone;
+}
+
+static size_t max_workspaces() {
+    static const size_t v = [] {
+        const char *e = std::getenv("PHAST_MAX_WORKSPACES");
+        long n = e && *e ? std::atol(e) : 8;
+        return (size_t)(n < 1 ? 1 : n > 64 ? 64 : n);
+    }();
+    return v;
+}
+
+struct Workspace {
+    void *d_scratch = nullptr;  // [cap][2][stride]: re plane then im plane per transform (typed by the planner)
+    size_t cap = 0;
+    size_t guard = 0;           // bytes of guard band before and after the scratch (debug hook, normally 0)
+    size_t per = 0;             // bytes per transform the scratch was cut for (2 * stride * sizeof(T))
+    void *d_stage = nullptr;    // device staging of the host-slice entry points (grow-only)
+    size_t stage_bytes = 0;
+    void *h_pin = nullptr;      // pinned host mirror of the staging buffer for SMALL host-slice calls
+    size_t pin_bytes = 0;
+    void *d_z = nullptr;        // unfused C2R: the preprocess workspace [z_cap][2][n/2] (PlannerR2c)
+    size_t z_cap = 0, z_bytes = 0;
+    hipStream_t stream = nullptr;  // the stream the last work of this workspace went to (valid while `pending`)
+    bool pending = false;          // work may still be running on `stream`
+    hipStream_t own = nullptr;     // the non-blocking stream of host-slice calls (created on first use)
+    bool busy = false;             // checked out by a host thread
+    bool captured = false;         // used under stream capture: pinned to the captured graphs (see above)
     // A buffer that has to grow is replaced, never freed inside the call that outgrew it: kernels already enqueued may
-    // still use the old one.  The predecessor is RETIRED with an event recorded behind the last work enqueued through
-    // this planner; a later call frees it once that event has completed (reap(): never under stream capture, where a
-    // hipFree is illegal).  Scratch grows geometrically, so what is retained at any time stays below the live size.
+    // still use the old one.  The predecessor is RETIRED with an event recorded on the workspace's stream behind them; a
+    // later call frees it once that event has completed (never under capture, never for a captured workspace).
     struct Retired {
         void *p;
         size_t bytes;
-        hipEvent_t done;  // nullptr: retired under stream capture -- released with the planner
+        hipEvent_t done;  // nullptr: released with the planner
         bool pinned;
     };
-    mutable std::vector<Retired> retired;
-    mutable size_t retired_dev_bytes = 0;
-    mutable hipStream_t last_stream = nullptr;  // the stream the previous call enqueued on (call_mu held)
+    std::vector<Retired> retired;
+    size_t retired_dev_bytes = 0;
 
-    static bool capturing(hipStream_t s) {
-        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(s, &st) != hipSuccess) {
-            (void)hipGetLastError();
-            return true;  // cannot tell: behave as if it were
-        }
-        return st != hipStreamCaptureStatusNone;
-    }
-    void retire(void *p, size_t bytes, bool pinned) const {
+    void retire(void *p, size_t bytes, bool pinned, hipStream_t on) {
         if (!p) return;
         Retired r{p, bytes, nullptr, pinned};
-        if (!capturing(last_stream)) {
+        if (!captured && !stream_capturing(on)) {
             hipEvent_t ev = nullptr;
             if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
-                if (hipEventRecord(ev, last_stream) == hipSuccess) r.done = ev;
+                if (hipEventRecord(ev, on) == hipSuccess) r.done = ev;
                 else hipEventDestroy(ev);
             }
             (void)hipGetLastError();
@@ -287,9 +303,9 @@ template <typename T> struct Planner {
         if (!pinned) retired_dev_bytes += bytes;
         retired.push_back(r);
     }
-    // free what is provably idle; `wait`: block for it (out-of-memory recovery).  Not under capture of `stream`.
-    void reap(hipStream_t stream, bool wait = false) const {
-        if (retired.empty() || capturing(stream)) return;
+    // free what is provably idle; `wait`: block for it (out-of-memory recovery).  Not under capture of `on`.
+    void reap(hipStream_t on, bool wait = false) {
+        if (retired.empty() || stream_capturing(on)) return;
         size_t keep = 0;
         for (size_t i = 0; i < retired.size(); ++i) {
             Retired &r = retired[i];
@@ -309,12 +325,192 @@ template <typename T> struct Planner {
         retired.resize(keep);
         (void)hipGetLastError();  // hipEventQuery's hipErrorNotReady is not an error of the call being made
     }
-    // plans of strided batches (column FFTs), built on first use per (log2 stride, log2 batch): see make_strided_passes
+    size_t device_bytes() const { return cap * per + stage_bytes + z_bytes + retired_dev_bytes; }
+    void release() {  // with the planner (hipFree waits for the device: whatever still used the buffers is done afterwards)
+        if (d_scratch) hipFree(reinterpret_cast<char *>(d_scratch) - guard);
+        if (d_stage) hipFree(d_stage);
+        if (d_z) hipFree(d_z);
+        if (h_pin) hipHostFree(h_pin);
+        for (const Retired &r : retired) {
+            if (r.pinned) hipHostFree(r.p);
+            else hipFree(r.p);
+            if (r.done) hipEventDestroy(r.done);
+        }
+        retired.clear();
+        if (own) hipStreamDestroy(own);
+        d_scratch = d_stage = d_z = h_pin = nullptr;
+        own = nullptr;
+        cap = stage_bytes = z_cap = z_bytes = pin_bytes = retired_dev_bytes = 0;
+    }
+};
+
+template <typename T> struct Planner {
+    size_t n = 0;
+    unsigned log_n = 0;
+    std::vector<PassDesc> passes;      // throughput plan; empty => small path
+    std::vector<PassDesc> passes_lat;  // latency plan (one small transform); may equal `passes`
+    std::vector<PassDesc> passes_mid;  // a few transforms in flight, where that wants a plan of its own (plan.hpp)
+    std::vector<PassDesc> passes_one;  // ONE (or two) transforms: wave / quad tiles etc. (plan.hpp: single_plan)
+    void *d_small_tw = nullptr;
+    // elements per transform and plane in the scratch: n plus the padding of the intermediate layouts (plan.hpp:
+    // scratch_pad_bytes); the largest over this planner's plans, fixed before the first allocation grows past it
+    size_t scratch_stride = 0;
+    size_t sstride() const { return scratch_stride ? scratch_stride : n; }
+    mutable size_t reserve = 1;
+    mutable size_t table_bytes = 0;
+    int device = -1;  // the device this planner's tables and scratch live on (current at creation); calls run there
+    // the workspace pool (see Workspace); `mu` guards the pool's bookkeeping, never a launch
+    mutable std::mutex mu;
+    mutable std::condition_variable cv;
+    mutable std::vector<std::unique_ptr<Workspace>> pool;
+    // plans are read by every call and replaced by set_plan (a tuning hook): shared for the enqueue, exclusive to swap
+    mutable std::shared_mutex plan_mu;
+    // tables a set_plan replaced: kernels already enqueued (or captured) may still read them -- released with the planner
+    mutable std::vector<void *> old_tables;
+    mutable size_t old_table_bytes = 0;
+    // plans of strided batches (column FFTs), built on first use per (log2 stride, log2 batch): see make_strided_passes;
+    // guarded by `mu`, entries never move
     struct StridedPlan {
         unsigned s = 0, sb = 0, grid_log_n = 0;
         std::vector<PassDesc> passes;
     };
-    mutable std::vector<StridedPlan> strided_plans;
+    mutable std::vector<std::unique_ptr<StridedPlan>> strided_plans;
+
+    static bool capturing(hipStream_t s) { return stream_capturing(s); }
+
+    // One checked-out workspace + the shared hold on the plans, for the duration of a call's enqueue (host-slice calls: of
+    // the whole blocking call).  `stream` is where the call's work goes: the caller's for _dev calls, the workspace's own
+    // for host-slice calls.
+    struct Lease {
+        const Planner *pl = nullptr;
+        Workspace *ws = nullptr;
+        hipStream_t stream = nullptr;
+        bool host = false;
+        std::shared_lock<std::shared_mutex> plans;
+        Lease() = default;
+        Lease(const Lease &) = delete;
+        Lease &operator=(const Lease &) = delete;
+        ~Lease() {
+            if (pl && ws) pl->check_in(ws, stream, host);
+        }
+    };
+    // which = 0: a _dev call on `stream`; 1: a host-slice call (runs on the workspace's own stream); 2: bookkeeping only
+    // (reserve_batch: any free eager workspace, nothing is enqueued)
+    int check_out(Lease &L, hipStream_t stream, int which = 0) const {
+        L.plans = std::shared_lock<std::shared_mutex>(plan_mu);
+        const bool cap = which == 0 && capturing(stream);
+        std::unique_lock<std::mutex> lk(mu);
+        Workspace *pick = nullptr;
+        for (;;) {
+            if (which == 0)  // 1. the workspace this stream used last: stream order protects its buffers
+                for (auto &w : pool)
+                    if (!w->busy && w->pending && w->stream == stream && (cap || !w->captured)) {
+                        pick = w.get();
+                        break;
+                    }
+            if (!pick && cap) {
+                // 1b. under capture nothing executes now and nothing may be allocated or queried: any eager workspace will
+                // do (the largest: least likely to need growing) -- it belongs to the graph from here on, so no eager call
+                // can meet a replay in it.  What was enqueued in it BEFORE the capture is ordered before the replays by
+                // the caller (a capture stream is always forked from the stream that did the warm-up).
+                for (auto &w : pool)
+                    if (!w->busy && !w->captured && (!pick || w->cap > pick->cap)) pick = w.get();
+            }
+            if (!pick && !cap) {  // 2. one with nothing in flight (never one that belongs to a captured graph)
+                for (auto &w : pool)
+                    if (!w->busy && !w->captured && !w->pending) {
+                        pick = w.get();
+                        break;
+                    }
+                if (!pick)
+                    for (auto &w : pool)
+                        if (!w->busy && !w->captured && !stream_capturing(w->stream) && hipStreamQuery(w->stream) == hipSuccess) {
+                            w->pending = false;
+                            pick = w.get();
+                            break;
+                        }
+                (void)hipGetLastError();  // hipErrorNotReady is an answer, not a failure
+            }
+            if (pick) break;
+            size_t eager = 0;
+            for (auto &w : pool) eager += !w->captured;
+            if (cap || eager < max_workspaces()) {  // 3. a new one
+                pool.emplace_back(new (std::nothrow) Workspace());
+                if (!pool.back()) {
+                    pool.pop_back();
+                    return PHAST_ERR_ALLOC;
+                }
+                pick = pool.back().get();
+                break;
+            }
+            // 4. pool exhausted: queue behind another stream's work ON THE DEVICE (never behind a stream that is being
+            // captured: recording an event there would become part of somebody's graph)
+            bool any_busy = false;
+            for (auto &w : pool) {
+                if (w->busy) any_busy = true;
+                else if (!w->captured && !stream_capturing(w->stream)) {
+                    pick = w.get();
+                    break;
+                }
+            }
+            if (pick) break;
+            if (!any_busy) {  // nothing to wait for: one workspace beyond the limit
+                pool.emplace_back(new (std::nothrow) Workspace());
+                if (!pool.back()) {
+                    pool.pop_back();
+                    return PHAST_ERR_ALLOC;
+                }
+                pick = pool.back().get();
+                break;
+            }
+            cv.wait(lk);  // 5. every candidate is checked out by a thread that is enqueueing: wait for one
+        }
+        pick->busy = true;
+        lk.unlock();
+        hipStream_t work = stream;
+        if (which == 1) {
+            if (!pick->own) {
+                hipError_t e = hipStreamCreateWithFlags(&pick->own, hipStreamNonBlocking);
+                if (e != hipSuccess) {
+                    std::lock_guard<std::mutex> g(mu);
+                    pick->busy = false;
+                    cv.notify_one();
+                    return hip_fail(e, "hipStreamCreateWithFlags(workspace stream)");
+                }
+            }
+            work = pick->own;
+        }
+        if (which != 2 && !cap && pick->pending && pick->stream != work) {
+            // the buffers change streams with work possibly in flight (case 4, or a host-slice call after a _dev call):
+            // order the new stream behind the old one's work on the device
+            hipEvent_t ev = nullptr;
+            hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventRecord(ev, pick->stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(work, ev, 0);
+            if (ev) hipEventDestroy(ev);
+            if (e != hipSuccess) {  // e.g. the old stream has been destroyed: its work is ordered before the destruction
+                (void)hipGetLastError();
+                (void)hipDeviceSynchronize();
+            }
+        }
+        L.pl = this;
+        L.ws = pick;
+        L.stream = work;
+        L.host = which == 1;
+        if (which != 2) {
+            if (cap) pick->captured = true;
+            pick->stream = work;
+            pick->pending = true;
+            if (!cap) pick->reap(work);
+        }
+        return PHAST_OK;
+    }
+    void check_in(Workspace *ws, hipStream_t, bool host_synchronised) const {
+        std::lock_guard<std::mutex> g(mu);
+        if (host_synchronised && !ws->captured) ws->pending = false;  // a host-slice call returns with its stream drained
+        ws->busy = false;
+        cv.notify_one();
+    }
 
     ~Planner() { release(); }
     // Host-slice calls up to this many staged bytes go through the pinned mirror (one memcpy each way on the host,
@@ -327,27 +523,29 @@ template <typename T> struct Planner {
         }();
         return v;
     }
-    int pinned(size_t bytes, void **out) const {
-        if (pin_bytes < bytes) {
-            retire(h_pin, pin_bytes, true);
-            h_pin = nullptr;
-            pin_bytes = 0;
-            PHAST_HIP(hipHostMalloc(&h_pin, bytes ? bytes : 1, hipHostMallocDefault));
-            pin_bytes = bytes;
+    int pinned(const Lease &L, size_t bytes, void **out) const {
+        Workspace &w = *L.ws;
+        if (w.pin_bytes < bytes) {
+            w.retire(w.h_pin, w.pin_bytes, true, L.stream);
+            w.h_pin = nullptr;
+            w.pin_bytes = 0;
+            PHAST_HIP(hipHostMalloc(&w.h_pin, bytes ? bytes : 1, hipHostMallocDefault));
+            w.pin_bytes = bytes;
         }
-        *out = h_pin;
+        *out = w.h_pin;
         return PHAST_OK;
     }
-    // device staging buffer of at least `bytes` (call with call_mu held)
-    int stage(size_t bytes, void **out) const {
-        if (stage_bytes < bytes) {
-            retire(d_stage, stage_bytes, false);
-            d_stage = nullptr;
-            stage_bytes = 0;
-            PHAST_HIP(hipMalloc(&d_stage, bytes ? bytes : 1));
-            stage_bytes = bytes;
+    // device staging buffer of at least `bytes`
+    int stage(const Lease &L, size_t bytes, void **out) const {
+        Workspace &w = *L.ws;
+        if (w.stage_bytes < bytes) {
+            w.retire(w.d_stage, w.stage_bytes, false, L.stream);
+            w.d_stage = nullptr;
+            w.stage_bytes = 0;
+            PHAST_HIP(hipMalloc(&w.d_stage, bytes ? bytes : 1));
+            w.stage_bytes = bytes;
         }
-        *out = d_stage;
+        *out = w.d_stage;
         return PHAST_OK;
     }
     static void free_passes(std::vector<PassDesc> &v) {
@@ -358,42 +556,33 @@ template <typename T> struct Planner {
         }
         v.clear();
     }
-    void retire_passes(std::vector<PassDesc> &v) {
+    void retire_passes(std::vector<PassDesc> &v) {  // plan_mu held exclusively
         for (auto &p : v) {
-            retire(p.d_tw3, p.pre_tw ? ((size_t)3 << p.tw_bits) * sizeof(cx_t<T>) : 0, false);
-            retire(p.d_twr, 64 * sizeof(cx_t<T>), false);
-            retire(p.d_twu, ((size_t)1 << p.lr) * sizeof(cx_t<T>), false);
+            for (void *t : {p.d_tw3, p.d_twr, p.d_twu})
+                if (t) old_tables.push_back(t);
+            old_table_bytes += (p.pre_tw ? ((size_t)3 << p.tw_bits) : 0) * sizeof(cx_t<T>) + 64 * sizeof(cx_t<T>) +
+                               (p.d_twu ? ((size_t)1 << p.lr) * sizeof(cx_t<T>) : 0);
         }
         v.clear();
     }
     void release_passes() {
-        for (auto &sp : strided_plans) free_passes(sp.passes);
+        for (auto &sp : strided_plans) free_passes(sp->passes);
         strided_plans.clear();
         free_passes(passes);
         free_passes(passes_lat);
         free_passes(passes_mid);
         free_passes(passes_one);
+        for (void *t : old_tables) hipFree(t);
+        old_tables.clear();
+        old_table_bytes = 0;
     }
     void release() {
         DeviceGuard on(device);
         release_passes();
         if (d_small_tw) hipFree(d_small_tw);
-        if (d_scratch) hipFree(reinterpret_cast<char *>(d_scratch) - scratch_guard);
-        if (d_stage) hipFree(d_stage);
-        if (h_pin) hipHostFree(h_pin);
-        for (const Retired &r : retired) {  // hipFree waits for the device: whatever still used them is done afterwards
-            if (r.pinned) hipHostFree(r.p);
-            else hipFree(r.p);
-            if (r.done) hipEventDestroy(r.done);
-        }
-        retired.clear();
-        retired_dev_bytes = 0;
-        h_pin = nullptr;
-        pin_bytes = 0;
         d_small_tw = nullptr;
-        d_scratch = nullptr;
-        d_stage = nullptr;
-        scratch_cap = stage_bytes = 0;
+        for (auto &w : pool) w->release();
+        pool.clear();
     }
 
     // the plan for `batch` transforms in flight: throughput when its tiles fill the chip, else the mid plan for
@@ -457,10 +646,10 @@ template <typename T> struct Planner {
             if (rc) return rc;
         }
         const size_t need = (size_t)scratch_elems(geo, log_n);
-        // exec() reads the pass vectors while holding call_mu: take it, so a plan is never swapped under a launch
-        // sequence; kernels already enqueued keep reading the old tables, which are therefore retired, not freed
-        std::lock_guard<std::recursive_mutex> call_lock(call_mu);
-        std::lock_guard<std::mutex> lk(mu);
+        // every call reads the pass vectors under a shared hold of plan_mu for as long as it enqueues: a plan is never
+        // swapped under a launch sequence; kernels already enqueued (or captured) keep reading the old tables, which
+        // are therefore kept until the planner goes, not freed
+        std::unique_lock<std::shared_mutex> plans(plan_mu);
         if (which == 2) {
             retire_passes(passes_lat);
             passes_lat = std::move(ps);
@@ -480,16 +669,9 @@ template <typename T> struct Planner {
             }
         }
         table_bytes = tb;
-        if (need > sstride()) {  // a plan with wider pitches than the scratch was cut for: the scratch is re-cut on next use
-            const size_t old_per = 2 * sstride() * sizeof(T);
-            scratch_stride = need;
-            if (d_scratch) {
-                retire(reinterpret_cast<char *>(d_scratch) - scratch_guard, scratch_cap * old_per + 2 * scratch_guard, false);
-                d_scratch = nullptr;
-                scratch_cap = 0;
-                scratch_guard = 0;
-            }
-        }
+        // a plan with wider pitches than the scratches were cut for: every workspace re-cuts its scratch on next use
+        // (ensure_scratch compares Workspace::per)
+        if (need > sstride()) scratch_stride = need;
         return PHAST_OK;
     }
 
@@ -535,42 +717,48 @@ template <typename T> struct Planner {
         return PHAST_OK;
     }
 
-    // scratch for `want` transforms in flight (capped by the target footprint, at least 1).  Grows geometrically: a
-    // sequence of slowly growing batches retires O(log) buffers whose sizes sum to less than the live one (and reap()
-    // frees them as soon as the work that used them is done).  Out of device memory: idle retired buffers are
+    // scratch for `want` transforms in flight (capped by the target footprint, at least 1) in the leased workspace.  Grows
+    // geometrically: a sequence of slowly growing batches retires O(log) buffers whose sizes sum to less than the live one
+    // (and reap() frees them as soon as the work that used them is done).  Out of device memory: idle retired buffers are
     // released, then the request is halved (exec() loops over chunks) down to the reserved batch.
-    int ensure_scratch(size_t batch, size_t *cap_out, bool exact = false, hipStream_t stream = nullptr) const {
+    int ensure_scratch(const Lease &L, size_t batch, size_t *cap_out, bool exact = false) const {
         if (passes.empty() && !exact) {  // whole transforms on chip: no scratch (strided batches of such sizes need one)
             *cap_out = batch;
             return PHAST_OK;
         }
-        std::lock_guard<std::mutex> lk(mu);
-        reap(stream);
+        Workspace &w = *L.ws;
+        hipStream_t stream = L.stream;
         const size_t per = 2 * sstride() * sizeof(T);
+        if (w.cap && w.per != per) {  // cut for another plan's pitches (set_plan): start over
+            w.retire(reinterpret_cast<char *>(w.d_scratch) - w.guard, w.cap * w.per + 2 * w.guard, false, stream);
+            w.d_scratch = nullptr;
+            w.cap = w.guard = 0;
+        }
+        w.per = per;
         size_t target = scratch_target_bytes() / (2 * n * sizeof(T));  // counted in transforms of the caller's size: the
         if (target < 1) target = 1;                                   // row padding of the scratch rides on top (1.5-3 %)
         if (target < reserve) target = reserve;
         size_t want = target;
         if (want > batch && batch >= reserve) want = batch;
         if (exact && want < batch) want = batch;  // work that cannot be cut into chunks (strided batches)
-        if (scratch_cap < want) {
-            if (!exact && scratch_cap && want < 2 * scratch_cap) want = std::min(2 * scratch_cap, std::max(target, want));
-            const size_t floor_cap = exact ? want : std::max<size_t>(std::max<size_t>(reserve, 1), scratch_cap + 1);
+        if (w.cap < want) {
+            if (!exact && w.cap && want < 2 * w.cap) want = std::min(2 * w.cap, std::max(target, want));
+            const size_t floor_cap = exact ? want : std::max<size_t>(std::max<size_t>(reserve, 1), w.cap + 1);
             const size_t guard = g_guard_bytes;
             void *d = nullptr;
             hipError_t e = hipMalloc(&d, want * per + 2 * guard);
             if (e == hipErrorOutOfMemory && !capturing(stream)) {
                 (void)hipGetLastError();
-                reap(stream, true);  // whatever retired buffers are idle (or become so) go first
+                w.reap(stream, true);  // whatever retired buffers are idle (or become so) go first
                 e = hipMalloc(&d, want * per + 2 * guard);
                 while (e == hipErrorOutOfMemory && want > floor_cap) {
                     (void)hipGetLastError();
                     want = std::max(floor_cap, want / 2);
                     e = hipMalloc(&d, want * per + 2 * guard);
                 }
-                if (e == hipErrorOutOfMemory && !exact && scratch_cap >= std::max<size_t>(reserve, 1)) {
+                if (e == hipErrorOutOfMemory && !exact && w.cap >= std::max<size_t>(reserve, 1)) {
                     (void)hipGetLastError();  // cannot grow: keep working in the chunks the present scratch allows
-                    *cap_out = scratch_cap;
+                    *cap_out = w.cap;
                     return PHAST_OK;
                 }
             }
@@ -579,28 +767,29 @@ template <typename T> struct Planner {
                 PHAST_HIP(hipMemset(d, kGuardFill, guard));
                 PHAST_HIP(hipMemset(reinterpret_cast<char *>(d) + guard + want * per, kGuardFill, guard));
             }
-            retire(d_scratch ? reinterpret_cast<char *>(d_scratch) - scratch_guard : nullptr, scratch_cap * per + 2 * scratch_guard, false);
-            d_scratch = reinterpret_cast<T *>(reinterpret_cast<char *>(d) + guard);
-            scratch_guard = guard;
-            scratch_cap = want;
+            w.retire(w.d_scratch ? reinterpret_cast<char *>(w.d_scratch) - w.guard : nullptr, w.cap * per + 2 * w.guard, false, stream);
+            w.d_scratch = reinterpret_cast<char *>(d) + guard;
+            w.guard = guard;
+            w.cap = want;
         }
-        *cap_out = scratch_cap;
+        *cap_out = w.cap;
         return PHAST_OK;
     }
 
-    // debug: bytes of the scratch's guard bands that no longer hold the fill value (blocks until the device is idle)
+    // debug: bytes of the scratches' guard bands that no longer hold the fill value (blocks until the device is idle)
     int check_guards(size_t *bad_out) const {
-        std::lock_guard<std::recursive_mutex> call_lock(call_mu);
         PHAST_ON_DEVICE(device);
+        std::lock_guard<std::mutex> lk(mu);
         size_t bad = 0;
-        if (d_scratch && scratch_guard) {
-            PHAST_HIP(hipDeviceSynchronize());
-            std::vector<unsigned char> h(scratch_guard);
-            const size_t per = 2 * sstride() * sizeof(T);
-            const char *lo = reinterpret_cast<const char *>(d_scratch) - scratch_guard;
-            const char *hi = reinterpret_cast<const char *>(d_scratch) + scratch_cap * per;
+        PHAST_HIP(hipDeviceSynchronize());
+        for (auto &wp : pool) {
+            const Workspace &w = *wp;
+            if (!w.d_scratch || !w.guard) continue;
+            std::vector<unsigned char> h(w.guard);
+            const char *lo = reinterpret_cast<const char *>(w.d_scratch) - w.guard;
+            const char *hi = reinterpret_cast<const char *>(w.d_scratch) + w.cap * w.per;
             for (const char *band : {lo, hi}) {
-                PHAST_HIP(hipMemcpy(h.data(), band, scratch_guard, hipMemcpyDeviceToHost));
+                PHAST_HIP(hipMemcpy(h.data(), band, w.guard, hipMemcpyDeviceToHost));
                 for (unsigned char c : h) bad += c != kGuardFill;
             }
         }
@@ -608,7 +797,12 @@ template <typename T> struct Planner {
         return PHAST_OK;
     }
     // live tables and scratch plus what is retired but not yet released
-    size_t device_bytes() const { return table_bytes + scratch_cap * 2 * sstride() * sizeof(T) + stage_bytes + retired_dev_bytes; }
+    size_t device_bytes() const {
+        std::lock_guard<std::mutex> lk(mu);
+        size_t b = table_bytes + old_table_bytes;
+        for (auto &w : pool) b += w->device_bytes();
+        return b;
+    }
 
     // tables + launch parameters of a pass list (shared by set_plan and the strided plans)
     int prepare_passes(std::vector<PassDesc> &ps, size_t *table_bytes_out) const {
@@ -695,32 +889,43 @@ template <typename T> struct Planner {
     // the caller's planes (forward arithmetic; `scale` on the last store).  make_strided_passes has the layouts.
     int exec_strided(T *re, T *im, unsigned s_bits, unsigned sb_bits, double scale, hipStream_t stream,
                      unsigned grid_log_n = 0, unsigned grid_col0 = 0) const {
-        std::lock_guard<std::recursive_mutex> call_lock(call_mu);
         PHAST_ON_DEVICE(device);
+        Lease L;
+        int rc = check_out(L, stream);
+        if (rc) return rc;
         const StridedPlan *plan = nullptr;
-        for (const auto &sp : strided_plans)
-            if (sp.s == s_bits && sp.sb == sb_bits && sp.grid_log_n == grid_log_n) plan = &sp;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (const auto &sp : strided_plans)
+                if (sp->s == s_bits && sp->sb == sb_bits && sp->grid_log_n == grid_log_n) plan = sp.get();
+        }
         if (!plan) {
             std::vector<PassGeom> geo;
             if (!make_strided_passes(log_n, s_bits, sb_bits, sizeof(T), geo, grid_log_n)) return PHAST_ERR_INVALID_ARG;
-            StridedPlan sp;
-            sp.s = s_bits;
-            sp.sb = sb_bits;
-            sp.grid_log_n = grid_log_n;
-            sp.passes.resize(geo.size());
-            for (size_t i = 0; i < geo.size(); ++i) static_cast<PassGeom &>(sp.passes[i]) = geo[i];
-            int rc = prepare_passes(sp.passes, nullptr);
+            std::unique_ptr<StridedPlan> sp(new StridedPlan());
+            sp->s = s_bits;
+            sp->sb = sb_bits;
+            sp->grid_log_n = grid_log_n;
+            sp->passes.resize(geo.size());
+            for (size_t i = 0; i < geo.size(); ++i) static_cast<PassGeom &>(sp->passes[i]) = geo[i];
+            rc = prepare_passes(sp->passes, nullptr);
             if (rc) return rc;
-            strided_plans.push_back(std::move(sp));
-            plan = &strided_plans.back();
+            std::lock_guard<std::mutex> lk(mu);
+            for (const auto &q : strided_plans)  // another thread may have built the same plan meanwhile
+                if (q->s == s_bits && q->sb == sb_bits && q->grid_log_n == grid_log_n) plan = q.get();
+            if (plan) {
+                free_passes(sp->passes);
+            } else {
+                strided_plans.push_back(std::move(sp));
+                plan = strided_plans.back().get();
+            }
         }
         // the whole [2^log_n][2^s] array is one unit of work: scratch for all of it (2^s "transforms" of n points)
         const size_t cols = (size_t)1 << s_bits;
         size_t cap = 0;
-        int rc = ensure_scratch(cols, &cap, true, stream);
+        rc = ensure_scratch(L, cols, &cap, true);
         if (rc) return rc;
-        last_stream = stream;
-        T *s_re = d_scratch, *s_im = d_scratch + cap * n;
+        T *s_re = reinterpret_cast<T *>(L.ws->d_scratch), *s_im = s_re + cap * n;
         const size_t np = plan->passes.size();
         for (size_t i = 0; i < np; ++i) {
             const PassDesc &p = plan->passes[i];
@@ -772,9 +977,7 @@ template <typename T> struct Planner {
                         size_t out_dist, size_t batch, double scale, const void *rtw3, unsigned rtw_bits,
                         hipStream_t stream) const {
         if (batch == 0) return PHAST_OK;
-        std::lock_guard<std::recursive_mutex> call_lock(call_mu);
-        PHAST_ON_DEVICE(device);
-        last_stream = stream;
+        PHAST_ON_DEVICE(device);  // no workspace: the one-pass kernel keeps whole transforms on chip
         const size_t chunk = (size_t)1 << 30;
         const size_t in_el = mode == 1 ? 2 * sizeof(T) : sizeof(T), out_el = mode == 1 ? sizeof(T) : 2 * sizeof(T);
         for (size_t b0 = 0; b0 < batch; b0 += chunk) {
@@ -816,16 +1019,32 @@ template <typename T> struct Planner {
         const unsigned min_log = fuse_min_log() ? fuse_min_log() : 23u;
         return r2c_fuse_enabled() && batch * n >= ((size_t)1 << min_log);
     }
-    // `fuse` (R2C): the last pass takes the untangle with it where its fused form exists; *fused_out says whether it did
+    // a _dev call: checks a workspace out for the enqueue
     int exec(const void *in_re, const void *in_im, size_t in_dist, unsigned in_mode, void *out_re, void *out_im,
              size_t out_dist, unsigned out_mode, size_t batch, double scale, hipStream_t stream,
-             PassTimer *timer = nullptr, const R2cFuse *fuse = nullptr, bool *fused_out = nullptr) const {
-        if (fused_out) *fused_out = false;
+             PassTimer *timer = nullptr) const {
         if (batch == 0) return PHAST_OK;
-        std::lock_guard<std::recursive_mutex> call_lock(call_mu);
         PHAST_ON_DEVICE(device);
+        Lease L;
+        if (!passes.empty()) {  // (the one-pass kernel keeps whole transforms on chip: nothing to check out)
+            int rc = check_out(L, stream);
+            if (rc) return rc;
+        } else {
+            L.stream = stream;
+        }
+        return exec_in(L, in_re, in_im, in_dist, in_mode, out_re, out_im, out_dist, out_mode, batch, scale, timer);
+    }
+    // The launches of one batched transform in the leased workspace, on L.stream.
+    // `fuse` (R2C): the last pass takes the untangle with it where its fused form exists; *fused_out says whether it did;
+    // *np_out = the number of passes of the plan that ran (the timer slots 0 .. np - 1 belong to them)
+    int exec_in(const Lease &L, const void *in_re, const void *in_im, size_t in_dist, unsigned in_mode, void *out_re,
+                void *out_im, size_t out_dist, unsigned out_mode, size_t batch, double scale, PassTimer *timer = nullptr,
+                const R2cFuse *fuse = nullptr, bool *fused_out = nullptr, size_t *np_out = nullptr) const {
+        if (fused_out) *fused_out = false;
+        if (np_out) *np_out = 1;
+        if (batch == 0) return PHAST_OK;
+        hipStream_t stream = L.stream;
         if (passes.empty()) {
-            last_stream = stream;
             const size_t chunk = (size_t)1 << 30;  // transforms per launch: the tile count stays below 2^32
             for (size_t b0 = 0; b0 < batch; b0 += chunk) {
                 SmallArgs sa{};
@@ -850,17 +1069,17 @@ template <typename T> struct Planner {
             return PHAST_OK;
         }
         size_t cap = 0;
-        int rc = ensure_scratch(batch, &cap, false, stream);
+        int rc = ensure_scratch(L, batch, &cap, false);
         if (rc) return rc;
-        last_stream = stream;
         const size_t sd = sstride();       // elements per transform and plane in the (padded) scratch
-        T *s_re = d_scratch;               // plane layout: all re planes, then all im planes
-        T *s_im = d_scratch + cap * sd;
+        T *s_re = reinterpret_cast<T *>(L.ws->d_scratch);  // plane layout: all re planes, then all im planes
+        T *s_im = s_re + cap * sd;
         // R2C: fused or not is decided ONCE per call, from the size of a full chunk -- a smaller tail chunk follows the others
         // (the caller runs the untangle sweep over the whole batch or not at all)
         const bool r2c_fuse = fuse && in_mode != 3 && fuse_pays(batch < cap ? batch : cap);
         const std::vector<PassDesc> &passes = in_mode == 3 ? plan_for_c2r(batch) : r2c_fuse ? plan_for_r2c(batch) : plan_for(batch);
         const size_t np = passes.size();
+        if (np_out) *np_out = np;
         for (size_t b0 = 0; b0 < batch; b0 += cap) {
             const size_t nb = batch - b0 < cap ? batch - b0 : cap;
             for (size_t i = 0; i < np; ++i) {
@@ -940,17 +1159,14 @@ template <typename T> struct Planner {
 // R2C planner (planner.rs:164-212)
 // ------------------------------------------------------------------------------------------------
 template <typename T> struct PlannerR2c {
+    using Lease = typename Planner<T>::Lease;
     size_t n = 0;
-    Planner<T> dit;
+    Planner<T> dit;         // the inner N/2-point transform; its workspace pool serves the real transforms too
     void *d_tw3 = nullptr;  // W_N^e three-level table for the untangle / c2r-preprocess passes
     unsigned tw_bits = 1;
-    mutable T *d_z = nullptr;  // C2R workspace [cap][2][n/2]
-    mutable size_t z_cap = 0;
-    mutable std::mutex mu;
     ~PlannerR2c() {
         DeviceGuard on(dit.device);
         if (d_tw3) hipFree(d_tw3);
-        if (d_z) hipFree(d_z);
     }
     int init(size_t n_) {
         n = n_;
@@ -959,35 +1175,37 @@ template <typename T> struct PlannerR2c {
         tw_bits = tw3_bits_for(ilog2(n));
         return upload<T>(host_tw3<T>(ilog2(n), tw_bits), &d_tw3);
     }
-    // C2R workspace for `batch` transforms (call with dit.call_mu held); outgrown ones are retired through the inner
-    // planner (freed once idle, Planner::reap), growth is geometric
-    int ensure_z(size_t batch, size_t *cap_out, hipStream_t stream) const {
-        std::lock_guard<std::mutex> lk(mu);
+    // unfused C2R: the preprocess workspace for `batch` transforms in the leased workspace; an outgrown one is retired
+    // (freed once idle, Workspace::reap), growth is geometric
+    int ensure_z(const Lease &L, size_t batch, size_t *cap_out) const {
+        Workspace &w = *L.ws;
+        hipStream_t stream = L.stream;
         const size_t per = n * sizeof(T);  // 2 planes of n/2
         size_t target = scratch_target_bytes() / per;
         if (target < 1) target = 1;
         size_t want = target < batch ? target : batch;
-        if (z_cap < want) {
-            if (z_cap && want < 2 * z_cap) want = std::min(2 * z_cap, target);
+        if (w.z_cap < want) {
+            if (w.z_cap && want < 2 * w.z_cap) want = std::min(2 * w.z_cap, target);
             void *d = nullptr;
             hipError_t e = hipMalloc(&d, want * per);
-            while (e == hipErrorOutOfMemory && want > z_cap + 1 && !Planner<T>::capturing(stream)) {
+            while (e == hipErrorOutOfMemory && want > w.z_cap + 1 && !Planner<T>::capturing(stream)) {
                 (void)hipGetLastError();
-                dit.reap(stream, true);
-                want = std::max(z_cap + 1, want / 2);
+                w.reap(stream, true);
+                want = std::max(w.z_cap + 1, want / 2);
                 e = hipMalloc(&d, want * per);
             }
-            if (e == hipErrorOutOfMemory && z_cap) {
+            if (e == hipErrorOutOfMemory && w.z_cap) {
                 (void)hipGetLastError();
-                *cap_out = z_cap;
+                *cap_out = w.z_cap;
                 return PHAST_OK;
             }
             if (e != hipSuccess) return hip_fail(e, "hipMalloc(c2r workspace)");
-            dit.retire(d_z, z_cap * per, false);
-            d_z = reinterpret_cast<T *>(d);
-            z_cap = want;
+            w.retire(w.d_z, w.z_bytes, false, stream);
+            w.d_z = d;
+            w.z_cap = want;
+            w.z_bytes = want * per;
         }
-        *cap_out = z_cap;
+        *cap_out = w.z_cap;
         return PHAST_OK;
     }
 
@@ -1001,24 +1219,33 @@ template <typename T> struct PlannerR2c {
         const auto &ps = dit.plan_for_c2r(batch);
         return !ps.empty() && ps.front().c2r_blocks > 0;
     }
-    size_t inner_passes(size_t batch) const {
-        return (dit.fuse_pays(batch) ? dit.plan_for_r2c(batch) : dit.plan_for(batch)).size();
-    }
-    // r2c.rs:535-593 / 607-662 on device pointers
+    // r2c.rs:535-593 / 607-662 on device pointers (a _dev call: checks a workspace out for the enqueue)
     int r2c(const T *d_in, T *d_ore, T *d_oim, size_t batch, size_t in_dist, size_t out_dist, hipStream_t s,
             PassTimer *timer = nullptr) const {
-        const size_t half = n / 2;
         if (in_dist & 1) return PHAST_ERR_INVALID_ARG;  // the input is read as (even, odd) pairs
-        std::lock_guard<std::recursive_mutex> call_lock(dit.call_mu);
         PHAST_ON_DEVICE(dit.device);
+        Lease L;
+        if (!dit.passes.empty()) {
+            int rc = dit.check_out(L, s);
+            if (rc) return rc;
+        } else {
+            L.stream = s;
+        }
+        return r2c_in(L, d_in, d_ore, d_oim, batch, in_dist, out_dist, timer);
+    }
+    int r2c_in(const Lease &L, const T *d_in, T *d_ore, T *d_oim, size_t batch, size_t in_dist, size_t out_dist,
+               PassTimer *timer = nullptr) const {
+        const size_t half = n / 2;
+        hipStream_t s = L.stream;
         if (dit.passes.empty())  // N/2 <= 8192: one kernel, the untangle is its epilogue
             return dit.exec_small_real(1, d_in, nullptr, in_dist / 2, d_ore, d_oim, out_dist, batch, 1.0, d_tw3, tw_bits, s);
         const R2cFuse fuse{d_tw3, tw_bits};
         bool fused = false;
-        int rc = dit.exec(d_in, nullptr, in_dist / 2, 1, d_ore, d_oim, out_dist, 0, batch, 1.0, s, timer, &fuse, &fused);
+        size_t np = 0;
+        int rc = dit.exec_in(L, d_in, nullptr, in_dist / 2, 1, d_ore, d_oim, out_dist, 0, batch, 1.0, timer, &fuse, &fused, &np);
         if (rc) return rc;
         if (fused) return PHAST_OK;  // the last pass wrote X[k] and X[h - k] itself (r2c_fused.hpp)
-        const int untangle_slot = (int)inner_passes(batch);  // timer slot after the inner transform's passes
+        const int untangle_slot = (int)np;  // timer slot after the passes of the plan that ran
         for (size_t b0 = 0; b0 < batch; b0 += 65535) {
             UntangleArgs ua{};
             ua.re = d_ore + b0 * out_dist;
@@ -1038,23 +1265,34 @@ template <typename T> struct PlannerR2c {
     // r2c.rs:740-790 / 836-895 on device pointers
     int c2r(const T *d_ire, const T *d_iim, T *d_out, size_t batch, size_t in_dist, size_t out_dist,
             hipStream_t s, PassTimer *timer = nullptr) const {
-        const size_t half = n / 2;
         if (out_dist & 1) return PHAST_ERR_INVALID_ARG;
-        std::lock_guard<std::recursive_mutex> call_lock(dit.call_mu);
         PHAST_ON_DEVICE(dit.device);
+        Lease L;
+        if (!dit.passes.empty()) {
+            int rc = dit.check_out(L, s);
+            if (rc) return rc;
+        } else {
+            L.stream = s;
+        }
+        return c2r_in(L, d_ire, d_iim, d_out, batch, in_dist, out_dist, timer);
+    }
+    int c2r_in(const Lease &L, const T *d_ire, const T *d_iim, T *d_out, size_t batch, size_t in_dist, size_t out_dist,
+               PassTimer *timer = nullptr) const {
+        const size_t half = n / 2;
+        hipStream_t s = L.stream;
         if (dit.passes.empty())  // N/2 <= 8192: one kernel, the preprocess is its prologue
             return dit.exec_small_real(2, d_ire, d_iim, in_dist, d_out, nullptr, out_dist / 2, batch, 1.0 / (double)half,
                                        d_tw3, tw_bits, s);
         if (c2r_fuses(batch)) {  // the first pass forms z on load: no preprocess sweep, no workspace (c2r_fused.hpp)
             const R2cFuse fuse{d_tw3, tw_bits};
-            return dit.exec(d_ire, d_iim, in_dist, 3, d_out, nullptr, out_dist / 2, 2, batch, 1.0 / (double)half, s, timer, &fuse);
+            return dit.exec_in(L, d_ire, d_iim, in_dist, 3, d_out, nullptr, out_dist / 2, 2, batch, 1.0 / (double)half, timer, &fuse);
         }
         size_t cap = 0;
-        int rc = ensure_z(batch, &cap, s);
+        int rc = ensure_z(L, batch, &cap);
         if (rc) return rc;
         for (size_t b0 = 0; b0 < batch; b0 += cap) {
             const size_t nb = batch - b0 < cap ? batch - b0 : cap;
-            T *z_re = d_z, *z_im = d_z + cap * half;
+            T *z_re = reinterpret_cast<T *>(L.ws->d_z), *z_im = z_re + cap * half;
             C2rPreArgs pa{};
             pa.in_re = d_ire + b0 * in_dist;
             pa.in_im = d_iim + b0 * in_dist;
@@ -1067,12 +1305,13 @@ template <typename T> struct PlannerR2c {
             pa.tw_bits = tw_bits;
             pa.batch = (unsigned)nb;
             hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (timer) PHAST_HIP(timer->pair((int)dit.plan_for(batch).size(), &e0, &e1));  // slot after the inner passes
+            // the sweep's timer slot sits after the inner passes: of the plan a chunk of nb transforms runs (exec_in
+            // picks it from nb too)
+            if (timer) PHAST_HIP(timer->pair((int)dit.plan_for(nb).size(), &e0, &e1));
             PHAST_HIP(launch_c2r_preprocess<T>(pa, s, e0, e1));
             // inverse by the swap trick (algorithms/dit.rs:297-300): forward FFT of (z_im, z_re), 1/half scale,
             // and the (positional re, positional im) = (caller im, caller re) pair is stored as (im, re)
-            rc = dit.exec(z_im, z_re, half, 0, d_out + b0 * out_dist, nullptr, out_dist / 2, 2, nb,
-                          1.0 / (double)half, s, timer);
+            rc = dit.exec_in(L, z_im, z_re, half, 0, d_out + b0 * out_dist, nullptr, out_dist / 2, 2, nb, 1.0 / (double)half, timer);
             if (rc) return rc;
         }
         return PHAST_OK;
@@ -1132,9 +1371,24 @@ template <typename T>
 static int fft_dev_many(T *const *d_re, T *const *d_im, size_t count, size_t n, int direction, const Planner<T> *pl,
                         hipStream_t s) {
     if (!pl || (!d_re && count) || (!d_im && count)) return PHAST_ERR_INVALID_ARG;
-    std::lock_guard<std::recursive_mutex> call_lock(pl->call_mu);
+    if (direction != PHAST_FORWARD && direction != PHAST_REVERSE) return PHAST_ERR_INVALID_ARG;
+    if (!is_pow2(n)) return PHAST_ERR_NOT_POW2;
+    if (ilog2(n) != pl->log_n) return PHAST_ERR_PLANNER_SIZE;
+    for (size_t i = 0; i < count; ++i)
+        if (!d_re[i] || !d_im[i]) return PHAST_ERR_INVALID_ARG;
+    if (count == 0) return PHAST_OK;
+    PHAST_ON_DEVICE(pl->device);
+    typename Planner<T>::Lease L;  // one workspace for the whole list: the transforms follow each other on the stream
+    if (!pl->passes.empty()) {
+        int rc = pl->check_out(L, s);
+        if (rc) return rc;
+    } else {
+        L.stream = s;
+    }
     for (size_t i = 0; i < count; ++i) {
-        int rc = fft_dev<T>(d_re[i], d_im[i], n, 1, n, direction, pl, s);
+        int rc = direction == PHAST_REVERSE
+                     ? pl->exec_in(L, d_im[i], d_re[i], n, 0, d_im[i], d_re[i], n, 0, 1, 1.0 / (double)n)
+                     : pl->exec_in(L, d_re[i], d_im[i], n, 0, d_re[i], d_im[i], n, 0, 1, 1.0);
         if (rc) return rc;
     }
     return PHAST_OK;
@@ -1167,9 +1421,9 @@ template <typename T>
 static int time_passes(const Planner<T> *pl, T *d_re, T *d_im, size_t batch, size_t dist, int reps, float *pass_ms,
                        int *n_passes, hipStream_t s) {
     if (!pl || !d_re || !d_im || !pass_ms || !n_passes || reps < 1) return PHAST_ERR_INVALID_ARG;
-    const int np = pl->passes.empty() ? 1 : (int)pl->plan_for(batch).size();
+    int np = 1;  // the slots the launches really used (a batch above the scratch runs in chunks, each with its own plan)
     PHAST_ON_DEVICE(pl->device);
-    double acc[3] = {0, 0, 0};
+    double acc[4] = {0, 0, 0, 0};
     for (int r = 0; r < reps; ++r) {
         PassTimer tm;
         int rc = pl->exec(d_re, d_im, dist, 0, d_re, d_im, dist, 0, batch, 1.0, s, &tm);
@@ -1178,7 +1432,8 @@ static int time_passes(const Planner<T> *pl, T *d_re, T *d_im, size_t batch, siz
         for (size_t i = 0; i < tm.pass_of.size(); ++i) {
             float ms = 0;
             PHAST_HIP(hipEventElapsedTime(&ms, tm.ev[2 * i], tm.ev[2 * i + 1]));
-            acc[tm.pass_of[i]] += ms;
+            acc[tm.pass_of[i] & 3] += ms;
+            np = std::max(np, (tm.pass_of[i] & 3) + 1);
         }
     }
     for (int i = 0; i < np; ++i) pass_ms[i] = (float)(acc[i] / reps);
@@ -1192,7 +1447,7 @@ template <typename T>
 static int time_passes_r2c(const PlannerR2c<T> *pl, const T *d_in, T *d_ore, T *d_oim, size_t batch, size_t in_dist,
                            size_t out_dist, int reps, float *pass_ms, int *n_passes, hipStream_t s) {
     if (!pl || !d_in || !d_ore || !d_oim || !pass_ms || !n_passes || reps < 1) return PHAST_ERR_INVALID_ARG;
-    const int np = pl->dit.passes.empty() ? 1 : (int)pl->inner_passes(batch) + (pl->fuses(batch) ? 0 : 1);
+    int np = 1;  // slots the launches really used: the plan and the fuse decision are exec_in's
     PHAST_ON_DEVICE(pl->dit.device);
     double acc[4] = {0, 0, 0, 0};
     for (int r = 0; r < reps; ++r) {
@@ -1204,7 +1459,8 @@ static int time_passes_r2c(const PlannerR2c<T> *pl, const T *d_in, T *d_ore, T *
         for (size_t i = 0; i < tm.pass_of.size(); ++i) {
             float ms = 0;
             PHAST_HIP(hipEventElapsedTime(&ms, tm.ev[2 * i], tm.ev[2 * i + 1]));
-            acc[tm.pass_of[i]] += ms;
+            acc[tm.pass_of[i] & 3] += ms;
+            np = std::max(np, (tm.pass_of[i] & 3) + 1);
         }
     }
     for (int i = 0; i < np; ++i) pass_ms[i] = (float)(acc[i] / reps);
@@ -1218,7 +1474,7 @@ template <typename T>
 static int time_passes_c2r(const PlannerR2c<T> *pl, const T *d_ire, const T *d_iim, T *d_out, size_t batch, size_t in_dist,
                            size_t out_dist, int reps, float *pass_ms, int *n_passes, hipStream_t s) {
     if (!pl || !d_ire || !d_iim || !d_out || !pass_ms || !n_passes || reps < 1) return PHAST_ERR_INVALID_ARG;
-    const int np = pl->dit.passes.empty() ? 1 : pl->c2r_fuses(batch) ? (int)pl->dit.plan_for_c2r(batch).size() : (int)pl->dit.plan_for(batch).size() + 1;
+    int np = 1;
     PHAST_ON_DEVICE(pl->dit.device);
     double acc[4] = {0, 0, 0, 0};
     for (int r = 0; r < reps; ++r) {
@@ -1230,7 +1486,8 @@ static int time_passes_c2r(const PlannerR2c<T> *pl, const T *d_ire, const T *d_i
         for (size_t i = 0; i < tm.pass_of.size(); ++i) {
             float ms = 0;
             PHAST_HIP(hipEventElapsedTime(&ms, tm.ev[2 * i], tm.ev[2 * i + 1]));
-            acc[tm.pass_of[i]] += ms;
+            acc[tm.pass_of[i] & 3] += ms;
+            np = std::max(np, (tm.pass_of[i] & 3) + 1);
         }
     }
     for (int i = 0; i < np; ++i) pass_ms[i] = (float)(acc[i] / reps);
@@ -1264,17 +1521,18 @@ struct DevBuf {
     }
 };
 
-// Host slices <-> the planner's device staging buffer.  `parts` are (host pointer, byte offset in the staging
-// buffer, bytes); small totals travel through the pinned mirror (see Planner::pinned_max_bytes).
+// Host slices <-> the leased workspace's device staging buffer, on the workspace's own stream.  `parts` are (host pointer,
+// byte offset in the staging buffer, bytes); small totals travel through the pinned mirror (Planner::pinned_max_bytes).
 struct HostPart {
     void *host;
     size_t off, bytes;
 };
 template <typename T>
-static int host_in(const Planner<T> *pl, void *d_stage, const HostPart *parts, int np, size_t total, bool small) {
+static int host_in(const Planner<T> *pl, const typename Planner<T>::Lease &L, void *d_stage, const HostPart *parts, int np,
+                   size_t total, bool small) {
     if (small) {
         void *pin = nullptr;
-        int rc = pl->pinned(total, &pin);
+        int rc = pl->pinned(L, total, &pin);
         if (rc) return rc;
         size_t lo = total, hi = 0;
         for (int i = 0; i < np; ++i) {
@@ -1282,32 +1540,35 @@ static int host_in(const Planner<T> *pl, void *d_stage, const HostPart *parts, i
             lo = std::min(lo, parts[i].off);
             hi = std::max(hi, parts[i].off + parts[i].bytes);
         }
-        if (hi > lo) PHAST_HIP(hipMemcpyAsync((char *)d_stage + lo, (char *)pin + lo, hi - lo, hipMemcpyHostToDevice, nullptr));
+        if (hi > lo) PHAST_HIP(hipMemcpyAsync((char *)d_stage + lo, (char *)pin + lo, hi - lo, hipMemcpyHostToDevice, L.stream));
         return PHAST_OK;
     }
+    // pageable memory: the runtime stages the copy; issued on the workspace's stream so that nothing waits on, or is
+    // waited for by, the NULL stream (other threads' calls on this planner run beside this one)
     for (int i = 0; i < np; ++i)
-        PHAST_HIP(hipMemcpy((char *)d_stage + parts[i].off, parts[i].host, parts[i].bytes, hipMemcpyHostToDevice));
+        PHAST_HIP(hipMemcpyAsync((char *)d_stage + parts[i].off, parts[i].host, parts[i].bytes, hipMemcpyHostToDevice, L.stream));
     return PHAST_OK;
 }
 template <typename T>
-static int host_out(const Planner<T> *pl, void *d_stage, const HostPart *parts, int np, size_t total, bool small) {
+static int host_out(const Planner<T> *pl, const typename Planner<T>::Lease &L, void *d_stage, const HostPart *parts, int np,
+                    size_t total, bool small) {
     if (small) {
         void *pin = nullptr;
-        int rc = pl->pinned(total, &pin);
+        int rc = pl->pinned(L, total, &pin);
         if (rc) return rc;
         size_t lo = total, hi = 0;
         for (int i = 0; i < np; ++i) {
             lo = std::min(lo, parts[i].off);
             hi = std::max(hi, parts[i].off + parts[i].bytes);
         }
-        if (hi > lo) PHAST_HIP(hipMemcpyAsync((char *)pin + lo, (char *)d_stage + lo, hi - lo, hipMemcpyDeviceToHost, nullptr));
-        PHAST_HIP(hipStreamSynchronize(nullptr));
+        if (hi > lo) PHAST_HIP(hipMemcpyAsync((char *)pin + lo, (char *)d_stage + lo, hi - lo, hipMemcpyDeviceToHost, L.stream));
+        PHAST_HIP(hipStreamSynchronize(L.stream));
         for (int i = 0; i < np; ++i) std::memcpy(parts[i].host, (char *)pin + parts[i].off, parts[i].bytes);
         return PHAST_OK;
     }
-    PHAST_HIP(hipStreamSynchronize(nullptr));
     for (int i = 0; i < np; ++i)
-        PHAST_HIP(hipMemcpy(parts[i].host, (char *)d_stage + parts[i].off, parts[i].bytes, hipMemcpyDeviceToHost));
+        PHAST_HIP(hipMemcpyAsync(parts[i].host, (char *)d_stage + parts[i].off, parts[i].bytes, hipMemcpyDeviceToHost, L.stream));
+    PHAST_HIP(hipStreamSynchronize(L.stream));
     return PHAST_OK;
 }
 
@@ -1319,7 +1580,9 @@ static bool zero_copy_small() {  // PHAST_ZERO_COPY=0: small host-slice calls st
     return v;
 }
 
-// lib.rs:143-226 on host slices: validate as the reference asserts, stage through device memory
+// lib.rs:143-226 on host slices: validate as the reference asserts, stage through device memory.  The call checks a
+// workspace out for its whole (blocking) duration and runs on that workspace's own stream: concurrent host threads on
+// one planner overlap their copies and kernels (planner.rs:38-39).
 template <typename T>
 static int fft_host(T *re, size_t re_len, T *im, size_t im_len, int direction, const Planner<T> *pl) {
     if (!pl || (!re && re_len) || (!im && im_len)) return PHAST_ERR_INVALID_ARG;
@@ -1328,66 +1591,76 @@ static int fft_host(T *re, size_t re_len, T *im, size_t im_len, int direction, c
     if (!is_pow2(re_len)) return PHAST_ERR_NOT_POW2;          // dit.rs:285
     if (ilog2(re_len) != pl->log_n) return PHAST_ERR_PLANNER_SIZE;  // dit.rs:289
     const size_t n = re_len, bytes = n * sizeof(T), total = 2 * bytes;
-    std::lock_guard<std::recursive_mutex> call_lock(pl->call_mu);
     PHAST_ON_DEVICE(pl->device);
-    pl->reap(nullptr);
-    void *stage = nullptr;
-    int rc = pl->stage(total, &stage);
+    typename Planner<T>::Lease L;
+    int rc = pl->check_out(L, nullptr, 1);
     if (rc) return rc;
+    const double scale = direction == PHAST_REVERSE ? 1.0 / (double)n : 1.0;
     const bool small = total <= Planner<T>::pinned_max_bytes();
     const HostPart parts[2] = {{re, 0, bytes}, {im, bytes, bytes}};
     if (small && zero_copy_small()) {
         // Up to the pinned limit (1 MiB of planes: N <= 2^16 in f64) the kernels read and write the pinned mirror themselves
-        // over PCIe (pinned host memory is device-accessible): no DMA copy either way, one wait per call.  A multi-pass
-        // transform touches the mirror in its first load and its last store only (tools/host_call_cost.py: 2^12 43.7 ->
-        // 30.3 us per call, 2^14 67 -> 52, 2^16 143 -> 127).
+        // over PCIe (pinned host memory is device-accessible): no DMA copy either way, one wait per call, and no device
+        // staging buffer at all.  A multi-pass transform touches the mirror in its first load and its last store only
+        // (tools/host_call_cost.py: 2^12 43.7 -> 30.3 us per call, 2^14 67 -> 52, 2^16 143 -> 127).
         void *pin = nullptr;
-        rc = pl->pinned(total, &pin);
+        rc = pl->pinned(L, total, &pin);
         if (rc) return rc;
         T *p_re = reinterpret_cast<T *>(pin), *p_im = p_re + n;
         std::memcpy(p_re, re, bytes);
         std::memcpy(p_im, im, bytes);
-        rc = fft_dev<T>(p_re, p_im, n, 1, n, direction, pl, nullptr);
+        rc = direction == PHAST_REVERSE ? pl->exec_in(L, p_im, p_re, n, 0, p_im, p_re, n, 0, 1, scale)
+                                        : pl->exec_in(L, p_re, p_im, n, 0, p_re, p_im, n, 0, 1, scale);
         if (rc) return rc;
-        PHAST_HIP(hipStreamSynchronize(nullptr));
+        PHAST_HIP(hipStreamSynchronize(L.stream));
         std::memcpy(re, p_re, bytes);
         std::memcpy(im, p_im, bytes);
         return PHAST_OK;
     }
+    void *stage = nullptr;
+    rc = pl->stage(L, total, &stage);
+    if (rc) return rc;
     T *d_re = reinterpret_cast<T *>(stage), *d_im = d_re + n;
-    rc = host_in(pl, stage, parts, 2, total, small);
-    if (!rc) rc = fft_dev<T>(d_re, d_im, n, 1, n, direction, pl, nullptr);
-    if (!rc) rc = host_out(pl, stage, parts, 2, total, small);
+    rc = host_in(pl, L, stage, parts, 2, total, small);
+    if (!rc)
+        rc = direction == PHAST_REVERSE ? pl->exec_in(L, d_im, d_re, n, 0, d_im, d_re, n, 0, 1, scale)
+                                        : pl->exec_in(L, d_re, d_im, n, 0, d_re, d_im, n, 0, 1, scale);
+    if (!rc) rc = host_out(pl, L, stage, parts, 2, total, small);
     return rc;
 }
 
 template <typename T> static int fft_interleaved_host(T *signal, size_t n, int direction, const Planner<T> *pl) {
     if (!pl || (!signal && n)) return PHAST_ERR_INVALID_ARG;
+    if (direction != PHAST_FORWARD && direction != PHAST_REVERSE) return PHAST_ERR_INVALID_ARG;
     if (!is_pow2(n)) return PHAST_ERR_NOT_POW2;
     if (ilog2(n) != pl->log_n) return PHAST_ERR_PLANNER_SIZE;
-    std::lock_guard<std::recursive_mutex> call_lock(pl->call_mu);
     PHAST_ON_DEVICE(pl->device);
-    pl->reap(nullptr);
-    const size_t total = 2 * n * sizeof(T);
-    void *stage = nullptr;
-    int rc = pl->stage(total, &stage);
+    typename Planner<T>::Lease L;
+    int rc = pl->check_out(L, nullptr, 1);
     if (rc) return rc;
+    const size_t total = 2 * n * sizeof(T);
     const bool small = total <= Planner<T>::pinned_max_bytes();
     const HostPart parts[1] = {{signal, 0, total}};
+    // swap trick for the inverse: read (im, re), transform, store (im, re) scaled by 1/N (fft_interleaved_dev)
+    const unsigned mode = direction == PHAST_REVERSE ? 2u : 1u;
+    const double scale = direction == PHAST_REVERSE ? 1.0 / (double)n : 1.0;
     if (small && zero_copy_small()) {  // the kernels work on the pinned mirror itself, as in fft_host
         void *pin = nullptr;
-        rc = pl->pinned(total, &pin);
+        rc = pl->pinned(L, total, &pin);
         if (rc) return rc;
         std::memcpy(pin, signal, total);
-        rc = fft_interleaved_dev<T>(reinterpret_cast<T *>(pin), n, 1, n, direction, pl, nullptr);
+        rc = pl->exec_in(L, pin, nullptr, n, mode, pin, nullptr, n, mode, 1, scale);
         if (rc) return rc;
-        PHAST_HIP(hipStreamSynchronize(nullptr));
+        PHAST_HIP(hipStreamSynchronize(L.stream));
         std::memcpy(signal, pin, total);
         return PHAST_OK;
     }
-    rc = host_in(pl, stage, parts, 1, total, small);
-    if (!rc) rc = fft_interleaved_dev<T>(reinterpret_cast<T *>(stage), n, 1, n, direction, pl, nullptr);
-    if (!rc) rc = host_out(pl, stage, parts, 1, total, small);
+    void *stage = nullptr;
+    rc = pl->stage(L, total, &stage);
+    if (rc) return rc;
+    rc = host_in(pl, L, stage, parts, 1, total, small);
+    if (!rc) rc = pl->exec_in(L, stage, nullptr, n, mode, stage, nullptr, n, mode, 1, scale);
+    if (!rc) rc = host_out(pl, L, stage, parts, 1, total, small);
     return rc;
 }
 
@@ -1438,6 +1711,13 @@ template <typename P> struct PlannerCache {
             std::shared_ptr<P> evicted;  // released outside the lock (frees device memory)
             {
                 std::lock_guard<std::mutex> lk(mu);
+                for (Entry &e : entries)  // a concurrent miss of the same size got there first: use its planner, drop ours
+                    if (e.n == n && e.device == dev) {
+                        e.stamp = ++clock;
+                        evicted = std::move(*out);
+                        *out = e.pl;
+                        return PHAST_OK;
+                    }
                 if (entries.size() >= kMaxEntries) {
                     size_t lru = 0;
                     for (size_t i = 1; i < entries.size(); ++i)
@@ -1472,33 +1752,34 @@ static int r2c_host(const T *in, size_t in_len, T *ore, size_t ore_len, T *oim, 
     if (in_len != n) return PHAST_ERR_R2C_INPUT_LEN;
     if (ore_len != half + 1) return PHAST_ERR_R2C_OUT_RE_LEN;
     if (oim_len != half + 1) return PHAST_ERR_R2C_OUT_IM_LEN;
-    std::lock_guard<std::recursive_mutex> call_lock(pl->dit.call_mu);
     PHAST_ON_DEVICE(pl->dit.device);
-    pl->dit.reap(nullptr);
-    const size_t ob = (half + 1) * sizeof(T), total = n * sizeof(T) + 2 * ob;
-    void *stage = nullptr;
-    int rc = pl->dit.stage(total, &stage);
+    typename Planner<T>::Lease L;
+    int rc = pl->dit.check_out(L, nullptr, 1);
     if (rc) return rc;
+    const size_t ob = (half + 1) * sizeof(T), total = n * sizeof(T) + 2 * ob;
     const bool small = total <= Planner<T>::pinned_max_bytes();
-    T *d_in = reinterpret_cast<T *>(stage), *d_ore = d_in + n, *d_oim = d_ore + half + 1;
     const HostPart pin[1] = {{const_cast<T *>(in), 0, n * sizeof(T)}};
     const HostPart pout[2] = {{ore, n * sizeof(T), ob}, {oim, n * sizeof(T) + ob, ob}};
     if (small && pl->dit.passes.empty() && zero_copy_small()) {  // one kernel on the pinned mirror itself, as fft_host
         void *pm = nullptr;
-        rc = pl->dit.pinned(total, &pm);
+        rc = pl->dit.pinned(L, total, &pm);
         if (rc) return rc;
         T *p_in = reinterpret_cast<T *>(pm), *p_ore = p_in + n, *p_oim = p_ore + half + 1;
         std::memcpy(p_in, in, n * sizeof(T));
-        rc = pl->r2c(p_in, p_ore, p_oim, 1, n, half + 1, nullptr);
+        rc = pl->r2c_in(L, p_in, p_ore, p_oim, 1, n, half + 1);
         if (rc) return rc;
-        PHAST_HIP(hipStreamSynchronize(nullptr));
+        PHAST_HIP(hipStreamSynchronize(L.stream));
         std::memcpy(ore, p_ore, ob);
         std::memcpy(oim, p_oim, ob);
         return PHAST_OK;
     }
-    rc = host_in(&pl->dit, stage, pin, 1, total, small);
-    if (!rc) rc = pl->r2c(d_in, d_ore, d_oim, 1, n, half + 1, nullptr);
-    if (!rc) rc = host_out(&pl->dit, stage, pout, 2, total, small);
+    void *stage = nullptr;
+    rc = pl->dit.stage(L, total, &stage);
+    if (rc) return rc;
+    T *d_in = reinterpret_cast<T *>(stage), *d_ore = d_in + n, *d_oim = d_ore + half + 1;
+    rc = host_in(&pl->dit, L, stage, pin, 1, total, small);
+    if (!rc) rc = pl->r2c_in(L, d_in, d_ore, d_oim, 1, n, half + 1);
+    if (!rc) rc = host_out(&pl->dit, L, stage, pout, 2, total, small);
     return rc;
 }
 
@@ -1512,33 +1793,34 @@ static int c2r_host(const T *ire, size_t ire_len, const T *iim, size_t iim_len, 
     if (iim_len != half + 1) return PHAST_ERR_C2R_IN_IM_LEN;
     if (check_scratch && sre_len != half) return PHAST_ERR_C2R_SCRATCH_RE;
     if (check_scratch && sim_len != half) return PHAST_ERR_C2R_SCRATCH_IM;
-    std::lock_guard<std::recursive_mutex> call_lock(pl->dit.call_mu);
     PHAST_ON_DEVICE(pl->dit.device);
-    pl->dit.reap(nullptr);
-    const size_t ib = (half + 1) * sizeof(T), total = n * sizeof(T) + 2 * ib;
-    void *stage = nullptr;
-    int rc = pl->dit.stage(total, &stage);
+    typename Planner<T>::Lease L;
+    int rc = pl->dit.check_out(L, nullptr, 1);
     if (rc) return rc;
+    const size_t ib = (half + 1) * sizeof(T), total = n * sizeof(T) + 2 * ib;
     const bool small = total <= Planner<T>::pinned_max_bytes();
-    T *d_out = reinterpret_cast<T *>(stage), *d_ire = d_out + n, *d_iim = d_ire + half + 1;
     const HostPart pin[2] = {{const_cast<T *>(ire), n * sizeof(T), ib}, {const_cast<T *>(iim), n * sizeof(T) + ib, ib}};
     const HostPart pout[1] = {{out, 0, n * sizeof(T)}};
     if (small && pl->dit.passes.empty() && zero_copy_small()) {  // one kernel on the pinned mirror itself, as fft_host
         void *pm = nullptr;
-        rc = pl->dit.pinned(total, &pm);
+        rc = pl->dit.pinned(L, total, &pm);
         if (rc) return rc;
         T *p_out = reinterpret_cast<T *>(pm), *p_ire = p_out + n, *p_iim = p_ire + half + 1;
         std::memcpy(p_ire, ire, ib);
         std::memcpy(p_iim, iim, ib);
-        rc = pl->c2r(p_ire, p_iim, p_out, 1, half + 1, n, nullptr);
+        rc = pl->c2r_in(L, p_ire, p_iim, p_out, 1, half + 1, n);
         if (rc) return rc;
-        PHAST_HIP(hipStreamSynchronize(nullptr));
+        PHAST_HIP(hipStreamSynchronize(L.stream));
         std::memcpy(out, p_out, n * sizeof(T));
         return PHAST_OK;
     }
-    rc = host_in(&pl->dit, stage, pin, 2, total, small);
-    if (!rc) rc = pl->c2r(d_ire, d_iim, d_out, 1, half + 1, n, nullptr);
-    if (!rc) rc = host_out(&pl->dit, stage, pout, 1, total, small);
+    void *stage = nullptr;
+    rc = pl->dit.stage(L, total, &stage);
+    if (rc) return rc;
+    T *d_out = reinterpret_cast<T *>(stage), *d_ire = d_out + n, *d_iim = d_ire + half + 1;
+    rc = host_in(&pl->dit, L, stage, pin, 2, total, small);
+    if (!rc) rc = pl->c2r_in(L, d_ire, d_iim, d_out, 1, half + 1, n);
+    if (!rc) rc = host_out(&pl->dit, L, stage, pout, 1, total, small);
     return rc;
 }
 
@@ -1722,11 +2004,14 @@ int phast_options_guess(size_t input_size, phast_options *out) {
     }                                                                                                              \
     int phast_planner_dit##SFX##_reserve_batch(phast_planner_dit##SFX *p, size_t max_batch) {                      \
         if (!p || max_batch == 0) return PHAST_ERR_INVALID_ARG;                                                    \
-        std::lock_guard<std::recursive_mutex> call_lock(p->call_mu);                                               \
         PHAST_ON_DEVICE(p->device);                                                                                \
         p->reserve = max_batch;                                                                                    \
+        Planner<T>::Lease L;                                                                                       \
+        int rc = p->check_out(L, nullptr, 2);                                                                      \
+        if (rc) return rc;                                                                                         \
+        L.stream = L.ws->pending ? L.ws->stream : nullptr;                                                         \
         size_t cap;                                                                                                \
-        return p->ensure_scratch(max_batch, &cap);                                                                 \
+        return p->ensure_scratch(L, max_batch, &cap);                                                              \
     }                                                                                                              \
     int phast_planner_dit##SFX##_set_plan(phast_planner_dit##SFX *p, const unsigned *lr, const unsigned *tl,       \
                                           size_t np, unsigned points_log) {                                        \
