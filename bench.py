@@ -201,6 +201,16 @@ def roofline_of(pass_ms, alg_bytes, names=None, plan_used=""):
     }, dom
 
 
+def add_copy_frac(roof, sp):
+    """quote a config's dominant kernel -- and every pass -- against the hand-written copy kernel's rate (stream_probe)"""
+    if not roof or not sp or "pass_ms" not in roof or "achieved" not in roof:
+        return
+    roof["frac_of_copy"] = roof["achieved"] / sp["copy"]
+    per = roof.get("algorithmic_bytes_per_launch")
+    if per:
+        roof["pass_frac_of_copy"] = [per / (t * 1e-3) / 1e9 / sp["copy"] for t in roof["pass_ms"]]
+
+
 def hbm_copy_probe(torch, dev, mib: int = 1024, reps: int = 10):
     """Device-to-device copy of ``mib`` MiB (read + write counted): what this box's HBM gives a plain streaming
     kernel, reported beside the 8 TB/s spec peak (SURVEY.md 8d "bounding roofline")."""
@@ -661,14 +671,22 @@ def main():
                 touch=lambda: P.fft_64_dit_with_planner(*views[0], P.Direction.Forward, planner))
             P.fill_uniform(views[0][0], views[0][1], N, seed=0xCAFE, first_id=0)
         torch.cuda.synchronize()
+        # HIP events around the K timed steps, on the stream they are launched on (torch's current
+        # stream: the graph replay / the library's launches go there); the wall clock around the same region --
+        # synchronize, K steps, synchronize -- is kept beside it as ms_per_step_wall (it adds the fixed ~50 us of one graph
+        # launch + the closing synchronisation to the K steps: profiles/r03_graph_protocol.log)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
+        ev0.record()
         if graph is not None:
             graph.replay()
         else:
             for i in range(steps):
                 step(warmup + i)
+        ev1.record()
         torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
+        elapsed_wall = time.perf_counter() - t0
+        elapsed = ev0.elapsed_time(ev1) * 1e-3
         samples_per_step = N
         workload = f"single f64 forward FFT N=2^{LOG_N}, in place, planar (BASELINE configs[1])"
         # --- roofline of the dominant pass kernel, HIP events bound to the dispatches (fresh buffers) ---
@@ -722,6 +740,7 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
         elapsed = max_over_ranks(time.perf_counter() - t0, dist, dev)
+        elapsed_wall = elapsed
         # after the timed region: every rank checks its shard (Parseval on all, sampled ids against the oracle), then
         # the trivial gather (RCCL over xGMI): one 32-byte digest per transform -> (total, 4) on every rank
         ok, check_info, state["digest"] = check_shard(P, torch, re, im, refill, sb.step, first, shard)
@@ -751,6 +770,10 @@ def main():
             "metric": "GSamples/s f64 forward FFT N=2^20" + (" (N=2^26, round trip, R2C: see configs)" if not multi else ""),
             "value": value, "unit": "GSamples/s",
             "n_gpus": n_gpus, "steps": steps, "warmup": warmup, "ms_per_step": ms_per_step,
+            "ms_per_step_wall": 1e3 * elapsed_wall / steps,
+            "timing": ("HIP events on the launch stream around the K steps (SURVEY.md 8d); ms_per_step_wall = wall clock "
+                       "around synchronize + K steps + synchronize" if not multi else
+                       "wall clock between barrier + synchronize on both sides, MAX over ranks"),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic (counter-based uniform [-1,1), seed 0xCAFE, generated on device)",
             "config": {"workload": workload, "n": N, "transforms_per_step": samples_per_step // N,
@@ -770,8 +793,14 @@ def main():
             roofline.update(traffic)
         if not multi:
             probe = hbm_copy_probe(torch, dev)
-            roofline["copy_probe_GBps"] = probe          # measured d2d copy rate of this box, same run
+            roofline["copy_probe_GBps"] = probe          # torch's d2d copy_ on this box, same run (kept for continuity)
             roofline["frac_of_copy_probe"] = achieved / probe
+            # the ceilings that matter: the library's own hand-written read / write / copy kernels on 1 GiB, this box, this
+            # run (csrc/probe.hip).  A pass reads and writes every byte once: `copy` is what 100 % looks like for it here.
+            sp = P.stream_probe(1024, 5)
+            roofline["stream_probe"] = sp
+            roofline["frac_of_copy"] = achieved / sp["copy"]
+            roofline["pass_frac_of_copy"] = [alg_bytes / (t * 1e-3) / 1e9 / sp["copy"] for t in pass_ms]
             torch.cuda.empty_cache()
         cpu = not multi and not args.no_cpu_baseline
         if cpu:
@@ -786,8 +815,13 @@ def main():
             t26 = load_profiled_traffic_key("single_2p26", fwd["roofline"])
             if t26:
                 fwd["roofline"].update(t26)
+            for c in out["configs"].values():   # every config's passes against the copy kernel of this box, this run
+                add_copy_frac(c.get("roofline"), sp)
+            c2r = out["configs"]["c2r_f32_2p24"]
+            c2r["pass_frac_of_copy"] = [8 * (1 << 24) / (t * 1e-3) / 1e9 / sp["copy"] for t in c2r["pass_ms"]]
         if not multi and not args.no_scaling_reference:
             out["weak_scaling_reference"] = shard_on_one_gpu(P, torch, dev, args.shard)
+            add_copy_frac(out["weak_scaling_reference"]["roofline"], sp)
         print(json.dumps(out), flush=True)
     if multi:
         import torch.distributed as dist

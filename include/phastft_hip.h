@@ -250,6 +250,14 @@ int phast_digest_f64_dev(const double *d_reals, const double *d_imags, size_t n,
 int phast_digest_f32_dev(const float *d_reals, const float *d_imags, size_t n, size_t batch, size_t dist,
                          size_t probe, double *d_digest, void *stream);
 
+/* harness: the streaming ceilings of the current device, measured with hand-written grid-stride kernels (probe.hip):
+ * d_a (read) and d_b (written) are device buffers of `bytes` each (a multiple of 16, >= 1 MiB; use >= 1 GiB so that
+ * the 256 MiB Infinity Cache does not help); out_gbps[3] = {read-only, write-only, 1:1 copy with read + write counted}
+ * in GB/s, each the best of several access widths / grid sizes over `reps` back-to-back launches.  Blocks until done.
+ * bench.py reports them as roofline.stream_probe: the copy figure is what a pass that reads and writes every byte once
+ * can reach on this box. */
+int phast_stream_probe_dev(const void *d_a, void *d_b, size_t bytes, int reps, double *out_gbps, void *stream);
+
 /* The _dev entry points are stream-capture safe (no allocation, no synchronisation in the steady state), so a
  * launch-bound sequence of transforms is captured into a HIP graph with the plain HIP API around them.  This helper is
  * hipGraphUpload for hosts that hold a hipGraphExec_t but cannot call HIP themselves (bench.py: the exec handle of a

@@ -741,6 +741,21 @@ def digest(reals, imags, n: int, probe: int = 1):
     return out
 
 
+def stream_probe(mib: int = 1024, reps: int = 5) -> dict:
+    """This box's HBM streaming ceilings from the library's hand-written probe kernels (csrc/probe.hip): GB/s of a
+    read-only, a write-only and a 1:1 copy kernel (read + write counted) over two buffers of ``mib`` MiB -- the figure a
+    pass that reads and writes every byte once is to be read against."""
+    import torch
+
+    a = torch.empty(mib << 17, dtype=torch.float64, device="cuda").fill_(1.0)
+    b = torch.empty_like(a)
+    out = (C.c_double * 3)()
+    _check(_lib.lib().phast_stream_probe_dev(C.c_void_p(a.data_ptr()), C.c_void_p(b.data_ptr()), C.c_size_t(mib << 20),
+                                             C.c_int(reps), out, _stream()))
+    del a, b
+    return {"read": out[0], "write": out[1], "copy": out[2], "unit": "GB/s", "MiB": mib}
+
+
 def debug_set_guard_bytes(nbytes: int) -> None:
     """debug: scratch buffers allocated from now on carry `nbytes` of 0xA5 guard band on either side"""
     _lib.lib().phast_debug_set_guard_bytes(C.c_size_t(nbytes))

@@ -32,7 +32,7 @@ phast_r2c_fft_f64_dev phast_r2c_fft_f32_dev
 phast_c2r_fft_f64 phast_c2r_fft_f32 phast_c2r_fft_f64_with_planner phast_c2r_fft_f32_with_planner
 phast_c2r_fft_f64_with_planner_and_scratch phast_c2r_fft_f32_with_planner_and_scratch
 phast_c2r_fft_f64_dev phast_c2r_fft_f32_dev
-phast_fill_f64_dev phast_fill_f32_dev phast_digest_f64_dev phast_digest_f32_dev phast_hip_graph_upload
+phast_fill_f64_dev phast_fill_f32_dev phast_digest_f64_dev phast_digest_f32_dev phast_hip_graph_upload phast_stream_probe_dev
 phast_planner_dit64_set_plan phast_planner_dit32_set_plan
 phast_planner_dit64_time_passes phast_planner_dit32_time_passes phast_debug_set_wg_per_cu phast_debug_set_trace
 phast_debug_set_guard_bytes phast_planner_dit64_debug_check_guards phast_planner_dit32_debug_check_guards

@@ -23,7 +23,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libphastft_hip.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
-UNITS = ["api", "tile_f64_a", "tile_f64_bc", "tile_f64_bc_wide", "tile_f32_a", "tile_f32_bc", "tile_f32_bc_wide", "tile_f64_r2c", "tile_f32_r2c", "tile_f64_c2r", "tile_f32_c2r", "wave_f64", "wave_f32", "quad_f64", "small_fft", "bitrev", "r2c", "fill", "twiddle"]
+UNITS = ["api", "tile_f64_a", "tile_f64_bc", "tile_f64_bc_wide", "tile_f32_a", "tile_f32_bc", "tile_f32_bc_wide", "tile_f64_r2c", "tile_f32_r2c", "tile_f64_c2r", "tile_f32_c2r", "wave_f64", "wave_f32", "quad_f64", "small_fft", "bitrev", "r2c", "fill", "probe", "twiddle"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-ffp-contract=fast", "-Rpass-analysis=kernel-resource-usage"]
 # per-unit compiler options (the scheduling strategy is a translation-unit option: tile_dispatch.hpp says why)

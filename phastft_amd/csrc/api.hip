@@ -1949,6 +1949,15 @@ int phast_hip_graph_upload(void *graph_exec, void *stream) {
     return PHAST_OK;
 }
 
+int phast_stream_probe_dev(const void *d_a, void *d_b, size_t bytes, int reps, double *out_gbps, void *stream) {
+    if (!d_a || !d_b || !out_gbps || reps < 1 || bytes < ((size_t)1 << 20) || (bytes & 15)) return PHAST_ERR_INVALID_ARG;
+    int dev = 0;
+    int rc = ensure_device(&dev);
+    if (rc) return rc;
+    PHAST_HIP(stream_probe(d_a, d_b, bytes, reps, cus_of(dev), out_gbps, static_cast<hipStream_t>(stream)));
+    return PHAST_OK;
+}
+
 void phast_debug_set_guard_bytes(size_t bytes) { g_guard_bytes = (bytes + 255) & ~(size_t)255; }
 
 void phast_debug_set_wg_per_cu(int wg_per_cu) { g_wg_per_cu_override = wg_per_cu; }
