@@ -330,6 +330,13 @@ int phast_planner_r2c64_time_c2r_passes(const phast_planner_r2c64 *p, const doub
 int phast_planner_r2c32_time_c2r_passes(const phast_planner_r2c32 *p, const float *d_input_re, const float *d_input_im,
                                         float *d_output, size_t batch, size_t in_dist, size_t out_dist, int reps,
                                         float *pass_ms, int *n_passes, void *stream);
+/* tuning hook, as phast_planner_dit*_set_plan but for the inner N/2-point transform of a real-transform planner (R2C and
+ * C2R then run that plan for every batch size; np = 0 restores the library's own plans).  tools/sweep_real.py */
+int phast_planner_r2c64_set_inner_plan(phast_planner_r2c64 *p, const unsigned *log_rows, const unsigned *tile_logs,
+                                       size_t n_passes, unsigned points_log);
+int phast_planner_r2c32_set_inner_plan(phast_planner_r2c32 *p, const unsigned *log_rows, const unsigned *tile_logs,
+                                       size_t n_passes, unsigned points_log);
+
 /* plan of the inner N/2-point complex transform, as phast_planner_dit*_describe */
 int phast_planner_r2c64_describe(const phast_planner_r2c64 *p, char *buf, size_t buf_len);
 int phast_planner_r2c32_describe(const phast_planner_r2c32 *p, char *buf, size_t buf_len);

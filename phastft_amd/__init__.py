@@ -271,6 +271,15 @@ class _PlannerR2c:
         _check(getattr(_lib.lib(), f"phast_planner_r2c{self._sfx}_describe")(self._h, buf, C.c_size_t(1024)))
         return buf.value.decode()
 
+    def set_plan(self, log_rows=(), tile_log=12, points_log=4) -> None:
+        """Force the pass factorisation of the inner N/2-point transform (tuning hook, as ``PlannerDit*.set_plan``);
+        ``()`` restores the library's own plans."""
+        n = len(log_rows)
+        tls = [tile_log] * n if isinstance(tile_log, int) else list(tile_log)
+        arr = (C.c_uint * max(1, n))(*log_rows)
+        tarr = (C.c_uint * max(1, n))(*tls)
+        _check(getattr(_lib.lib(), f"phast_planner_r2c{self._sfx}_set_inner_plan")(self._h, arr, tarr, C.c_size_t(n), C.c_uint(points_log)))
+
     def time_passes(self, input_re, output_re, output_im, reps: int = 10):
         """Average HIP-event duration (ms) of every kernel of one R2C transform of the device tensors: the passes of the
         inner N/2-point transform, then the untangle sweep.  Measurement hook for bench.py."""

@@ -36,7 +36,7 @@ phast_fill_f64_dev phast_fill_f32_dev phast_digest_f64_dev phast_digest_f32_dev 
 phast_planner_dit64_set_plan phast_planner_dit32_set_plan
 phast_planner_dit64_time_passes phast_planner_dit32_time_passes phast_debug_set_wg_per_cu phast_debug_set_trace
 phast_debug_set_guard_bytes phast_planner_dit64_debug_check_guards phast_planner_dit32_debug_check_guards
-phast_planner_r2c64_time_passes phast_planner_r2c32_time_passes phast_planner_r2c64_time_c2r_passes phast_planner_r2c32_time_c2r_passes phast_planner_r2c64_describe phast_planner_r2c32_describe
+phast_planner_r2c64_time_passes phast_planner_r2c32_time_passes phast_planner_r2c64_time_c2r_passes phast_planner_r2c32_time_c2r_passes phast_planner_r2c64_describe phast_planner_r2c32_describe phast_planner_r2c64_set_inner_plan phast_planner_r2c32_set_inner_plan
 phast_twiddle_grid64_new phast_twiddle_grid32_new phast_twiddle_grid64_free phast_twiddle_grid32_free
 phast_twiddle_grid64_apply_dev phast_twiddle_grid32_apply_dev
 """.split()

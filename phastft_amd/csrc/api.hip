@@ -351,6 +351,9 @@ template <typename T> struct Planner {
     std::vector<PassDesc> passes_lat;  // latency plan (one small transform); may equal `passes`
     std::vector<PassDesc> passes_mid;  // a few transforms in flight, where that wants a plan of its own (plan.hpp)
     std::vector<PassDesc> passes_one;  // ONE (or two) transforms: wave / quad tiles etc. (plan.hpp: single_plan)
+    // C2R only (PlannerR2c::init): passes_one / passes_lat with the pass ORDER reversed, where that gives the first pass --
+    // which reads the caller's planar half-spectrum -- the wide rows the C2C order gives the last (see make_c2r_plans)
+    std::vector<PassDesc> passes_c2r_one, passes_c2r_lat;
     void *d_small_tw = nullptr;
     // elements per transform and plane in the scratch: n plus the padding of the intermediate layouts (plan.hpp:
     // scratch_pad_bytes); the largest over this planner's plans, fixed before the first allocation grows past it
@@ -572,6 +575,8 @@ template <typename T> struct Planner {
         free_passes(passes_lat);
         free_passes(passes_mid);
         free_passes(passes_one);
+        free_passes(passes_c2r_one);
+        free_passes(passes_c2r_lat);
         for (void *t : old_tables) hipFree(t);
         old_tables.clear();
         old_table_bytes = 0;
@@ -611,7 +616,10 @@ template <typename T> struct Planner {
     }
     // C2R, the same on the other side: a plan whose FIRST pass is a wave tile has no fused form of it (c2r_fused.hpp)
     const std::vector<PassDesc> &plan_for_c2r(size_t batch) const {
-        const std::vector<PassDesc> &ps = plan_for(batch);
+        const std::vector<PassDesc> &ps0 = plan_for(batch);
+        const std::vector<PassDesc> &ps = (&ps0 == &passes_one && !passes_c2r_one.empty())   ? passes_c2r_one
+                                          : (&ps0 == &passes_lat && !passes_c2r_lat.empty()) ? passes_c2r_lat
+                                                                                             : ps0;
         if (!ps.empty() && ps.front().c2r_blocks == 0 && !passes_lat.empty() && passes_lat.front().c2r_blocks > 0 && c2r_lat_ok())
             return passes_lat;
         return ps;
@@ -652,13 +660,22 @@ template <typename T> struct Planner {
         std::unique_lock<std::shared_mutex> plans(plan_mu);
         if (which == 2) {
             retire_passes(passes_lat);
+            retire_passes(passes_c2r_lat);  // derived from the plan that goes
             passes_lat = std::move(ps);
         } else if (which == 3) {
             retire_passes(passes_mid);
             passes_mid = std::move(ps);
         } else if (which == 4) {
             retire_passes(passes_one);
+            retire_passes(passes_c2r_one);
             passes_one = std::move(ps);
+        } else if (which == 5 || which == 6) {  // the C2R orders: additional plans, table_bytes and scratch pitch below
+            std::vector<PassDesc> &dst = which == 5 ? passes_c2r_one : passes_c2r_lat;
+            retire_passes(dst);
+            dst = std::move(ps);
+            table_bytes += tb;
+            if (need > sstride()) scratch_stride = need;
+            return PHAST_OK;
         } else {
             retire_passes(passes);
             passes = std::move(ps);
@@ -666,6 +683,8 @@ template <typename T> struct Planner {
                 retire_passes(passes_lat);
                 retire_passes(passes_mid);
                 retire_passes(passes_one);
+                retire_passes(passes_c2r_one);
+                retire_passes(passes_c2r_lat);
             }
         }
         table_bytes = tb;
@@ -713,6 +732,39 @@ template <typename T> struct Planner {
         if (single_plan<T>(log_n, lrs, tls, lp)) {
             rc = set_plan(lrs, tls, 4, lp);
             if (rc != PHAST_OK && rc != PHAST_ERR_INVALID_ARG) return rc;
+        }
+        return PHAST_OK;
+    }
+
+    // C2R reads the caller's PLANAR half-spectrum in its first pass and writes (im, re) PAIRS in its last -- the mirror image
+    // of what the C2C plans were cut for (and of R2C: pairs in, planes out).  Where a plan gives its first pass rows of less
+    // than a 128-byte line of planar elements and its last pass wider ones (f32: [256x16A][256x16][128x32] -- 64-byte rows
+    // exactly where C2R has FOUR streams of them per tile: re / im of the element and of its mirror partner), the same passes
+    // in reverse order serve C2R better: [128x32A][256x16][256x16].  PHAST_C2R_REV=0: tools (A/B).
+    int make_c2r_plans() {
+        static const bool on = [] {
+            const char *e = std::getenv("PHAST_C2R_REV");
+            return !(e && *e == '0');
+        }();
+        if (!on) return PHAST_OK;
+        for (int k = 0; k < 2; ++k) {
+            const std::vector<PassDesc> &src = k == 0 ? passes_one : passes_lat;
+            // (three-pass plans: measured and NOT reversed -- f32 2^24 first pass 38 -> 35 us but the middle pass, now behind
+            // a 128-row first pass, 25 -> 31: profiles/r04_c2r_rev_ab.log; two-pass plans: 2^20 20.2 -> 17.9 us)
+            if (src.size() != 2 || src.front().wave || src.front().quad || src.back().wave || src.back().quad) continue;
+            if ((sizeof(T) << src.front().lc) >= 128 || src.back().lc <= src.front().lc) continue;
+            std::vector<unsigned> lrs, tls;
+            for (size_t i = src.size(); i-- > 0;) {
+                lrs.push_back(src[i].lr);
+                tls.push_back(src[i].lr + src[i].lc);
+            }
+            int rc = set_plan(lrs, tls, 5 + k, src.front().lp);
+            if (rc != PHAST_OK && rc != PHAST_ERR_INVALID_ARG) return rc;
+            std::vector<PassDesc> &dst = k == 0 ? passes_c2r_one : passes_c2r_lat;
+            if (rc == PHAST_OK && (dst.empty() || dst.front().c2r_blocks <= 0)) {  // no fused first pass: not worth having
+                std::unique_lock<std::shared_mutex> plans(plan_mu);
+                retire_passes(dst);
+            }
         }
         return PHAST_OK;
     }
@@ -968,6 +1020,8 @@ template <typename T> struct Planner {
         if (!passes_mid.empty()) add("mid", passes_mid);
         if (!passes_lat.empty()) add("latency", passes_lat);
         if (!passes_one.empty()) add("single", passes_one);
+        if (!passes_c2r_one.empty()) add("c2r-single", passes_c2r_one);
+        if (!passes_c2r_lat.empty()) add("c2r-latency", passes_c2r_lat);
         return s;
     }
 
@@ -1139,6 +1193,7 @@ template <typename T> struct Planner {
                     fa.tiles_per_xform = (1u << (p.log_s_in - p.lc - 1)) + 1u;
                     if ((unsigned long long)nb * fa.tiles_per_xform > 0xffffffffull) return PHAST_ERR_INVALID_ARG;
                     fa.tiles_total = (unsigned)(nb * fa.tiles_per_xform);
+                    fa.pair_tiles = (unsigned)(nb * (fa.tiles_per_xform - 1u));
                     unsigned grid = (unsigned)p.r2c_blocks * (unsigned)cus_of(device);
                     if (grid > fa.tiles_total) grid = fa.tiles_total;
                     if (grid >= 8) grid &= ~7u;
@@ -1172,6 +1227,10 @@ template <typename T> struct PlannerR2c {
         n = n_;
         int rc = dit.init(n / 2);
         if (rc) return rc;
+        if (!dit.passes.empty()) {
+            rc = dit.make_c2r_plans();
+            if (rc) return rc;
+        }
         tw_bits = tw3_bits_for(ilog2(n));
         return upload<T>(host_tw3<T>(ilog2(n), tw_bits), &d_tw3);
     }
@@ -2046,6 +2105,13 @@ int phast_options_guess(size_t input_size, phast_options *out) {
                                                  float *pass_ms, int *n_passes, void *stream) {                     \
         return time_passes_c2r<T>(p, d_ire, d_iim, d_out, batch, in_dist, out_dist, reps, pass_ms, n_passes,        \
                                   static_cast<hipStream_t>(stream));                                               \
+    }                                                                                                              \
+    int phast_planner_r2c##SFX##_set_inner_plan(phast_planner_r2c##SFX *p, const unsigned *lr, const unsigned *tl,  \
+                                                size_t np, unsigned points_log) {                                  \
+        if (!p) return PHAST_ERR_INVALID_ARG;                                                                      \
+        int rc = set_plan_c<T>(&p->dit, lr, tl, np, points_log);                                                   \
+        if (rc == PHAST_OK && np == 0 && !p->dit.passes.empty()) rc = p->dit.make_c2r_plans();                     \
+        return rc;                                                                                                 \
     }                                                                                                              \
     int phast_planner_r2c##SFX##_describe(const phast_planner_r2c##SFX *p, char *buf, size_t len) {                \
         return p ? describe_to<T>(&p->dit, buf, len) : PHAST_ERR_INVALID_ARG;                                      \

@@ -43,7 +43,8 @@ struct R2cFuseArgs {
     const void *twu;    // [R] complex: W_{2R}^kc
     unsigned twn_bits;
     unsigned tiles_per_xform;  // M / (2 COLS) + 1
-    unsigned tiles_total;
+    unsigned tiles_total;      // batch * tiles_per_xform
+    unsigned pair_tiles;       // batch * (tiles_per_xform - 1): the tiles with g0 < M/2 (locate)
 };
 
 template <typename T, int LR, int LC, int LP, bool SEQ> struct R2cLastBody {
@@ -52,15 +53,26 @@ template <typename T, int LR, int LC, int LP, bool SEQ> struct R2cLastBody {
     using cx = cx_t<T>;
     static constexpr int P = Body::P, M = Body::M, COLS = Body::COLS, ROWS = Body::ROWS;
 
-    // tile t of the fused pass -> (transform, first column, is it the self-mirrored block at M/2)
+    // position t of the launch -> (transform, first column, is it the self-mirrored block at M/2).
+    // The pair tiles (g0 < M/2: M / (2 COLS) per transform, a power of two) come first, in the XCD-aware order of
+    // TileBody::locate: workgroup b runs on XCD b % 8 and XCD x gets the contiguous run [x pair_tiles / 8, ...) of them, so
+    // that a tile and its neighbours -- which share the split lines of the mirrored side, 124 + 4 bytes -- are in flight in
+    // ONE L2 at the same time (the 4-byte piece of a line is then an L2 hit on the way in and merges with the 124-byte
+    // piece on the way out).  The self-mirrored blocks (one per transform) follow: they share nothing.  Round 3 applied the
+    // XCD order to all tiles_total = batch (M / (2 COLS) + 1) tiles -- an ODD number for one transform, for which the order
+    // falls back to t itself: neighbouring tiles on DIFFERENT XCDs, every split line fetched twice and written as two
+    // partial lines (PMC: 1.32 x the algorithmic traffic at f32 2^24, profiles/r03_pmc_hbm_traffic_r2c_f32_2p24.txt).
     PHAST_HD static bool locate(const TileArgs &a, const R2cFuseArgs &f, unsigned t, Regs &r) {
-        // XCD-aware order as TileBody::locate: workgroup b runs on XCD b % 8 and gets one contiguous run of tiles, so that a
-        // tile and its neighbours (which share the split lines of the mirrored side) meet in one L2
-        const unsigned tile = ((f.tiles_total & 7u) == 0u) ? (t & 7u) * (f.tiles_total >> 3) + (t >> 3) : t;
-        r.xform = tile / f.tiles_per_xform;
-        const unsigned ti = tile - r.xform * f.tiles_per_xform;
-        r.g0 = ti << LC;
-        return ti + 1u == f.tiles_per_xform;  // g0 == M/2
+        const unsigned pairs_per = f.tiles_per_xform - 1u;
+        if (t >= f.pair_tiles) {
+            r.xform = t - f.pair_tiles;
+            r.g0 = pairs_per << LC;  // M/2
+            return true;
+        }
+        const unsigned tile = ((f.pair_tiles & 7u) == 0u) ? (t & 7u) * (f.pair_tiles >> 3) + (t >> 3) : t;
+        r.xform = tile >> (unsigned)__builtin_ctz(pairs_per);
+        r.g0 = (tile & (pairs_per - 1u)) << LC;
+        return false;
     }
 
     // the conjugate of the mirrored columns: lane (col, tau) reads column M - (g0 + col) (column 0 for g = 0) of the rows

@@ -144,6 +144,7 @@ static int emu_r2c_fused(const T *in, unsigned log_n, T *ore, T *oim, const unsi
         fa.twu = twu.data();
         fa.tiles_per_xform = (1u << (p.log_s_in - p.lc - 1)) + 1u;
         fa.tiles_total = fa.tiles_per_xform;
+        fa.pair_tiles = fa.tiles_per_xform - 1u;
         if (!emu_r2c_last<T>(p, ta, fa)) return 3;
     }
     return 0;
