@@ -167,6 +167,12 @@ def plan_kind(P, n: int, batch: int, plan_text: str, dtype: str = "f64") -> str:
     return "mid" if (batch > 1 and "mid=" in plan_text) else "latency"
 
 
+def real_plan_list(plan_text: str, tag: str, fallback_kind: str) -> str:
+    """the pass list a single R2C / C2R call runs: the real transform's own plan where the planner has one
+    (`r2c-single=` / `c2r-single=` in describe(): plan.hpp real_plan), else the C2C plan of that kind"""
+    return plan_of(plan_text, tag if (tag + "=") in plan_text else fallback_kind)
+
+
 def kernel_tags(plan_list: str, dtype: str = "double"):
     """Substrings of the pass kernels' names of a plan, in launch order -- used to check that a committed PMC profile
     belongs to the plan that ran: 'tile_fft_kernel<double, LR, LC, LP, PRE_TW, TRANSPOSE,' for LDS tiles,
@@ -413,7 +419,8 @@ def config_r2c(P, torch, dev, steps: int, cpu: bool):
     pass_ms = [a / ring for a in acc]
     r2c_bytes = 4 * n + 8 * (n // 2 + 1)
     plan_text = pl.describe()
-    n_inner = len(kernel_tags(plan_of(plan_text, plan_kind(P, n // 2, 1, plan_text, "f32")), "float"))
+    r2c_list = real_plan_list(plan_text, "r2c-single", plan_kind(P, n // 2, 1, plan_text, "f32"))
+    n_inner = len(kernel_tags(r2c_list, "float"))
     fused = len(pass_ms) == n_inner  # round 3: the last pass takes the untangle with it (r2c_fused.hpp): no sweep of its own
     names = [f"tile_fft pass {i} of the inner 2^23-point transform" for i in range(n_inner)]
     if fused:
@@ -432,7 +439,7 @@ def config_r2c(P, torch, dev, steps: int, cpu: bool):
     out = {"workload": "r2c_fft_f32 N=2^24, real input -> N/2+1 planar outputs (BASELINE configs[3])",
            "value": n / (ms * 1e-3) / 1e9, "unit": "GSamples/s (real samples)", "steps": steps, "ms_per_step": ms,
            "dtype": "f32", "plan": plan_text, "roofline": roof}
-    tags = kernel_tags(plan_of(plan_text, plan_kind(P, n // 2, 1, plan_text, "f32")), "float")
+    tags = kernel_tags(r2c_list, "float")
     if fused:
         tags[-1] = tags[-1].replace("tile_fft_kernel", "r2c_last_pass_kernel").split(", true, false")[0]
     tr = traffic_for("r2c_f32_2p24", ["untangle_kernel"] if (not fused and dom == len(pass_ms) - 1) else [tags[dom]]) if dom < len(tags) + 1 else None

@@ -354,6 +354,9 @@ template <typename T> struct Planner {
     // C2R only (PlannerR2c::init): passes_one / passes_lat with the pass ORDER reversed, where that gives the first pass --
     // which reads the caller's planar half-spectrum -- the wide rows the C2C order gives the last (see make_c2r_plans)
     std::vector<PassDesc> passes_c2r_one, passes_c2r_lat;
+    // R2C only: the plan of ONE (or two) real transforms where plan.hpp (real_plan) has a better one than the C2C choice;
+    // passes_c2r_one is C2R's (from the same table, else the reversal above)
+    std::vector<PassDesc> passes_r2c;
     void *d_small_tw = nullptr;
     // elements per transform and plane in the scratch: n plus the padding of the intermediate layouts (plan.hpp:
     // scratch_pad_bytes); the largest over this planner's plans, fixed before the first allocation grows past it
@@ -577,6 +580,7 @@ template <typename T> struct Planner {
         free_passes(passes_one);
         free_passes(passes_c2r_one);
         free_passes(passes_c2r_lat);
+        free_passes(passes_r2c);
         for (void *t : old_tables) hipFree(t);
         old_tables.clear();
         old_table_bytes = 0;
@@ -608,16 +612,18 @@ template <typename T> struct Planner {
     // (wave / quad tiles of the single-transform plans) but the latency plan's generic tiles do, the latency plan runs --
     // its passes are a few per cent slower, the sweep it saves is a quarter of the transform (R2C of 2^24..2^26 f64 points:
     // +11..15 %; beyond 2^25 inner points the latency plan's passes lose more than the sweep gives: measured, tools/r2c_f64_probe.py)
-    const std::vector<PassDesc> &plan_for_r2c(size_t batch) const {
+    const std::vector<PassDesc> &plan_for_r2c(size_t batch, bool fusing = true) const {
+        if (batch <= 2 && !passes_r2c.empty()) return passes_r2c;  // ranked for R2C itself (plan.hpp: real_plan)
         const std::vector<PassDesc> &ps = plan_for(batch);
-        if (!ps.empty() && ps.back().r2c_blocks == 0 && log_n <= 25 && !passes_lat.empty() && passes_lat.back().r2c_blocks > 0 && r2c_lat_ok())
+        if (fusing && !ps.empty() && ps.back().r2c_blocks == 0 && log_n <= 25 && !passes_lat.empty() && passes_lat.back().r2c_blocks > 0 &&
+            r2c_lat_ok())
             return passes_lat;
         return ps;
     }
     // C2R, the same on the other side: a plan whose FIRST pass is a wave tile has no fused form of it (c2r_fused.hpp)
     const std::vector<PassDesc> &plan_for_c2r(size_t batch) const {
         const std::vector<PassDesc> &ps0 = plan_for(batch);
-        const std::vector<PassDesc> &ps = (&ps0 == &passes_one && !passes_c2r_one.empty())   ? passes_c2r_one
+        const std::vector<PassDesc> &ps = (batch <= 2 && !passes_c2r_one.empty())                 ? passes_c2r_one
                                           : (&ps0 == &passes_lat && !passes_c2r_lat.empty()) ? passes_c2r_lat
                                                                                              : ps0;
         if (!ps.empty() && ps.front().c2r_blocks == 0 && !passes_lat.empty() && passes_lat.front().c2r_blocks > 0 && c2r_lat_ok())
@@ -669,8 +675,8 @@ template <typename T> struct Planner {
             retire_passes(passes_one);
             retire_passes(passes_c2r_one);
             passes_one = std::move(ps);
-        } else if (which == 5 || which == 6) {  // the C2R orders: additional plans, table_bytes and scratch pitch below
-            std::vector<PassDesc> &dst = which == 5 ? passes_c2r_one : passes_c2r_lat;
+        } else if (which >= 5 && which <= 7) {  // the real transforms' own plans: additional, table_bytes and pitch below
+            std::vector<PassDesc> &dst = which == 5 ? passes_c2r_one : which == 6 ? passes_c2r_lat : passes_r2c;
             retire_passes(dst);
             dst = std::move(ps);
             table_bytes += tb;
@@ -685,6 +691,7 @@ template <typename T> struct Planner {
                 retire_passes(passes_one);
                 retire_passes(passes_c2r_one);
                 retire_passes(passes_c2r_lat);
+                retire_passes(passes_r2c);
             }
         }
         table_bytes = tb;
@@ -742,12 +749,25 @@ template <typename T> struct Planner {
     // exactly where C2R has FOUR streams of them per tile: re / im of the element and of its mirror partner), the same passes
     // in reverse order serve C2R better: [128x32A][256x16][256x16].  PHAST_C2R_REV=0: tools (A/B).
     int make_c2r_plans() {
-        static const bool on = [] {
+        static const bool rev = [] {
             const char *e = std::getenv("PHAST_C2R_REV");
             return !(e && *e == '0');
         }();
-        if (!on) return PHAST_OK;
-        for (int k = 0; k < 2; ++k) {
+        static const bool table = [] {  // PHAST_REAL_PLANS=0: R2C / C2R keep the C2C plans (tools: A/B, tools/sweep_real.py)
+            const char *e = std::getenv("PHAST_REAL_PLANS");
+            return !(e && *e == '0');
+        }();
+        // 1. the ranked plans of ONE real transform (plan.hpp: real_plan)
+        for (int c2r = 0; c2r < 2 && table; ++c2r) {
+            std::vector<unsigned> lrs, tls;
+            unsigned lp = 4;
+            if (!real_plan<T>(log_n, c2r != 0, lrs, tls, lp)) continue;
+            int rc = set_plan(lrs, tls, c2r ? 5 : 7, lp);
+            if (rc != PHAST_OK && rc != PHAST_ERR_INVALID_ARG) return rc;
+        }
+        // 2. C2R, two-pass plans: the reversed order
+        for (int k = 0; k < 2 && rev; ++k) {
+            if (k == 0 && !passes_c2r_one.empty()) continue;
             const std::vector<PassDesc> &src = k == 0 ? passes_one : passes_lat;
             // (three-pass plans: measured and NOT reversed -- f32 2^24 first pass 38 -> 35 us but the middle pass, now behind
             // a 128-row first pass, 25 -> 31: profiles/r04_c2r_rev_ab.log; two-pass plans: 2^20 20.2 -> 17.9 us)
@@ -1022,6 +1042,7 @@ template <typename T> struct Planner {
         if (!passes_one.empty()) add("single", passes_one);
         if (!passes_c2r_one.empty()) add("c2r-single", passes_c2r_one);
         if (!passes_c2r_lat.empty()) add("c2r-latency", passes_c2r_lat);
+        if (!passes_r2c.empty()) add("r2c-single", passes_r2c);
         return s;
     }
 
@@ -1131,7 +1152,7 @@ template <typename T> struct Planner {
         // R2C: fused or not is decided ONCE per call, from the size of a full chunk -- a smaller tail chunk follows the others
         // (the caller runs the untangle sweep over the whole batch or not at all)
         const bool r2c_fuse = fuse && in_mode != 3 && fuse_pays(batch < cap ? batch : cap);
-        const std::vector<PassDesc> &passes = in_mode == 3 ? plan_for_c2r(batch) : r2c_fuse ? plan_for_r2c(batch) : plan_for(batch);
+        const std::vector<PassDesc> &passes = in_mode == 3 ? plan_for_c2r(batch) : fuse ? plan_for_r2c(batch, r2c_fuse) : plan_for(batch);
         const size_t np = passes.size();
         if (np_out) *np_out = np;
         for (size_t b0 = 0; b0 < batch; b0 += cap) {

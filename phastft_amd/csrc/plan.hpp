@@ -248,6 +248,37 @@ inline bool single_plan(unsigned L, std::vector<unsigned> &lrs, std::vector<unsi
     return false;
 }
 
+// The inner N/2-point transform of ONE (or two) REAL transforms (`L` = log2 of the inner length).  The C2C plans above were
+// ranked on planar input and output; R2C reads (re, im) PAIRS in its first pass and ends in the fused untangle pass (twice
+// the work per tile, mirrored columns: r2c_fused.hpp), C2R starts with the fused preprocess pass (four streams per tile:
+// c2r_fused.hpp) and ends writing pairs -- the best factorisations differ.  Ranked on the GPU over every 2- / 3-pass
+// factorisation x tile size x points per thread (tools/sweep_real.py, profiles/r04_sweep_real_*.log), adopted where they
+// beat the C2C choice by more than the run-to-run noise (3 %):
+//   R2C  f32 2^25: 198 -> 177 us, 2^26: 429 -> 395;  f64 2^23: 122 -> 106, 2^24: 208 -> 174, 2^25: 401 -> 357, 2^26: 763 -> 695
+//   C2R  f32 2^23: 50.9 -> 48.1, 2^25: 201 -> 184, 2^26: 444 -> 389;  f64 2^23: 98 -> 82, 2^24: 188 -> 172, 2^25: 450 -> 356,
+//        2^26: 822 -> 724
+// (real lengths; everything else keeps the C2C plan).  Returns false where there is no entry.
+template <typename T>
+inline bool real_plan(unsigned L, bool c2r, std::vector<unsigned> &lrs, std::vector<unsigned> &tls, unsigned &lp) {
+    struct E {
+        unsigned L, a, b, c, ta, tb, tc, lp;
+    };
+    static const E r2c32[] = {{24, 8, 9, 7, 12, 13, 12, 4}, {25, 8, 9, 8, 13, 13, 13, 4}};
+    static const E r2c64[] = {{22, 8, 7, 7, 13, 13, 13, 4}, {23, 9, 8, 6, 12, 12, 12, 3}, {24, 9, 9, 6, 12, 13, 12, 4}, {25, 9, 9, 7, 12, 13, 12, 4}};
+    static const E c2r32[] = {{22, 8, 7, 7, 13, 12, 12, 4}, {24, 8, 8, 8, 13, 13, 13, 4}, {25, 8, 9, 8, 13, 13, 13, 4}};
+    static const E c2r64[] = {{22, 8, 7, 7, 12, 13, 13, 4}, {23, 8, 8, 7, 12, 12, 13, 4}, {24, 8, 8, 8, 12, 12, 12, 4}, {25, 8, 9, 8, 13, 13, 13, 4}};
+    const E *tab = sizeof(T) == 4 ? (c2r ? c2r32 : r2c32) : (c2r ? c2r64 : r2c64);
+    const size_t cnt = sizeof(T) == 4 ? (c2r ? sizeof c2r32 : sizeof r2c32) / sizeof(E) : (c2r ? sizeof c2r64 : sizeof r2c64) / sizeof(E);
+    for (size_t i = 0; i < cnt; ++i)
+        if (tab[i].L == L) {
+            lrs = {tab[i].a, tab[i].b, tab[i].c};
+            tls = {tab[i].ta, tab[i].tb, tab[i].tc};
+            lp = tab[i].lp;
+            return true;
+        }
+    return false;
+}
+
 // A third plan for "a few transforms in flight" where neither of the two above fits: N = 2^20, whose latency plan
 // takes three passes (best for ONE transform) while 2..15 transforms are better served by two passes of
 // 8192-point tiles (64 / 68 / 75 GSamples/s at 2 / 4 / 8 transforms against 47 / 44 / 49,
