@@ -23,7 +23,11 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libphastft_hip.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
-UNITS = ["api", "tile_f64_a", "tile_f64_bc", "tile_f64_bc_wide", "tile_f32_a", "tile_f32_bc", "tile_f32_bc_wide", "tile_f64_r2c", "tile_f32_r2c", "tile_f64_c2r", "tile_f32_c2r", "wave_f64", "wave_f32", "quad_f64", "small_fft", "bitrev", "r2c", "fill", "probe", "twiddle"]
+UNITS = ["api", "tile_f64_a", "tile_f64_bc", "tile_f64_bc_wide", "tile_f32_a", "tile_f32_bc", "tile_f32_bc_wide", "tile_f64_r2c", "tile_f32_r2c", "tile_f64_c2r", "tile_f32_c2r", "wave_f64", "quad_f64", "small_fft", "bitrev", "r2c", "fill", "probe", "twiddle"]
+# built only with --experimental (lib/libphastft_hip_exp.so): the f32 wave tiles -- parity-tested, slower than the generic tiles
+# for every plan measured (profiles/r03_sweep_wave_f32.log), so not part of the product library
+EXPERIMENTAL_UNITS = ["wave_f32"]
+EXPERIMENTAL_FLAGS = ("-DPHAST_EXPERIMENTAL_WAVE_F32",)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-ffp-contract=fast", "-Rpass-analysis=kernel-resource-usage"]
 # per-unit compiler options (the scheduling strategy is a translation-unit option: tile_dispatch.hpp says why)
@@ -84,15 +88,20 @@ def _resource_usage(remarks: str) -> dict:
 
 
 def build(force: bool = False, jobs: int | None = None, verbose: bool = False, trace: bool = False,
-          extra: tuple = (), tag: str = "") -> str:
+          extra: tuple = (), tag: str = "", experimental: bool = False) -> str:
     """trace=True builds lib/libphastft_hip_trace.so with per-phase s_memtime stamps (tools/trace_tile.py;
     load it with PHASTFT_HIP_LIB=...); the product library never carries them."""
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIB_DIR, exist_ok=True)
-    jobs = jobs or min(len(UNITS), os.cpu_count() or 4)
+    units = list(UNITS)
+    if experimental:
+        units += EXPERIMENTAL_UNITS
+        extra = tuple(extra) + EXPERIMENTAL_FLAGS
+        tag = tag + "_exp"
+    jobs = jobs or min(len(units), os.cpu_count() or 4)
     lib = LIB.replace(".so", ("_trace" if trace else "") + tag + ".so")  # tag/extra: experimental variants (tools/)
     with cf.ThreadPoolExecutor(jobs) as ex:
-        objs = list(ex.map(lambda u: _compile(u, force, trace, extra, tag), UNITS))
+        objs = list(ex.map(lambda u: _compile(u, force, trace, extra, tag), units))
     if force or _stale(lib, objs):
         cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs]
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -115,6 +124,7 @@ if __name__ == "__main__":
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--jobs", type=int, default=None)
     ap.add_argument("--trace", action="store_true")
+    ap.add_argument("--experimental", action="store_true", help="lib/libphastft_hip_exp.so: + the f32 wave tiles")
     a = ap.parse_args()
-    build(a.force, a.jobs, verbose=True, trace=a.trace)
+    build(a.force, a.jobs, verbose=True, trace=a.trace, experimental=a.experimental)
     sys.exit(0)

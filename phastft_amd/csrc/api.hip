@@ -175,7 +175,11 @@ template <> struct Types<double> {
 template <typename T> static hipError_t launch_wave(bool transpose, hipStream_t s, const TileArgs &a, bool q, int *b, size_t *l,
                                                     hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
     if constexpr (sizeof(T) == 8) return launch_wave_f64(transpose, s, a, q, b, l, e0, e1);
+#ifdef PHAST_EXPERIMENTAL_WAVE_F32
     else return launch_wave_f32(transpose, s, a, q, b, l, e0, e1);
+#else
+    else return hipErrorInvalidValue;  // the f32 wave tiles are not in the product library (build.py --experimental)
+#endif
 }
 template <typename T> static hipError_t launch_quad(unsigned grid, hipStream_t s, const TileArgs &a, bool q, int *b, size_t *l,
                                                     hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
@@ -651,6 +655,11 @@ template <typename T> struct Planner {
     int set_plan(const std::vector<unsigned> &lrs, const std::vector<unsigned> &tls, int which = 0, unsigned lp = 4) {
         std::vector<PassGeom> geo;
         if (!make_passes(log_n, lrs, tls, geo, lp, sizeof(T))) return PHAST_ERR_INVALID_ARG;
+#ifndef PHAST_EXPERIMENTAL_WAVE_F32
+        if (sizeof(T) == 4)  // f32 wave tiles: measured, slower than the generic tiles everywhere, built with --experimental only
+            for (const PassGeom &g : geo)
+                if (g.wave) return PHAST_ERR_INVALID_ARG;
+#endif
         PHAST_ON_DEVICE(device);
         std::vector<PassDesc> ps(geo.size());
         for (size_t i = 0; i < geo.size(); ++i) static_cast<PassGeom &>(ps[i]) = geo[i];

@@ -370,51 +370,28 @@ static hipError_t launch_bitrev_u(U *data, unsigned log_n, size_t batch, size_t 
     return hipGetLastError();
 }
 
-static int bitrev_variant() {  // tuning hook (tools/sweep_bitrev.py): PHAST_BITREV_VARIANT=0 (default) | 1..4
-    const char *e = getenv("PHAST_BITREV_VARIANT");
-    return e ? atoi(e) : 0;
-}
-
-// Defaults (first generation) from profiles/r01_sweep_bitrev.log: the persistent kernel with 64 x 64 tiles (512-byte rows for f64,
-// 256-byte for f32), 512 threads, 4 workgroups per CU -- 3.4-3.7 TB/s at 2^26..2^30 f64, 3.4-4.6 f32.  Variant 1
-// is the one-pair-per-workgroup kernel (32 x 32 tiles for f64) the persistent one replaced.
+// Which generation runs where (profiles/r01_sweep_bitrev.log, r02_sweep_bitrev.log; the other generations of those sweeps --
+// 32 x 32 pairs per workgroup at every size, 1024-thread forms, the plain tile order of the 16-byte generation, a 128 x 128 u32
+// form that needed scratch memory -- lost everywhere and were removed in round 4 together with the PHAST_BITREV_VARIANT hook that selected them):
+//   N < 2^12             one pair of tiles per workgroup
+//   default              persistent workgroups, 64 x 64 tiles (512-byte rows for f64, 256-byte for f32), 512 threads, 4 per CU:
+//                        3.4-3.7 TB/s at 2^26..2^30 f64, 3.4-4.6 f32 -- for 4-byte elements it stays ahead at every size
+//   f64, >= 2^25 points  past the 256 MiB Infinity Cache the 16-byte-per-lane, non-temporal generation is 4-10 % faster
+//                        (2^26: 3.9 vs 3.6 TB/s)
+//   f64, N >= 2^27       128 x 128 tiles held in registers (1 KiB rows): 2^27 3.4 -> 4.1 TB/s, 2^28 3.9 -> 4.0, 2^30 3.8 -> 4.0;
+//                        below that there are too few tiles per CU for its one workgroup per CU (2^26: 3.7 vs 3.9)
 template <> hipError_t launch_bitrev<double>(double *data, unsigned log_n, size_t batch, size_t dist, hipStream_t s) {
     auto *p = reinterpret_cast<unsigned long long *>(data);
-    const int v = bitrev_variant();
-    if (v == 1 || log_n < 12) return launch_bitrev_u<unsigned long long, 5, 256>(p, log_n, batch, dist, s);
-    if (v == 2) return launch_bitrev_persistent<unsigned long long, 5, 256>(p, log_n, batch, dist, s, 8);
-    if (v == 3) return launch_bitrev_persistent<unsigned long long, 6, 512>(p, log_n, batch, dist, s, 2);
-    if (v == 4) return launch_bitrev_persistent<unsigned long long, 6, 1024>(p, log_n, batch, dist, s, 2);
+    if (log_n < 12) return launch_bitrev_u<unsigned long long, 5, 256>(p, log_n, batch, dist, s);
     const bool even = (dist & 1) == 0 && (reinterpret_cast<size_t>(data) & 15) == 0;  // 16-byte accesses need it
-    if (v == 5 && even) return launch_bitrev_persistent2<unsigned long long, 6, 512, false>(p, log_n, batch, dist, s, 4);
-    if (v == 6 && even) return launch_bitrev_persistent2<unsigned long long, 6, 512, true>(p, log_n, batch, dist, s, 4);
-    if (v == 7 && even) return launch_bitrev_persistent2<unsigned long long, 6, 256, true>(p, log_n, batch, dist, s, 4);
-    if (v == 8 && even) return launch_bitrev_persistent2<unsigned long long, 6, 512, true>(p, log_n, batch, dist, s, 2);
-    if (v == 9 && even && log_n >= 14) return launch_bitrev_persistent3<unsigned long long, 7, 1024>(p, log_n, batch, dist, s);
-    if (v == 10 && even && log_n >= 14) return launch_bitrev_persistent3<unsigned long long, 7, 512>(p, log_n, batch, dist, s);
-    // round 2 (profiles/r02_sweep_bitrev.log): once the array is past the 256 MiB Infinity Cache the 16-byte-per-lane,
-    // non-temporal generation is 4-10 % faster (2^26: 3.9 vs 3.6 TB/s with 256 threads, 2^30: 3.8 vs 3.4 with 512);
-    // the spread tile order buys nothing (so HBM channel camping is not what holds this kernel at ~0.75 of the copy
-    // rate), and for 4-byte elements the first generation stays ahead at every size
-    // 2^27 points and up: 128 x 128 tiles held in registers (1 KiB rows): 2^27 3.4 -> 4.1 TB/s, 2^28 3.9 -> 4.0, 2^30 3.8 -> 4.0
-    // (profiles/r02_sweep_bitrev.log); below that there are too few tiles per CU for its one workgroup per CU (2^26: 3.7 vs 3.9)
-    if (v == 0 && even && log_n >= 27) return launch_bitrev_persistent3<unsigned long long, 7, 1024>(p, log_n, batch, dist, s);
-    if (v == 0 && even && (((size_t)batch << log_n) >= ((size_t)1 << 25)))
+    if (even && log_n >= 27) return launch_bitrev_persistent3<unsigned long long, 7, 1024>(p, log_n, batch, dist, s);
+    if (even && (((size_t)batch << log_n) >= ((size_t)1 << 25)))
         return launch_bitrev_persistent2<unsigned long long, 6, 256, true>(p, log_n, batch, dist, s, 4);
     return launch_bitrev_persistent<unsigned long long, 6, 512>(p, log_n, batch, dist, s, 4);
 }
 template <> hipError_t launch_bitrev<float>(float *data, unsigned log_n, size_t batch, size_t dist, hipStream_t s) {
     auto *p = reinterpret_cast<unsigned *>(data);
-    const int v = bitrev_variant();
-    if (v == 1 || log_n < 12) return launch_bitrev_u<unsigned, 6, 512>(p, log_n, batch, dist, s);
-    if (v == 2) return launch_bitrev_persistent<unsigned, 6, 512>(p, log_n, batch, dist, s, 8);
-    if (v == 3) return launch_bitrev_persistent<unsigned, 6, 1024>(p, log_n, batch, dist, s, 2);
-    if (v == 4 && log_n >= 14) return launch_bitrev_persistent<unsigned, 7, 1024>(p, log_n, batch, dist, s, 2);
-    const bool even = (dist & 3) == 0 && (reinterpret_cast<size_t>(data) & 15) == 0;
-    if (v == 5 && even) return launch_bitrev_persistent2<unsigned, 6, 512, false>(p, log_n, batch, dist, s, 4);
-    if (v == 6 && even) return launch_bitrev_persistent2<unsigned, 6, 512, true>(p, log_n, batch, dist, s, 4);
-    if (v == 7 && even) return launch_bitrev_persistent2<unsigned, 6, 256, true>(p, log_n, batch, dist, s, 4);
-    if (v == 8 && even && log_n >= 14) return launch_bitrev_persistent2<unsigned, 7, 1024, true>(p, log_n, batch, dist, s, 2);
+    if (log_n < 12) return launch_bitrev_u<unsigned, 6, 512>(p, log_n, batch, dist, s);
     return launch_bitrev_persistent<unsigned, 6, 512>(p, log_n, batch, dist, s, 4);
 }
 

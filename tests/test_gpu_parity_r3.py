@@ -336,49 +336,19 @@ def test_planner_follows_its_device_not_the_callers(gpu, oracle):
 
 
 # ---------------------------------------------------------------- f32 wave tiles (the f32 twin of wave_fft.hpp)
-def test_f32_wave_tiles_all_passes_batched_inverse_and_interleaved(gpu, oracle):
-    """wave_fft.hpp in f32 (one wave per 64-row x 32-column tile, 32 points per lane, ONE lane bit exchanged by
-    v_permlane32_swap): N = 2^18 as three wave-tile passes, batched with a ragged tile count per workgroup, the inverse,
-    the interleaved first-pass load / last-pass store, and a mixed plan (wave tiles around a generic 256-row pass).
-    Built and parity-tested; NOT in a default plan -- the generic 4096-point tiles are faster for one f32 transform
-    (profiles/r03_sweep_wave_f32.log)."""
-    import torch
-
-    n = 1 << 18
-    planner = gpu.PlannerDit32(n)
-    planner.set_plan((6, 6, 6), 11, 3 | 0x10)
-    assert planner.describe().count(" w32 ") == 3, planner.describe()
-    for batch in (1, 3):
-        re = torch.empty(batch * n, dtype=torch.float32, device="cuda")
-        im = torch.empty_like(re)
-        gpu.fill_uniform(re, im, n, seed=0x77, first_id=9)
-        gpu.fft_dit_batched(re, im, n, gpu.Direction.Forward, planner)
-        for b in range(batch):
-            r, m = oracle.fill(n, np.float32, seed=0x77, transform_id=9 + b)
-            oracle.fft_32_dit(r, m, oracle.FORWARD)
-            assert rel_l2(re[b * n:(b + 1) * n].cpu().numpy(), im[b * n:(b + 1) * n].cpu().numpy(), r, m) <= F32_REL
-        gpu.fft_dit_batched(re, im, n, gpu.Direction.Reverse, planner)
-        ref_re, ref_im = torch.empty_like(re), torch.empty_like(im)
-        gpu.fill_uniform(ref_re, ref_im, n, seed=0x77, first_id=9)
-        assert float((re - ref_re).abs().max()) < 1e-5 and float((im - ref_im).abs().max()) < 1e-5
-    r, m = oracle.fill(n, np.float32, seed=0x78, transform_id=1)
-    z = np.empty(n, np.complex64)
-    z.real, z.imag = r, m
-    d = torch.from_numpy(z.copy()).cuda()
-    gpu.fft_32_interleaved_with_planner(d, gpu.Direction.Forward, planner)
-    oracle.fft_32_dit(r, m, oracle.FORWARD)
-    h = d.cpu().numpy()
-    assert rel_l2(h.real.copy(), h.imag.copy(), r, m) <= F32_REL
-    # mixed: 2^20 = 64 . 256 . 64 with wave tiles outside and the generic 256 x 16 tile in the middle
-    n = 1 << 20
-    planner = gpu.PlannerDit32(n)
-    planner.set_plan((6, 8, 6), (11, 12, 11), 3 | 0x10)
-    assert planner.describe().count(" w32 ") == 2, planner.describe()
-    r, m = oracle.fill(n, np.float32, seed=0x79, transform_id=2)
-    d_re, d_im = dev(r.copy()), dev(m.copy())
-    gpu.fft_32_dit_with_planner(d_re, d_im, gpu.Direction.Forward, planner)
-    oracle.fft_32_dit(r, m, oracle.FORWARD)
-    assert rel_l2(d_re.cpu().numpy(), d_im.cpu().numpy(), r, m) <= F32_REL
+def test_f32_wave_tiles_are_not_in_the_product_library(gpu):
+    """wave_fft.hpp in f32 (one wave per 64-row x 32-column tile, 32 points per lane): built, emulated on the CPU
+    (tests/test_emulator.py::test_f32_wave_tiles_vs_oracle) and parity-tested on the GPU in round 3, slower than the generic
+    4096-point tiles for every plan measured (profiles/r03_sweep_wave_f32.log) -- round 4 took them out of the product
+    library (`python -m phastft_amd.build --experimental` builds lib/libphastft_hip_exp.so with them for tools/): a plan that
+    asks for them is refused, nothing else changes."""
+    planner = gpu.PlannerDit32(1 << 18)
+    before = planner.describe()
+    with pytest.raises(Exception):
+        planner.set_plan((6, 6, 6), 11, 3 | 0x10)
+    assert planner.describe() == before and " w32 " not in before
+    planner.set_plan((6, 6, 6), 12, 3)          # the same factorisation on generic tiles is fine
+    assert planner.describe().count("[64x64") == 3, planner.describe()
 
 
 def test_transform_list_one_call_many_single_transforms(gpu, oracle):

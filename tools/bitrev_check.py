@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""PHAST_BITREV_VARIANT=<v> python tools/bitrev_check.py [L ...]: the stand-alone f64 bit reversal of 2^L points (and of a
+"""python tools/bitrev_check.py [L ...]: the stand-alone f64 bit reversal of 2^L points (and of a
 batch of four) against the permutation computed with integer tensor ops; then its time and rate."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -33,4 +33,4 @@ for L in [int(a) for a in sys.argv[1:]] or [14, 15, 20, 21, 26]:
     for _ in range(10): run()
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 10
-    print(f"variant {os.environ.get('PHAST_BITREV_VARIANT', '0')}: 2^{L}: exact; {ms * 1e3:8.1f} us  {2 * n * 8 / ms / 1e6:6.0f} GB/s", flush=True)
+    print(f"2^{L}: exact; {ms * 1e3:8.1f} us  {2 * n * 8 / ms / 1e6:6.0f} GB/s", flush=True)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Single-transform f32: the library's default plan against forced plans built around the f32 WAVE tiles (64 rows x 32
-columns, wave_fft.hpp; points code | 0x10) -- HIP-graph timing on a cold ring, as tools/sweep_wq.py does for f64."""
+columns, wave_fft.hpp; points code | 0x10; needs the experimental build: python -m phastft_amd.build --experimental, PHASTFT_HIP_LIB=phastft_amd/lib/libphastft_hip_exp.so) -- HIP-graph timing on a cold ring, as tools/sweep_wq.py does for f64."""
 import os
 import sys
 
