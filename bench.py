@@ -64,6 +64,10 @@ def parse():
     ap.add_argument("--plan", default=None, help="experiment: force a plan, e.g. 6,8,6@12p8 (default: the library's own)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for dry runs)")
     ap.add_argument("--same-gpu", action="store_true", help="dry run: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--dist-fft", type=int, default=0, metavar="L",
+                    help="instead of the batch: ONE f64 transform of 2^L points spread over the --gpus ranks (SURVEY.md 8 f-3, "
+                         "phastft_amd/distributed.py), every stage timed with HIP events; --gpus 1 runs it on a one-rank process "
+                         "group (the exchanges are self-copies)")
     ap.add_argument("--sharded", action="store_true",
                     help="run the N > 1 code path (process group, sharded batch, digest gather) even with WORLD_SIZE=1: on "
                          "a one-GPU box this is what puts RCCL init and the device collectives on real hardware")
@@ -592,6 +596,87 @@ def self_launch(args, torch) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def dist_fft_mode(args, P, torch, dev, rank, world):
+    """bench.py --dist-fft L [--gpus N]: ONE f64 transform of 2^L points over the ranks of the process group
+    (phastft_amd/distributed.py: four-step split, three all_to_all_single exchanges per plane over RCCL).  Every stage is
+    timed with HIP events on the rank's stream; the step time is the wall clock between barriers, MAX over ranks.  Prints
+    one JSON line: per-stage milliseconds (rank 0's, averaged over the steps), the bytes every exchange moves per rank and
+    how many of them leave the GPU."""
+    import torch.distributed as dist
+
+    from phastft_amd.distributed import gpu_transform
+    from phastft_amd.sharding import max_over_ranks
+
+    L = args.dist_fft
+    n = 1 << L
+    steps = args.steps if args.steps is not None else 5
+    warmup = args.warmup if args.warmup is not None else 2
+    slab = n // world
+    re = torch.empty(slab, dtype=torch.float64, device=dev)
+    im = torch.empty_like(re)
+    P.fill_uniform(re, im, slab, seed=0xCAFE + rank)
+    t = gpu_transform(n, rank, world, dist, "f64")
+    for _ in range(warmup):
+        t.run(re, im)
+    P.fill_uniform(re, im, slab, seed=0xCAFE + rank)
+    before = float((re.double() ** 2 + im.double() ** 2).sum())
+    marks = []
+
+    def on_stage(name):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        marks.append((name, e))
+
+    t.on_stage = on_stage
+    stage_ms = {}
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        start = torch.cuda.Event(enable_timing=True)
+        start.record()
+        marks.clear()
+        t.run(re, im, reverse=bool(i & 1))   # forward / inverse alternately: values stay in range
+        torch.cuda.synchronize()
+        prev = start
+        for name, e in marks:
+            stage_ms[name] = stage_ms.get(name, 0.0) + prev.elapsed_time(e) / steps
+            prev = e
+    dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = max_over_ranks(time.perf_counter() - t0, dist, dev)
+    if steps % 2 == 0:   # an even number of steps is `steps / 2` round trips: the input must be back
+        after = float((re.double() ** 2 + im.double() ** 2).sum())
+        energy_ok = abs(after / before - 1.0) < 1e-9
+    else:                # ... plus one forward transform: Parseval, sum |X|^2 = N sum |x|^2 (summed over the ranks)
+        loc = torch.tensor([before, float((re.double() ** 2 + im.double() ** 2).sum())], dtype=torch.float64,
+                           device="cpu" if args.backend == "gloo" else dev)
+        dist.all_reduce(loc)
+        energy_ok = abs(float(loc[1]) / (n * float(loc[0])) - 1.0) < 1e-9
+    if rank == 0:
+        per_exchange = 2 * slab * 8                      # both planes of the rank's slab
+        ms = 1e3 * elapsed / steps
+        local = sum(v for k, v in stage_ms.items() if k.startswith(("fft", "twiddle")))
+        exch = sum(v for k, v in stage_ms.items() if k.startswith("exchange"))
+        perm = sum(v for k, v in stage_ms.items() if k.startswith(("pack", "unpack", "store")))
+        out = {"metric": f"GSamples/s ONE f64 transform of 2^{L} points over {world} GPU(s) (four-step split, SURVEY.md 8 f-3)",
+               "value": n / (ms * 1e-3) / 1e9, "unit": "GSamples/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+               "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+               "data": "synthetic (counter-based uniform [-1,1), generated on device)",
+               "config": {"workload": f"one transform of 2^{L} f64 points, slab of 2^{L}/{world} per rank, natural order in and out",
+                          "n1_x_n2": [t.n1, t.n2], "backend": args.backend, "energy_ok": bool(energy_ok)},
+               "stages_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+               "summary_ms": {"local_ffts": round(local, 4), "exchanges": round(exch, 4), "pack_unpack_store": round(perm, 4)},
+               "exchange": {"count_per_plane": 3, "bytes_per_exchange_per_rank": per_exchange,
+                            "bytes_leaving_the_gpu_per_exchange": per_exchange * (world - 1) // world,
+                            "note": ("one rank: every exchange is RCCL's self-copy -- no xGMI byte moves" if world == 1 else
+                                     "RCCL all_to_all_single over xGMI: (P-1)/P of the slab leaves the GPU per exchange")}}
+        print(json.dumps(out), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     args = parse()
     # the host driver of this pool only supports dmabuf IPC: without this RCCL / device-tensor sharing across the ranks
@@ -619,7 +704,7 @@ def main():
     if have < need:
         fail(f"{need} GPU(s) needed on this node, {have} visible"
              + ("" if need == 1 else " (use --same-gpu --backend gloo for a one-GPU dry run)"))
-    multi = world > 1 or args.sharded
+    multi = world > 1 or args.sharded or args.dist_fft > 0
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -644,6 +729,9 @@ def main():
     import phastft_amd as P
 
     dev = torch.device("cuda", local_rank if multi else 0)
+    if args.dist_fft:
+        dist_fft_mode(args, P, torch, dev, rank, n_gpus)
+        return
     planner = P.PlannerDit64(N)
     if args.plan:
         lrs_s, rest = args.plan.split("@")

@@ -60,6 +60,10 @@ class DistributedFft:
         self.n, self.rank, self.world, self.dist = n, rank, world, dist
         self.n1, self.n2 = split_factors(n.bit_length() - 1, world)
         self._fft, self._twiddle, self._fft_tw = column_fft, twiddle, column_fft_tw
+        # measurement hook (bench.py --dist-fft): called with the name of every stage of run() as it has been ENQUEUED --
+        # "pack1", "exchange1", "fft_n1", "twiddle" (only when not fused), "exchange2", "unpack2", "fft_n2", "exchange3",
+        # "unpack3", "store" -- so that the caller can drop an event on its stream behind each
+        self.on_stage: Callable[[str], None] | None = None
         if world > 1 and dist is None:
             raise ValueError("more than one rank needs a torch.distributed process group")
 
@@ -101,33 +105,48 @@ class DistributedFft:
         def unpack3(x):    # received [src s][k2 mine][k1 in s's block] -> [k2 mine][k1]
             return x.view(w, c2, r1).permute(1, 0, 2).contiguous().view(-1) if w > 1 else x
 
+        mark = self.on_stage or (lambda name: None)
         # exchange 1 -> [n1][n2 mine] (source-major = natural n1 order): column FFTs over n1
-        a_re, a_im = self._all_to_all(pack(re)), self._all_to_all(pack(im))
+        p_re, p_im = pack(re), pack(im)
+        mark("pack1")
+        a_re, a_im = self._all_to_all(p_re), self._all_to_all(p_im)
+        del p_re, p_im
         if self.dist is None:  # no exchange happened: a_re / a_im still alias the caller's slab
             a_re, a_im = a_re.clone(), a_im.clone()
+        mark("exchange1")
         self._fft(a_re, a_im, n1, c2)
+        mark("fft_n1")
         # The inter-factor twiddle W_N^(k1 * n2) commutes with the exchange (it is element-wise): it is applied on the
         # other side, fused into the first load of the column FFTs over n2 (rows n2, columns k1 = rank*r1 + c) where
         # the kernels can do that, else as its own sweep over [k1][n2 mine] before the exchange.
         fused = self._fft_tw is not None
         if not fused:
             self._twiddle(a_re, a_im, n1, c2, self.rank * c2)
+            mark("twiddle")
         # exchange 2: the block for rank q is the rows k1 of q's range -- contiguous as it stands
-        b_re, b_im = unpack2(self._all_to_all(a_re)), unpack2(self._all_to_all(a_im))
-        del a_re, a_im
+        x_re, x_im = self._all_to_all(a_re), self._all_to_all(a_im)
+        mark("exchange2")
+        b_re, b_im = unpack2(x_re), unpack2(x_im)
+        del a_re, a_im, x_re, x_im
+        mark("unpack2")
         if not fused or not self._fft_tw(b_re, b_im, n2, r1, self.rank * r1):   # -> [k2][k1 mine]
             if fused:  # the fused form declined this shape: W_N^(n2 * k1) on [n2][k1 mine], then the plain transform
                 self._twiddle_t(b_re, b_im, n2, r1, self.rank * r1)
             self._fft(b_re, b_im, n2, r1)
+        mark("fft_n2")
         # exchange 3: rows k2 of q's range, contiguous; unpack to natural order
-        c_re, c_im = unpack3(self._all_to_all(b_re)), unpack3(self._all_to_all(b_im))
-        del b_re, b_im
+        y_re, y_im = self._all_to_all(b_re), self._all_to_all(b_im)
+        mark("exchange3")
+        c_re, c_im = unpack3(y_re), unpack3(y_im)
+        del b_re, b_im, y_re, y_im
+        mark("unpack3")
         if reverse:
             scale = 1.0 / self.n  # algorithms/dit.rs:325-331
             c_re *= scale
             c_im *= scale
         re.copy_(c_re)
         im.copy_(c_im)
+        mark("store")
 
 
 def gpu_transform(n: int, rank: int, world: int, dist=None, dtype: str = "f64") -> DistributedFft:

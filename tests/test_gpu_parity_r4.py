@@ -196,3 +196,26 @@ def test_one_planner_four_threads_four_streams(gpu, tmp_path):
     assert four > 1.15 * one, res
     # a handful of workspaces (<= one per concurrent caller and batch size seen), not one per call
     assert res["device_bytes"] < 8 * 64 * 2 * (1 << 16) * 8 * 1.25, res
+
+
+# ---------------------------------------------------------------- bench.py --dist-fft (measured per stage)
+@pytest.mark.parametrize("argv,world", [(["--gpus", "1", "--dist-fft", "24", "--steps", "3", "--warmup", "1"], 1),
+                                        (["--gpus", "2", "--same-gpu", "--backend", "gloo", "--dist-fft", "22", "--steps", "2",
+                                          "--warmup", "1"], 2)])
+def test_bench_dist_fft_mode_times_every_stage(gpu, argv, world):
+    """ONE transform over the ranks of a process group with every stage timed by HIP events: on a one-rank RCCL group (the
+    exchanges are self-copies: the local-stage half of the f-3 estimate becomes a measured number) and, self-launched, on two
+    ranks sharing the GPU over gloo (the N-rank code path; its exchange times are host copies, not xGMI)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True,
+                       env=_plain_env(), timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == world and out["config"]["energy_ok"] is True, out["config"]
+    st = out["stages_ms"]
+    for name in ("pack1", "exchange1", "fft_n1", "exchange2", "unpack2", "fft_n2", "exchange3", "unpack3", "store"):
+        assert name in st and st[name] >= 0.0, (name, st)
+    assert abs(sum(st.values()) - out["ms_per_step"]) < 0.5 * out["ms_per_step"] + 1.0   # the stages add up to the step
+    assert out["exchange"]["bytes_leaving_the_gpu_per_exchange"] == out["exchange"]["bytes_per_exchange_per_rank"] * (world - 1) // world
+    assert out["summary_ms"]["local_ffts"] > 0 and out["value"] > 0.01
