@@ -648,12 +648,14 @@ def dist_fft_mode(args, P, torch, dev, rank, world):
     elapsed = max_over_ranks(time.perf_counter() - t0, dist, dev)
     if steps % 2 == 0:   # an even number of steps is `steps / 2` round trips: the input must be back
         after = float((re.double() ** 2 + im.double() ** 2).sum())
-        energy_ok = abs(after / before - 1.0) < 1e-9
+        ratio = after / before
+        energy_ok = abs(ratio - 1.0) < 1e-9
     else:                # ... plus one forward transform: Parseval, sum |X|^2 = N sum |x|^2 (summed over the ranks)
         loc = torch.tensor([before, float((re.double() ** 2 + im.double() ** 2).sum())], dtype=torch.float64,
                            device="cpu" if args.backend == "gloo" else dev)
         dist.all_reduce(loc)
-        energy_ok = abs(float(loc[1]) / (n * float(loc[0])) - 1.0) < 1e-9
+        ratio = float(loc[1]) / (n * float(loc[0]))
+        energy_ok = abs(ratio - 1.0) < 1e-9
     if rank == 0:
         per_exchange = 2 * slab * 8                      # both planes of the rank's slab
         ms = 1e3 * elapsed / steps
@@ -665,7 +667,8 @@ def dist_fft_mode(args, P, torch, dev, rank, world):
                "ms_per_step": ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
                "data": "synthetic (counter-based uniform [-1,1), generated on device)",
                "config": {"workload": f"one transform of 2^{L} f64 points, slab of 2^{L}/{world} per rank, natural order in and out",
-                          "n1_x_n2": [t.n1, t.n2], "backend": args.backend, "energy_ok": bool(energy_ok)},
+                          "n1_x_n2": [t.n1, t.n2], "backend": args.backend, "energy_ok": bool(energy_ok),
+                          "energy_ratio_minus_1": ratio - 1.0},
                "stages_ms": {k: round(v, 4) for k, v in stage_ms.items()},
                "summary_ms": {"local_ffts": round(local, 4), "exchanges": round(exch, 4), "pack_unpack_store": round(perm, 4)},
                "exchange": {"count_per_plane": 3, "bytes_per_exchange_per_rank": per_exchange,

@@ -71,6 +71,11 @@ class DistributedFft:
         """W_n^(r * (col0 + c)) on a row-major [rows][cols] block: the same call as `twiddle` (its roles are symmetric)"""
         self._twiddle(re, im, rows, cols, col0)
 
+    # largest block one collective call hands to one peer; larger blocks go in pieces.  RCCL's all_to_all_single was
+    # measured to corrupt the result from 2 GiB per peer on (one f64 transform of 2^28 points on a one-rank group lost 93 %
+    # of its energy, bench.py --dist-fft 28, round 4) -- 1 GiB pieces keep every count far below 2^31 bytes
+    max_block_bytes = 1 << 30
+
     def _all_to_all(self, send):
         """rank q receives every rank's q-th equal chunk of `send`; returns the chunks in source-rank order"""
         import torch
@@ -80,12 +85,27 @@ class DistributedFft:
         # with a process group the exchange is a real collective even for one rank (world-size-1 "nccl" group: RCCL's
         # all_to_all_single on device tensors, the one-GPU hardware test of this path)
         recv = torch.empty_like(send)
-        if self.dist.get_backend() == "gloo" and send.is_cuda:  # dry run on one GPU: through host memory
-            r = torch.empty(send.shape, dtype=send.dtype)
-            self.dist.all_to_all_single(r, send.cpu())
-            recv.copy_(r)
-        else:
-            self.dist.all_to_all_single(recv, send)
+        via_host = self.dist.get_backend() == "gloo" and send.is_cuda  # dry run on one GPU: through host memory
+        src = send.cpu() if via_host else send
+        dst = torch.empty(send.shape, dtype=send.dtype) if via_host else recv
+        block = send.numel() // self.world
+        pieces = -(-block * send.element_size() // self.max_block_bytes)
+        if pieces <= 1:
+            self.dist.all_to_all_single(dst, src)
+        else:  # piece j of every peer's block per call
+            step = -(-block // pieces)
+            views = self.dist.get_backend() == "nccl"  # RCCL: lists of views, no staging copy; gloo has no list form
+            for lo in range(0, block, step):
+                hi = min(block, lo + step)
+                if views:
+                    self.dist.all_to_all([dst[q * block + lo:q * block + hi] for q in range(self.world)],
+                                         [src[q * block + lo:q * block + hi] for q in range(self.world)])
+                else:
+                    out = torch.empty((self.world, hi - lo), dtype=src.dtype, device=src.device)
+                    self.dist.all_to_all_single(out.view(-1), src.view(self.world, block)[:, lo:hi].contiguous().view(-1))
+                    dst.view(self.world, block)[:, lo:hi] = out
+        if via_host:
+            recv.copy_(dst)
         return recv
 
     def run(self, reals, imags, reverse: bool = False):

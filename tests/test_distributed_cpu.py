@@ -121,7 +121,10 @@ def _dist_fft_worker(rank, world, port, log_n, reverse, out_dir, fused=False):
         column_fft(re, im, length, count)
         return True
 
-    DistributedFft(n, rank, world, column_fft, twiddle, dist, column_fft_tw if fused else None).run(re, im, reverse=reverse)
+    t = DistributedFft(n, rank, world, column_fft, twiddle, dist, column_fft_tw if fused else None)
+    if os.environ.get("PHAST_TEST_SMALL_BLOCKS"):  # force the chunked exchange (blocks above max_block_bytes go in pieces)
+        t.max_block_bytes = 96
+    t.run(re, im, reverse=reverse)
     np.save(os.path.join(out_dir, f"re{rank}.npy"), re.numpy())
     np.save(os.path.join(out_dir, f"im{rank}.npy"), im.numpy())
     dist.barrier()
@@ -143,6 +146,23 @@ def test_one_transform_over_ranks_gloo(tmp_path, world, log_n, reverse, fused):
     O.fft_64_dit(re, im, O.REVERSE if reverse else O.FORWARD)
     err = np.sqrt(np.sum((got_re - re) ** 2 + (got_im - im) ** 2) / np.sum(re ** 2 + im ** 2))
     assert err < 1e-13, err
+
+
+def test_one_transform_over_ranks_gloo_chunked_exchanges(tmp_path, monkeypatch):
+    """Blocks above DistributedFft.max_block_bytes are exchanged in pieces (dist.all_to_all on views: RCCL corrupts
+    all_to_all_single from 2 GiB per peer on -- found at 2^28 points on a one-rank group in round 4).  Forced here with a
+    96-byte limit: 2^12 points over 2 ranks = 8 KiB per peer and plane in 86 pieces, ragged last piece; same result."""
+    from oracle import oracle as O
+
+    monkeypatch.setenv("PHAST_TEST_SMALL_BLOCKS", "1")
+    world, log_n = 2, 12
+    mp.spawn(_dist_fft_worker, args=(world, _free_port(), log_n, False, str(tmp_path), True), nprocs=world, join=True)
+    n = 1 << log_n
+    got_re = np.concatenate([np.load(tmp_path / f"re{r}.npy") for r in range(world)])
+    got_im = np.concatenate([np.load(tmp_path / f"im{r}.npy") for r in range(world)])
+    re, im = O.fill(n, np.float64, seed=0xD157, transform_id=log_n)
+    O.fft_64_dit(re, im, O.FORWARD)
+    assert np.sqrt(np.sum((got_re - re) ** 2 + (got_im - im) ** 2) / np.sum(re ** 2 + im ** 2)) < 1e-13
 
 
 def test_split_factors():
