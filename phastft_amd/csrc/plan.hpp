@@ -254,19 +254,23 @@ inline bool single_plan(unsigned L, std::vector<unsigned> &lrs, std::vector<unsi
 // c2r_fused.hpp) and ends writing pairs -- the best factorisations differ.  Ranked on the GPU over every 2- / 3-pass
 // factorisation x tile size x points per thread (tools/sweep_real.py, profiles/r04_sweep_real_*.log), adopted where they
 // beat the C2C choice by more than the run-to-run noise (3 %):
-//   R2C  f32 2^25: 198 -> 177 us, 2^26: 429 -> 395;  f64 2^23: 122 -> 106, 2^24: 208 -> 174, 2^25: 401 -> 357, 2^26: 763 -> 695
+//   R2C  f32 2^25: 198 -> 177 us, 2^26: 429 -> 395, 2^27: 980 -> 820, 2^28: 1862 -> 1620 (the last two ran the untangle as a
+//        sweep of its own until round 4: the throughput plan's 32-point last pass has no fused form);
+//        f64 2^23: 122 -> 106, 2^24: 208 -> 174, 2^25: 401 -> 357, 2^26: 763 -> 695, 2^27: 1760 -> 1322
 //   C2R  f32 2^23: 50.9 -> 48.1, 2^25: 201 -> 184, 2^26: 444 -> 389;  f64 2^23: 98 -> 82, 2^24: 188 -> 172, 2^25: 450 -> 356,
-//        2^26: 822 -> 724
+//        2^26: 822 -> 724, 2^27: 1510 -> 1365
 // (real lengths; everything else keeps the C2C plan).  Returns false where there is no entry.
 template <typename T>
 inline bool real_plan(unsigned L, bool c2r, std::vector<unsigned> &lrs, std::vector<unsigned> &tls, unsigned &lp) {
     struct E {
         unsigned L, a, b, c, ta, tb, tc, lp;
     };
-    static const E r2c32[] = {{24, 8, 9, 7, 12, 13, 12, 4}, {25, 8, 9, 8, 13, 13, 13, 4}};
-    static const E r2c64[] = {{22, 8, 7, 7, 13, 13, 13, 4}, {23, 9, 8, 6, 12, 12, 12, 3}, {24, 9, 9, 6, 12, 13, 12, 4}, {25, 9, 9, 7, 12, 13, 12, 4}};
+    static const E r2c32[] = {{24, 8, 9, 7, 12, 13, 12, 4}, {25, 8, 9, 8, 13, 13, 13, 4}, {26, 9, 9, 8, 13, 13, 13, 4}, {27, 10, 9, 8, 13, 13, 13, 4}};
+    static const E r2c64[] = {{22, 8, 7, 7, 13, 13, 13, 4}, {23, 9, 8, 6, 12, 12, 12, 3}, {24, 9, 9, 6, 12, 13, 12, 4}, {25, 9, 9, 7, 12, 13, 12, 4},
+                              {26, 9, 9, 8, 13, 13, 13, 4}};
     static const E c2r32[] = {{22, 8, 7, 7, 13, 12, 12, 4}, {24, 8, 8, 8, 13, 13, 13, 4}, {25, 8, 9, 8, 13, 13, 13, 4}};
-    static const E c2r64[] = {{22, 8, 7, 7, 12, 13, 13, 4}, {23, 8, 8, 7, 12, 12, 13, 4}, {24, 8, 8, 8, 12, 12, 12, 4}, {25, 8, 9, 8, 13, 13, 13, 4}};
+    static const E c2r64[] = {{22, 8, 7, 7, 12, 13, 13, 4}, {23, 8, 8, 7, 12, 12, 13, 4}, {24, 8, 8, 8, 12, 12, 12, 4}, {25, 8, 9, 8, 13, 13, 13, 4},
+                              {26, 8, 9, 9, 13, 13, 12, 4}};
     const E *tab = sizeof(T) == 4 ? (c2r ? c2r32 : r2c32) : (c2r ? c2r64 : r2c64);
     const size_t cnt = sizeof(T) == 4 ? (c2r ? sizeof c2r32 : sizeof r2c32) / sizeof(E) : (c2r ? sizeof c2r64 : sizeof r2c64) / sizeof(E);
     for (size_t i = 0; i < cnt; ++i)
