@@ -9,6 +9,7 @@ set -u
 R=$(cd "$(dirname "$0")/.." && pwd)
 LIB=$R/phastft_amd/lib/libphastft_hip_asan.so
 EXE=$R/tests/cpp/host_api_test_asan
+EXE2=$R/tests/cpp/concurrent_planner_test_asan   # round 4: four threads x four streams on one planner (the workspace pool)
 CLANG=/opt/rocm/lib/llvm/bin/clang++
 case "${1:-run}" in
 build)
@@ -29,6 +30,10 @@ PY
     $CLANG -std=c++17 -O1 -g -fsanitize=address -shared-libsan -fno-omit-frame-pointer -I "$R/include" "$R/tests/cpp/host_api_test.cpp" \
         -o "$EXE" "$LIB" -Wl,-rpath,"$R/phastft_amd/lib" -Wl,-rpath,/opt/rocm/lib -Wl,-rpath,"$RT" || exit 1
     echo "$EXE"
+    $CLANG -std=c++17 -O1 -g -pthread -fsanitize=address -shared-libsan -fno-omit-frame-pointer -D__HIP_PLATFORM_AMD__ -I /opt/rocm/include \
+        -I "$R/include" "$R/tests/cpp/concurrent_planner_test.cpp" -o "$EXE2" "$LIB" -L /opt/rocm/lib -lamdhip64 \
+        -Wl,-rpath,"$R/phastft_amd/lib" -Wl,-rpath,/opt/rocm/lib -Wl,-rpath,"$RT" || exit 1
+    echo "$EXE2"
     ;;
 run)
     # Two passes, each under its own timeout.  The planner cache of the planner-less entry points (api.hip: PlannerCache)
@@ -41,6 +46,9 @@ run)
     echo "# exit code $?"
     echo "# $(date -u) host-side ASan pass 2 (planner cache on, leak check off): $EXE gpu"
     ASAN_OPTIONS=detect_leaks=0:halt_on_error=0:abort_on_error=0 timeout 120 "$EXE" gpu
+    echo "# exit code $?"
+    echo "# $(date -u) host-side ASan pass 3 (one planner, 4 threads x 4 streams: the workspace pool; leak check on): $EXE2"
+    ASAN_OPTIONS=detect_leaks=1:halt_on_error=0:abort_on_error=0 timeout 300 "$EXE2"
     echo "# exit code $?"
     ;;
 esac
