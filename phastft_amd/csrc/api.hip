@@ -279,6 +279,7 @@ struct Workspace {
     hipStream_t stream = nullptr;  // the stream the last work of this workspace went to (valid while `pending`)
     bool pending = false;          // work may still be running on `stream`
     hipStream_t own = nullptr;     // the non-blocking stream of host-slice calls (created on first use)
+    hipEvent_t idle = nullptr;     // recorded behind the last _dev call's work (Planner::check_in); owned by the workspace
     bool busy = false;             // checked out by a host thread
     bool captured = false;         // used under stream capture: pinned to the captured graphs (see above)
     // A buffer that has to grow is replaced, never freed inside the call that outgrew it: kernels already enqueued may
@@ -342,8 +343,10 @@ struct Workspace {
         }
         retired.clear();
         if (own) hipStreamDestroy(own);
+        if (idle) hipEventDestroy(idle);
         d_scratch = d_stage = d_z = h_pin = nullptr;
         own = nullptr;
+        idle = nullptr;
         cap = stage_bytes = z_cap = z_bytes = pin_bytes = retired_dev_bytes = 0;
     }
 };
@@ -405,12 +408,27 @@ template <typename T> struct Planner {
         }
     };
     // which = 0: a _dev call on `stream`; 1: a host-slice call (runs on the workspace's own stream); 2: bookkeeping only
-    // (reserve_batch: any free eager workspace, nothing is enqueued)
+    // (reserve_batch: any free eager workspace, nothing is enqueued).
+    // The library never touches a caller's stream handle after the call that was given it has returned -- the caller may
+    // destroy the stream the moment its work is done (round 4's first version asked hipStreamQuery about the stream a
+    // workspace had last served: a use-after-free inside the HIP runtime once that stream was gone, found by the ASan pass of
+    // tests/cpp/concurrent_planner_test.cpp).  What outlives a call is the workspace's OWN event, recorded behind the call's
+    // work while the stream is certainly alive (check_in): "has this workspace drained?" is hipEventQuery(idle), "order that
+    // stream behind it" is hipStreamWaitEvent(stream, idle).
     int check_out(Lease &L, hipStream_t stream, int which = 0) const {
         L.plans = std::shared_lock<std::shared_mutex>(plan_mu);
         const bool cap = which == 0 && capturing(stream);
         std::unique_lock<std::mutex> lk(mu);
         Workspace *pick = nullptr;
+        auto drained = [](Workspace &w) {  // nothing of this workspace's work can still be running
+            if (!w.pending) return true;
+            if (w.idle && hipEventQuery(w.idle) == hipSuccess) {
+                w.pending = false;
+                return true;
+            }
+            (void)hipGetLastError();  // hipErrorNotReady is an answer, not a failure
+            return false;
+        };
         for (;;) {
             if (which == 0)  // 1. the workspace this stream used last: stream order protects its buffers
                 for (auto &w : pool)
@@ -426,21 +444,12 @@ template <typename T> struct Planner {
                 for (auto &w : pool)
                     if (!w->busy && !w->captured && (!pick || w->cap > pick->cap)) pick = w.get();
             }
-            if (!pick && !cap) {  // 2. one with nothing in flight (never one that belongs to a captured graph)
+            if (!pick && !cap)  // 2. one with nothing in flight (never one that belongs to a captured graph)
                 for (auto &w : pool)
-                    if (!w->busy && !w->captured && !w->pending) {
+                    if (!w->busy && !w->captured && drained(*w)) {
                         pick = w.get();
                         break;
                     }
-                if (!pick)
-                    for (auto &w : pool)
-                        if (!w->busy && !w->captured && !stream_capturing(w->stream) && hipStreamQuery(w->stream) == hipSuccess) {
-                            w->pending = false;
-                            pick = w.get();
-                            break;
-                        }
-                (void)hipGetLastError();  // hipErrorNotReady is an answer, not a failure
-            }
             if (pick) break;
             size_t eager = 0;
             for (auto &w : pool) eager += !w->captured;
@@ -453,12 +462,11 @@ template <typename T> struct Planner {
                 pick = pool.back().get();
                 break;
             }
-            // 4. pool exhausted: queue behind another stream's work ON THE DEVICE (never behind a stream that is being
-            // captured: recording an event there would become part of somebody's graph)
+            // 4. pool exhausted: queue behind another stream's work ON THE DEVICE (below: the new stream waits for `idle`)
             bool any_busy = false;
             for (auto &w : pool) {
                 if (w->busy) any_busy = true;
-                else if (!w->captured && !stream_capturing(w->stream)) {
+                else if (!w->captured && w->idle) {
                     pick = w.get();
                     break;
                 }
@@ -477,31 +485,31 @@ template <typename T> struct Planner {
         }
         pick->busy = true;
         lk.unlock();
+        auto give_back = [&](int rc) {
+            std::lock_guard<std::mutex> g(mu);
+            pick->busy = false;
+            cv.notify_one();
+            return rc;
+        };
         hipStream_t work = stream;
         if (which == 1) {
             if (!pick->own) {
                 hipError_t e = hipStreamCreateWithFlags(&pick->own, hipStreamNonBlocking);
-                if (e != hipSuccess) {
-                    std::lock_guard<std::mutex> g(mu);
-                    pick->busy = false;
-                    cv.notify_one();
-                    return hip_fail(e, "hipStreamCreateWithFlags(workspace stream)");
-                }
+                if (e != hipSuccess) return give_back(hip_fail(e, "hipStreamCreateWithFlags(workspace stream)"));
             }
             work = pick->own;
         }
-        if (which != 2 && !cap && pick->pending && pick->stream != work) {
-            // the buffers change streams with work possibly in flight (case 4, or a host-slice call after a _dev call):
-            // order the new stream behind the old one's work on the device
-            hipEvent_t ev = nullptr;
-            hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
-            if (e == hipSuccess) e = hipEventRecord(ev, pick->stream);
-            if (e == hipSuccess) e = hipStreamWaitEvent(work, ev, 0);
-            if (ev) hipEventDestroy(ev);
-            if (e != hipSuccess) {  // e.g. the old stream has been destroyed: its work is ordered before the destruction
+        if (!cap && pick->pending && pick->idle) {
+            // Work of this workspace may still be in flight.  Same stream handle as last time: stream order already covers
+            // it -- unless the handle belongs to a NEW stream that reuses a destroyed one's address, so the (cheap) query
+            // decides; another stream (case 4, or a host-slice call after a _dev call): order this call's stream behind the
+            // workspace's last work on the device.  Bookkeeping calls (which == 2) enqueue nothing: they wait here.
+            if (hipEventQuery(pick->idle) != hipSuccess) {
                 (void)hipGetLastError();
-                (void)hipDeviceSynchronize();
+                hipError_t e = which == 2 ? hipEventSynchronize(pick->idle) : hipStreamWaitEvent(work, pick->idle, 0);
+                if (e != hipSuccess) return give_back(hip_fail(e, "hipStreamWaitEvent(workspace idle)"));
             }
+            if (which == 2) pick->pending = false;
         }
         L.pl = this;
         L.ws = pick;
@@ -515,9 +523,22 @@ template <typename T> struct Planner {
         }
         return PHAST_OK;
     }
-    void check_in(Workspace *ws, hipStream_t, bool host_synchronised) const {
+    // the call has enqueued everything (a host-slice call: and waited for it)
+    void check_in(Workspace *ws, hipStream_t stream, bool host_synchronised) const {
+        if (host_synchronised) {
+            (void)hipStreamSynchronize(stream);      // (already drained on the success path; an early error return may not be)
+            if (!ws->captured) ws->pending = false;  // returns with its stream drained
+        } else if (ws->pending && !ws->captured && !capturing(stream)) {
+            // behind this call's work, while the caller's stream is certainly alive: the only thing later calls look at
+            hipError_t e = ws->idle ? hipSuccess : hipEventCreateWithFlags(&ws->idle, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventRecord(ws->idle, stream);
+            if (e != hipSuccess) {  // cannot mark it: make sure nothing is in flight instead
+                (void)hipGetLastError();
+                (void)hipStreamSynchronize(stream);
+                ws->pending = false;
+            }
+        }
         std::lock_guard<std::mutex> g(mu);
-        if (host_synchronised && !ws->captured) ws->pending = false;  // a host-slice call returns with its stream drained
         ws->busy = false;
         cv.notify_one();
     }
@@ -2107,7 +2128,7 @@ int phast_options_guess(size_t input_size, phast_options *out) {
         Planner<T>::Lease L;                                                                                       \
         int rc = p->check_out(L, nullptr, 2);                                                                      \
         if (rc) return rc;                                                                                         \
-        L.stream = L.ws->pending ? L.ws->stream : nullptr;                                                         \
+        L.stream = nullptr; /* check_out waited for the workspace: whatever is retired below is idle */          \
         size_t cap;                                                                                                \
         return p->ensure_scratch(L, max_batch, &cap);                                                              \
     }                                                                                                              \

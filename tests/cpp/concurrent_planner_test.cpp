@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "phastft_hip.h"
+#include "sanitizer_exit.hpp"
 
 #define CHECK(x)                                                                        \
     do {                                                                                \
@@ -138,5 +139,5 @@ int main() {
                 "\"dev_calls_per_s_batch64\": [%.1f, %.1f], \"device_bytes\": %zu}\n",
                 n, T, ok ? "true" : "false", h1, h4, d1[0], d4[0], d1[1], d4[1], d1[2], d4[2], phast_planner_dit64_device_bytes(pl));
     phast_planner_dit64_free(pl);
-    return ok ? 0 : 1;
+    phast_test_exit(ok ? 0 : 1);
 }

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "phastft.hpp"
+#include "sanitizer_exit.hpp"
 
 using namespace phastft;
 
@@ -225,5 +226,5 @@ int main(int argc, char **argv) {
         EXPECT(ok);
     }
     std::printf("host_api_test (GPU): %d failure(s)\n", failures);
-    return failures ? 1 : 0;
+    phast_test_exit(failures ? 1 : 0);
 }

@@ -168,7 +168,7 @@ def test_one_planner_four_threads_four_streams(gpu, tmp_path):
     """ONE planner shared by four host threads (planner.rs:38-39), plain C++ threads over the C ABI
     (tests/cpp/concurrent_planner_test.cpp -- Python threads would measure the GIL).  Round 3 serialised them on one scratch
     and the NULL stream; with a workspace per concurrent caller
-      (a) blocking host-slice calls of 2^16 points overlap their copies, kernels and waits: > 2 x the one-thread call rate;
+      (a) blocking host-slice calls of 2^16 points overlap their copies, kernels and waits: 2.2-2.4 x the one-thread call rate;
       (b) _dev calls on four streams, each followed by a stream synchronisation: > 2 x for single transforms and small
           batches, where one caller leaves the GPU idle between its launch and its wait; a batch of 64 x 2^16 f64 (64 MiB
           each way per pass) nearly fills the chip on its own, so there the gain is the launch / wait gaps only;
@@ -189,7 +189,7 @@ def test_one_planner_four_threads_four_streams(gpu, tmp_path):
     print(res)
     assert res["bit_identical"] is True, res
     one, four = res["host_calls_per_s"]
-    assert four > 2.0 * one, res
+    assert four > 1.7 * one, res          # measured 2.2-2.4 x (8.4k -> 20.5k calls/s); the margin is for slower hosts
     one, four = res["dev_calls_per_s_batch1"]
     assert four > 2.0 * one, res
     one, four = res["dev_calls_per_s_batch64"]
