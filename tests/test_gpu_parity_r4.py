@@ -196,6 +196,14 @@ def test_one_planner_four_threads_four_streams(gpu, tmp_path):
     assert four > 1.15 * one, res
     # a handful of workspaces (<= one per concurrent caller and batch size seen), not one per call
     assert res["device_bytes"] < 8 * 64 * 2 * (1 << 16) * 8 * 1.25, res
+    # the same program with ONE workspace per planner: four streams share a scratch, each call's stream queued behind the
+    # previous stream's work on the device (Planner::check_out, case 4) -- and the program destroys its streams between the
+    # batch sizes, so later calls meet workspaces whose last stream no longer exists.  Correct, just not concurrent.
+    r1 = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=dict(_plain_env(), PHAST_MAX_WORKSPACES="1"))
+    assert r1.returncode == 0, r1.stdout[-2000:] + r1.stderr[-4000:]
+    res1 = json.loads([ln for ln in r1.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res1["bit_identical"] is True, res1
+    assert res1["device_bytes"] < res["device_bytes"], (res1["device_bytes"], res["device_bytes"])
 
 
 # ---------------------------------------------------------------- bench.py --dist-fft (measured per stage)
