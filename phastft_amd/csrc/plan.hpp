@@ -256,7 +256,7 @@ inline bool single_plan(unsigned L, std::vector<unsigned> &lrs, std::vector<unsi
 // beat the C2C choice by more than the run-to-run noise (3 %):
 //   R2C  f32 2^25: 198 -> 177 us, 2^26: 429 -> 395, 2^27: 980 -> 820, 2^28: 1862 -> 1620 (the last two ran the untangle as a
 //        sweep of its own until round 4: the throughput plan's 32-point last pass has no fused form);
-//        f64 2^23: 122 -> 106, 2^24: 208 -> 174, 2^25: 401 -> 357, 2^26: 763 -> 695, 2^27: 1760 -> 1322
+//        f64 2^23: 122 -> 106, 2^24: 208 -> 174, 2^25: 401 -> 357, 2^26: 763 -> 695, 2^27: 1760 -> 1322, 2^28: 3385 -> 2785 (last pass + sweep 1699 -> fused 1034)
 //   C2R  f32 2^23: 50.9 -> 48.1, 2^25: 201 -> 184, 2^26: 444 -> 389;  f64 2^23: 98 -> 82, 2^24: 188 -> 172, 2^25: 450 -> 356,
 //        2^26: 822 -> 724, 2^27: 1510 -> 1365
 // (real lengths; everything else keeps the C2C plan).  Returns false where there is no entry.
@@ -267,7 +267,7 @@ inline bool real_plan(unsigned L, bool c2r, std::vector<unsigned> &lrs, std::vec
     };
     static const E r2c32[] = {{24, 8, 9, 7, 12, 13, 12, 4}, {25, 8, 9, 8, 13, 13, 13, 4}, {26, 9, 9, 8, 13, 13, 13, 4}, {27, 10, 9, 8, 13, 13, 13, 4}};
     static const E r2c64[] = {{22, 8, 7, 7, 13, 13, 13, 4}, {23, 9, 8, 6, 12, 12, 12, 3}, {24, 9, 9, 6, 12, 13, 12, 4}, {25, 9, 9, 7, 12, 13, 12, 4},
-                              {26, 9, 9, 8, 13, 13, 13, 4}};
+                              {26, 9, 9, 8, 13, 13, 13, 4}, {27, 9, 10, 8, 13, 13, 13, 4}};
     static const E c2r32[] = {{22, 8, 7, 7, 13, 12, 12, 4}, {24, 8, 8, 8, 13, 13, 13, 4}, {25, 8, 9, 8, 13, 13, 13, 4}};
     static const E c2r64[] = {{22, 8, 7, 7, 12, 13, 13, 4}, {23, 8, 8, 7, 12, 12, 13, 4}, {24, 8, 8, 8, 12, 12, 12, 4}, {25, 8, 9, 8, 13, 13, 13, 4},
                               {26, 8, 9, 9, 13, 13, 12, 4}};

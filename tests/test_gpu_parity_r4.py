@@ -227,3 +227,38 @@ def test_bench_dist_fft_mode_times_every_stage(gpu, argv, world):
     assert abs(sum(st.values()) - out["ms_per_step"]) < 0.5 * out["ms_per_step"] + 1.0   # the stages add up to the step
     assert out["exchange"]["bytes_leaving_the_gpu_per_exchange"] == out["exchange"]["bytes_per_exchange_per_rank"] * (world - 1) // world
     assert out["summary_ms"]["local_ffts"] > 0 and out["value"] > 0.01
+
+
+# ---------------------------------------------------------------- the fused real-transform passes beyond 2^26
+def test_r2c_f32_2p27_fused_every_output(gpu, oracle):
+    """Real transforms of 2^27 / 2^28 points ran the untangle as a sweep of its own until round 4 (the throughput plan's 32-point
+    last pass has no fused form); `plan.hpp: real_plan` now gives them inner plans whose last pass fuses.  f32 2^27: three
+    kernels, every one of the 2^26 + 1 bins against the oracle's r2c and an independent float64 real FFT, the worst single
+    bin bounded, and the C2R round trip."""
+    import torch
+
+    n = 1 << 27
+    h1 = n // 2 + 1
+    x = torch.empty(n, dtype=torch.float32, device="cuda")
+    gpu.fill_uniform(x, None, n, seed=0x2727, first_id=3)
+    ore = torch.empty(h1, dtype=torch.float32, device="cuda")
+    oim = torch.empty_like(ore)
+    pl = gpu.PlannerR2c32(n)
+    gpu.r2c_fft_f32_with_planner(x, ore, oim, pl)
+    ms = pl.time_passes(x, ore, oim, reps=1)
+    assert len(ms) == 3 and "r2c-single=" in pl.describe(), (ms, pl.describe())   # no fourth kernel: the untangle is fused
+    hx = x.cpu().numpy()
+    ref_re, ref_im = np.zeros(h1, np.float32), np.zeros(h1, np.float32)
+    oracle.r2c_fft_f32(hx, ref_re, ref_im)
+    g_re, g_im = ore.cpu().numpy().astype(np.float64), oim.cpu().numpy().astype(np.float64)
+    ind = np.fft.rfft(hx.astype(np.float64))
+    den = np.sqrt(np.sum(ind.real ** 2 + ind.imag ** 2))
+    assert np.sqrt(np.sum((g_re - ind.real) ** 2 + (g_im - ind.imag) ** 2)) / den <= 1e-5
+    assert np.sqrt(np.sum((g_re - ref_re) ** 2 + (g_im - ref_im) ** 2)) / den <= 1e-5
+    rms = den / np.sqrt(h1)
+    assert max(np.max(np.abs(g_re - ind.real)), np.max(np.abs(g_im - ind.imag))) / rms <= 2e-3
+    assert g_im[0] == 0 and g_im[-1] == 0
+    del ind, ref_re, ref_im, g_re, g_im
+    back = torch.empty_like(x)
+    gpu.c2r_fft_f32_with_planner(ore, oim, back, pl)
+    assert float((back - x).abs().max()) < 2e-4
