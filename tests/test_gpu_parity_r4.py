@@ -262,3 +262,35 @@ def test_r2c_f32_2p27_fused_every_output(gpu, oracle):
     back = torch.empty_like(x)
     gpu.c2r_fft_f32_with_planner(ore, oim, back, pl)
     assert float((back - x).abs().max()) < 2e-4
+
+
+@pytest.mark.parametrize("k,dt", [(23, "f64"), (24, "f64"), (25, "f64"), (26, "f64"), (23, "f32"), (25, "f32"), (26, "f32")])
+def test_real_transform_plans_every_output(gpu, k, dt):
+    """One R2C / C2R transform runs the plan ranked for the real transform itself where `plan.hpp: real_plan` has one (round 4;
+    `r2c-single=` / `c2r-single=` in describe()).  Every bin of r2c_fft against an independent float64 real FFT (rel-L2 and
+    the worst single bin), exact zeros in Im X[0] and Im X[h], and c2r_fft gives the signal back -- at every size that has
+    an entry."""
+    import torch
+
+    n = 1 << k
+    h1 = n // 2 + 1
+    ndt, tdt, tol, tol_bin, tol_back = ((np.float64, torch.float64, 1e-13, 1e-11, 1e-10) if dt == "f64" else
+                                        (np.float32, torch.float32, 1e-5, 2e-3, 2e-4))
+    pl = (gpu.PlannerR2c64 if dt == "f64" else gpu.PlannerR2c32)(n)
+    desc = pl.describe()
+    assert "r2c-single=" in desc or "c2r-single=" in desc, desc
+    x = torch.empty(n, dtype=tdt, device="cuda")
+    gpu.fill_uniform(x, None, n, seed=0x4ea1, first_id=k)
+    ore = torch.full((h1,), 7.0, dtype=tdt, device="cuda")
+    oim = torch.full((h1,), 7.0, dtype=tdt, device="cuda")
+    (gpu.r2c_fft_f64_with_planner if dt == "f64" else gpu.r2c_fft_f32_with_planner)(x, ore, oim, pl)
+    ind = np.fft.rfft(x.cpu().numpy().astype(np.float64))
+    g_re, g_im = ore.cpu().numpy().astype(np.float64), oim.cpu().numpy().astype(np.float64)
+    den = np.sqrt(np.sum(ind.real ** 2 + ind.imag ** 2))
+    assert np.sqrt(np.sum((g_re - ind.real) ** 2 + (g_im - ind.imag) ** 2)) / den <= tol, desc
+    assert max(np.max(np.abs(g_re - ind.real)), np.max(np.abs(g_im - ind.imag))) / (den / np.sqrt(h1)) <= tol_bin, desc
+    assert g_im[0] == 0 and g_im[-1] == 0
+    del ind, g_re, g_im
+    back = torch.empty_like(x)
+    (gpu.c2r_fft_f64_with_planner if dt == "f64" else gpu.c2r_fft_f32_with_planner)(ore, oim, back, pl)
+    assert float((back - x).abs().max()) < tol_back, desc
