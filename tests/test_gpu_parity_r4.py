@@ -294,3 +294,26 @@ def test_real_transform_plans_every_output(gpu, k, dt):
     back = torch.empty_like(x)
     (gpu.c2r_fft_f64_with_planner if dt == "f64" else gpu.c2r_fft_f32_with_planner)(ore, oim, back, pl)
     assert float((back - x).abs().max()) < tol_back, desc
+
+
+def test_planner_pool_stress_eight_threads_three_planners(gpu, tmp_path):
+    """tests/cpp/planner_stress_test.cpp: eight host threads, three shared planners, a random mix of blocking host-slice calls,
+    _dev calls on private streams (batches of 1..6), R2C / C2R -- and streams destroyed and re-created in between, as callers
+    may.  Every result bit-identical to the single-threaded reference; with the default pool and with two workspaces per
+    planner (streams queue behind each other on the device)."""
+    from phastft_amd import build
+
+    lib = build.build()
+    libdir = os.path.dirname(lib)
+    exe = str(tmp_path / "planner_stress_test")
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-pthread", "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include",
+           "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "tests", "cpp"),
+           os.path.join(ROOT, "tests", "cpp", "planner_stress_test.cpp"), "-o", exe, "-L", libdir, "-lphastft_hip", "-L", "/opt/rocm/lib",
+           "-lamdhip64", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    for extra in ({}, {"PHAST_MAX_WORKSPACES": "2"}):
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=dict(_plain_env(), **extra))
+        assert r.returncode == 0, (extra, r.stdout[-2000:] + r.stderr[-4000:])
+        res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert res["mismatches"] == 0 and res["ops"] == 8 * 160, (extra, res)

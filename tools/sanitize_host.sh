@@ -10,6 +10,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 LIB=$R/phastft_amd/lib/libphastft_hip_asan.so
 EXE=$R/tests/cpp/host_api_test_asan
 EXE2=$R/tests/cpp/concurrent_planner_test_asan   # round 4: four threads x four streams on one planner (the workspace pool)
+EXE3=$R/tests/cpp/planner_stress_test_asan       # round 4: eight threads, three planners, random calls, streams destroyed in between
 CLANG=/opt/rocm/lib/llvm/bin/clang++
 case "${1:-run}" in
 build)
@@ -34,6 +35,10 @@ PY
         -I "$R/include" "$R/tests/cpp/concurrent_planner_test.cpp" -o "$EXE2" "$LIB" -L /opt/rocm/lib -lamdhip64 \
         -Wl,-rpath,"$R/phastft_amd/lib" -Wl,-rpath,/opt/rocm/lib -Wl,-rpath,"$RT" || exit 1
     echo "$EXE2"
+    $CLANG -std=c++17 -O1 -g -pthread -fsanitize=address -shared-libsan -fno-omit-frame-pointer -D__HIP_PLATFORM_AMD__ -I /opt/rocm/include \
+        -I "$R/include" -I "$R/tests/cpp" "$R/tests/cpp/planner_stress_test.cpp" -o "$EXE3" "$LIB" -L /opt/rocm/lib -lamdhip64 \
+        -Wl,-rpath,"$R/phastft_amd/lib" -Wl,-rpath,/opt/rocm/lib -Wl,-rpath,"$RT" || exit 1
+    echo "$EXE3"
     ;;
 run)
     # Two passes, each under its own timeout.  The planner cache of the planner-less entry points (api.hip: PlannerCache)
@@ -49,6 +54,12 @@ run)
     echo "# exit code $?"
     echo "# $(date -u) host-side ASan pass 3 (one planner, 4 threads x 4 streams: the workspace pool; leak check on): $EXE2"
     ASAN_OPTIONS=detect_leaks=1:halt_on_error=0:abort_on_error=0 timeout 300 "$EXE2"
+    echo "# exit code $?"
+    echo "# $(date -u) host-side ASan pass 4 (stress: 8 threads, 3 planners, streams destroyed in between; leak check on): $EXE3"
+    ASAN_OPTIONS=detect_leaks=1:halt_on_error=0:abort_on_error=0 timeout 600 "$EXE3"
+    echo "# exit code $?"
+    echo "# $(date -u) host-side ASan pass 5 (the same with PHAST_MAX_WORKSPACES=2)"
+    ASAN_OPTIONS=detect_leaks=1:halt_on_error=0:abort_on_error=0 PHAST_MAX_WORKSPACES=2 timeout 600 "$EXE3"
     echo "# exit code $?"
     ;;
 esac
