@@ -239,9 +239,9 @@ struct PassTimer {
 // call), so concurrent callers of one planner run side by side instead of one behind the other.
 //   * a workspace is bound to the stream its last work went to: calls on that stream come back to it (stream order makes
 //     the reuse of its scratch safe without any synchronisation);
-//   * a call on another stream takes a workspace whose stream has drained, or makes a new one (up to
-//     PHAST_MAX_WORKSPACES, default 8), or -- pool exhausted -- takes a busy one's buffers BEHIND an event: the new stream
-//     waits on the device for the old stream's work, the host never blocks;
+//   * a call on another stream takes a workspace whose work has drained (its own `idle` event, recorded behind every _dev
+//     call, has completed), or makes a new one (up to PHAST_MAX_WORKSPACES, default 8), or -- pool exhausted -- takes one
+//     whose work is still in flight BEHIND that event: the new stream waits on the device, the host never blocks;
 //   * host-slice calls run on the workspace's own non-blocking stream, never on the NULL stream;
 //   * a workspace that was used under stream capture belongs to the captured graph(s) from then on: replays may run at any
 //     time on streams this library never sees, so eager calls never take it and none of its buffers is ever freed before
