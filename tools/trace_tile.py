@@ -2,7 +2,7 @@
 """Phase timeline of the tile kernels for one transform (s_memtime stamps of every workgroup's FIRST tile).
 
     python -m phastft_amd.build --trace
-    PHASTFT_HIP_LIB=phastft_amd/lib/libphastft_hip_trace.so python tools/trace_tile.py 20 "7,6,7@11,10,11p8" ...
+    PHASTFT_HIP_LIB=phastft_amd/lib/libphastft_hip_trace.so python tools/trace_tile.py [--f32] 20 "7,6,7@11,10,11p8" ...
 
 Prints, per pass, when each phase boundary is reached (ticks since the first workgroup entered the kernel; min /
 mean / max over the workgroups): stamp 0 = entry, 1 = tables in LDS, 2 = tile loaded (+ pre-twiddle), then one per
@@ -20,18 +20,21 @@ import phastft_amd as P  # noqa: E402
 from phastft_amd import _lib  # noqa: E402
 
 lib = _lib.lib()
-log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-specs = sys.argv[2:] or ["default"]
+F32 = "--f32" in sys.argv
+ARGV = [a for a in sys.argv[1:] if a != "--f32"]
+log_n = int(ARGV[0]) if ARGV else 20
+specs = ARGV[1:] or ["default"]
+DT = torch.float32 if F32 else torch.float64
 n = 1 << log_n
 for spec in specs:
-    pl = P.PlannerDit64(n)
+    pl = (P.PlannerDit32 if F32 else P.PlannerDit64)(n)
     if spec != "default":
         lrs_s, rest = spec.split("@")
         tl_s, p_s = rest.split("p")
         pl.set_plan(tuple(int(x) for x in lrs_s.split(",")), tuple(int(x) for x in tl_s.split(",")),
                     {8: 3, 16: 4, 32: 5}[int(p_s)])
     ring = 40
-    re = torch.empty(n * ring, dtype=torch.float64, device="cuda")
+    re = torch.empty(n * ring, dtype=DT, device="cuda")
     im = torch.empty_like(re)
     P.fill_uniform(re, im, n)
     for i in range(3):
