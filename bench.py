@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X PhastFT path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]                     (N = 1)
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--steps K] [--warmup W]                                (N = 1)
+    python bench.py --gpus N ...            (N > 1: launches its own N ranks under torch.distributed.run on 127.0.0.1;
+                                             refuses -- rc 2, no JSON line -- what it cannot measure: fewer GPUs than N, a
+                                             launcher whose WORLD_SIZE differs from --gpus)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...      (the driver's form)
+    python bench.py --dist-fft L [--gpus N] (ONE transform of 2^L points over the ranks, every stage timed: SURVEY 8 f-3)
 
 Metric (BASELINE.json): GSamples/s of the f64 forward planar FFT at N=2^20 and 2^26 (and % of the HBM roofline),
 complex samples transformed per second over the whole job, inputs resident in HBM when the timed region starts.
@@ -28,7 +32,9 @@ complex samples transformed per second over the whole job, inputs resident in HB
     Parseval on every transform of the shard and >= 8 sampled transforms against digests computed from the CPU
     oracle's output (the oracle is the checker here, never the thing measured).
 
-"roofline": HIP-event duration of the dominant pass kernel vs the 8 TB/s HBM peak (DESIGN.md section 6);
+"roofline": HIP-event duration of the dominant pass kernel vs the 8 TB/s HBM peak, and -- N = 1 --
+`stream_probe` = {read, write, copy} GB/s of the library's own hand-written streaming kernels on 1 GiB in the same run
+(csrc/probe.hip) with `frac_of_copy` / `pass_frac_of_copy` for every config: the ceiling of THIS box on the line;
 "cpu_baseline": the -O3 build of the oracle (a C restatement of the reference's CPU algorithm, bit-identical to the
 checker build) timed on this host on a bounded sample; rank 0, N = 1 only.
 """
