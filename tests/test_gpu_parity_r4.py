@@ -317,3 +317,34 @@ def test_planner_pool_stress_eight_threads_three_planners(gpu, tmp_path):
         assert r.returncode == 0, (extra, r.stdout[-2000:] + r.stderr[-4000:])
         res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
         assert res["mismatches"] == 0 and res["ops"] == 8 * 160, (extra, res)
+
+
+@pytest.mark.parametrize("k", [27, 28])
+def test_r2c_f64_large_fused_vs_c2c_route(gpu, k):
+    """`r2c_fft_f64` of 2^27 / 2^28 real points runs a ranked plan with the untangle in the last pass (`real_plan`, round 4).
+    Every bin against the library's own C2C transform of the same signal with a zero imaginary part (another plan, other
+    kernels, no untangle): X[j] = C[j] for j <= N/2 -- rel-L2 and the worst single bin; then C2R gives the signal back."""
+    import torch
+
+    n = 1 << k
+    h1 = n // 2 + 1
+    x = torch.empty(n, dtype=torch.float64, device="cuda")
+    gpu.fill_uniform(x, None, n, seed=0x2828, first_id=k)
+    pl = gpu.PlannerR2c64(n)
+    assert "r2c-single=" in pl.describe(), pl.describe()
+    ore = torch.empty(h1, dtype=torch.float64, device="cuda")
+    oim = torch.empty_like(ore)
+    gpu.r2c_fft_f64_with_planner(x, ore, oim, pl)
+    assert len(pl.time_passes(x, ore, oim, reps=1)) == 3          # three kernels: the untangle is fused
+    c_re = x.clone()
+    c_im = torch.zeros_like(x)
+    gpu.fft_64_dit_with_planner(c_re, c_im, gpu.Direction.Forward, gpu.PlannerDit64(n))
+    d_re, d_im = ore - c_re[:h1], oim - c_im[:h1]
+    den = float((c_re[:h1] ** 2 + c_im[:h1] ** 2).sum().sqrt())
+    assert float((d_re ** 2 + d_im ** 2).sum().sqrt()) / den <= 1e-13
+    assert max(float(d_re.abs().max()), float(d_im.abs().max())) / (den / np.sqrt(h1)) <= 1e-11
+    assert float(oim[0]) == 0.0 and float(oim[-1]) == 0.0
+    del c_re, c_im, d_re, d_im
+    back = torch.empty_like(x)
+    gpu.c2r_fft_f64_with_planner(ore, oim, back, pl)
+    assert float((back - x).abs().max()) < 1e-10
