@@ -182,7 +182,10 @@ template <typename T, int LR, int LC, int LP, bool PRE_TW, bool TRANSPOSE, bool 
     static constexpr int kbits(int i) { return i <= 0 ? 0 : (i < S ? LP * i : LR); }
 
     // the pre-twiddle as two look-ups + a progression (see pre_twiddle): six table entries per thread and tile
-    static constexpr bool PROG = PRE_TW && LR >= PHAST_TW_PROG_MIN_LR && LP >= PHAST_TW_PROG_MIN_LP;
+    // (round 4: in f32 every shape takes the progression -- profiles/r04_prog_f32_ab.log: one transform of 2^22 / 2^23 points
+    // +3.7 %, 2^20 +1.5 %, 8 x 2^20 +2 %, 2^24 unchanged; the same switch in f64 is neutral to -3 %, so f64 keeps the shape
+    // condition)
+    static constexpr bool PROG = PRE_TW && (sizeof(T) == 4 || (LR >= PHAST_TW_PROG_MIN_LR && LP >= PHAST_TW_PROG_MIN_LP));
     // ... which may as well come straight from global memory when the three-level tables (48 KiB from N = 2^28 on)
     // no longer fit the LDS next to the tile: the 16384-point tiles stay available for the largest transforms
     // (2^28 f64: 1024 x 8 tiles with 64-byte rows were the fallback, 20 % slower)
