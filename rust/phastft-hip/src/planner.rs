@@ -1,7 +1,7 @@
 //! `phastft::planner` (planner.rs:10-212): `Direction`, `PlannerMode` and the four planners.  A planner owns
 //! device twiddle tables and device scratch inside `libphastft_hip.so`; like the reference's planners it is an
-//! immutable value any number of callers may borrow (`Send + Sync`, planner.rs:38-39) -- the library serialises
-//! the calls that share one planner's scratch.
+//! immutable value any number of callers may borrow (`Send + Sync`, planner.rs:38-39) -- inside the library every
+//! concurrent caller works in a workspace of its own (scratch, staging, stream), so borrowed planners run side by side.
 use crate::ffi::{self, Opaque};
 use std::ffi::c_int;
 
@@ -26,7 +26,7 @@ macro_rules! impl_planner_dit {
         pub struct $name {
             pub(crate) h: *mut Opaque,
         }
-        // SAFETY: the handle is immutable after creation; calls on one planner are serialised inside the library
+        // SAFETY: the handle is immutable after creation; what a call mutates lives in a per-call workspace inside the library
         unsafe impl Send for $name {}
         unsafe impl Sync for $name {}
         impl $name {
