@@ -59,6 +59,35 @@ __global__ void __launch_bounds__(NTH) bitrev_tiled_kernel(U *data, unsigned log
     }
 }
 
+// The tile pairs {t, rev t} of an array of 2^m tiles, ENUMERATED (round 4) -- every pair exactly once, by construction.
+// Until now the persistent kernels walked all 2^m tiles grid-stride and skipped those with t > rev(t); which of a
+// workgroup's items survive that test is decided by index bits the workgroup's items SHARE, so under the spread order of
+// the second generation half of the workgroups kept all of their items and the other half none (in linear order a
+// workgroup kept anything between none and all): half the chip idle or a long tail.
+// With t = (a | mid | rev_h(b)), h = floor(m / 2) bits each for a and b, the pairs are the (a, b) with a <= b (times the
+// middle bit when m is odd); the triangle is folded into an S/2 x (S + 1) rectangle (rows i and S - 1 - i together have
+// S + 1 elements), so position p -> pair needs one division and every workgroup gets the same number of pairs.
+struct PairEnum {
+    unsigned m, h, mb, S;
+    unsigned long long pairs;  // per array
+    __host__ __device__ explicit PairEnum(unsigned tile_bits) : m(tile_bits), h(tile_bits / 2), mb(tile_bits - 2 * (tile_bits / 2)), S(1u << (tile_bits / 2)) {
+        pairs = h == 0 ? (1ull << m) : ((unsigned long long)(S / 2) * (S + 1)) << mb;
+    }
+    __device__ unsigned tile(unsigned p) const {
+        if (h == 0) return p;
+        const unsigned mid = p & ((1u << mb) - 1u), q = p >> mb, i = q / (S + 1u), j = q - i * (S + 1u);
+        unsigned a, b;
+        if (j < S - i) {
+            a = i;
+            b = i + j;
+        } else {
+            a = S - 1u - i;
+            b = a + (j - (S - i));
+        }
+        return (a << (m - h)) | (mid << h) | (__brev(b) >> (32u - h));
+    }
+};
+
 // Persistent form: a workgroup walks the tile pairs (t <= rev t) grid-stride, with the NEXT pair's rows already in
 // flight (registers) while the current pair goes through LDS -- the loads of pair i+1 overlap the transposing
 // reads and the stores of pair i, and the half of the index space that would exit at once never becomes a
@@ -72,19 +101,13 @@ __global__ void __launch_bounds__(NTH) bitrev_persistent_kernel(U *data, unsigne
     const unsigned tile_bits = log_n - 2 * BETA;
     const unsigned ustride_log = log_n - BETA;
     auto rev_t = [&](unsigned t) { return tile_bits ? (__brev(t) >> (32u - tile_bits)) : 0u; };
-    // next work item at or after `w` whose tile is the smaller of its pair
-    auto advance = [&](unsigned long long w) {
-        while (w < total) {
-            const unsigned t = (unsigned)(w % tiles);
-            if (t <= rev_t(t)) break;
-            w += gridDim.x;
-        }
-        return w;
-    };
+    const PairEnum pe(tile_bits);  // `total` = arrays x pe.pairs: work item w = pair w % pe.pairs of array w / pe.pairs
+    (void)tiles;
+    auto advance = [&](unsigned long long w) { return w; };
     U ra[PER], rb[PER];
     auto load = [&](unsigned long long w) {
-        const unsigned t = (unsigned)(w % tiles), tr = rev_t(t);
-        U *x = data + (size_t)(w / tiles) * dist;
+        const unsigned t = pe.tile((unsigned)(w % pe.pairs)), tr = rev_t(t);
+        U *x = data + (size_t)(w / pe.pairs) * dist;
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             const int idx = i * NTH + threadIdx.x;
@@ -96,8 +119,8 @@ __global__ void __launch_bounds__(NTH) bitrev_persistent_kernel(U *data, unsigne
     unsigned long long w = advance(blockIdx.x);
     if (w < total) load(w);
     while (w < total) {
-        const unsigned t = (unsigned)(w % tiles), tr = rev_t(t);
-        U *x = data + (size_t)(w / tiles) * dist;
+        const unsigned t = pe.tile((unsigned)(w % pe.pairs)), tr = rev_t(t);
+        U *x = data + (size_t)(w / pe.pairs) * dist;
         __syncthreads();  // the previous pair's readers are done
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
@@ -150,28 +173,16 @@ __global__ void __launch_bounds__(NTH) bitrev_persistent2_kernel(U *data, unsign
     const unsigned tile_bits = log_n - 2 * BETA;
     const unsigned ustride_log = log_n - BETA;
     auto rev_t = [&](unsigned t) { return tile_bits ? (__brev(t) >> (32u - tile_bits)) : 0u; };
-    auto tile_of = [&](unsigned wl) {  // position in the work order -> tile
-        if (!SPREAD) return wl;
-        unsigned t = 0;
-        for (unsigned i = 0; i < tile_bits; ++i) {
-            const unsigned bit = (wl >> i) & 1u;
-            const unsigned pos = (i & 1u) ? tile_bits - 1u - (i >> 1) : (i >> 1);
-            t |= bit << pos;
-        }
-        return t;
-    };
-    auto advance = [&](unsigned long long w) {  // next work item at or after `w` whose tile is the smaller of its pair
-        while (w < total) {
-            const unsigned t = tile_of((unsigned)(w % tiles));
-            if (t <= rev_t(t)) break;
-            w += gridDim.x;
-        }
-        return w;
-    };
+    // (round 4: the pairs are enumerated, PairEnum above; the SPREAD order of round 2 -- which "bought nothing" by its own
+    // measurement and left half of the workgroups without a single pair -- is gone, the template flag is kept for the name)
+    const PairEnum pe(tile_bits);
+    (void)tiles;
+    auto tile_of = [&](unsigned p) { return pe.tile(p); };
+    auto advance = [&](unsigned long long w) { return w; };
     V2 ra[PER], rb[PER];
     auto load = [&](unsigned long long w) {
-        const unsigned t = tile_of((unsigned)(w % tiles)), tr = rev_t(t);
-        const U *x = data + (size_t)(w / tiles) * dist;
+        const unsigned t = tile_of((unsigned)(w % pe.pairs)), tr = rev_t(t);
+        const U *x = data + (size_t)(w / pe.pairs) * dist;
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             const int idx = i * NTH + threadIdx.x;
@@ -183,8 +194,8 @@ __global__ void __launch_bounds__(NTH) bitrev_persistent2_kernel(U *data, unsign
     unsigned long long w = advance(blockIdx.x);
     if (w < total) load(w);
     while (w < total) {
-        const unsigned t = tile_of((unsigned)(w % tiles)), tr = rev_t(t);
-        U *x = data + (size_t)(w / tiles) * dist;
+        const unsigned t = tile_of((unsigned)(w % pe.pairs)), tr = rev_t(t);
+        U *x = data + (size_t)(w / pe.pairs) * dist;
         __syncthreads();  // the previous pair's readers are done
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
@@ -238,18 +249,13 @@ __global__ void __launch_bounds__(NTH) bitrev_persistent3_kernel(U *data, unsign
     const unsigned tile_bits = log_n - 2 * BETA;
     const unsigned ustride_log = log_n - BETA;
     auto rev_t = [&](unsigned t) { return tile_bits ? (__brev(t) >> (32u - tile_bits)) : 0u; };
-    auto advance = [&](unsigned long long w) {  // next work item at or after `w` whose tile is the smaller of its pair
-        while (w < total) {
-            const unsigned t = (unsigned)(w % tiles);
-            if (t <= rev_t(t)) break;
-            w += gridDim.x;
-        }
-        return w;
-    };
+    const PairEnum pe(tile_bits);  // the pairs enumerated: see PairEnum
+    (void)tiles;
+    auto advance = [&](unsigned long long w) { return w; };
     V2 ra[PER], rb[PER];
     auto load = [&](unsigned long long w) {
-        const unsigned t = (unsigned)(w % tiles), tr = rev_t(t);
-        const U *x = data + (size_t)(w / tiles) * dist;
+        const unsigned t = pe.tile((unsigned)(w % pe.pairs)), tr = rev_t(t);
+        const U *x = data + (size_t)(w / pe.pairs) * dist;
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             const int idx = i * NTH + threadIdx.x;
@@ -289,8 +295,8 @@ __global__ void __launch_bounds__(NTH) bitrev_persistent3_kernel(U *data, unsign
     unsigned long long w = advance(blockIdx.x);
     if (w < total) load(w);
     while (w < total) {
-        const unsigned t = (unsigned)(w % tiles), tr = rev_t(t);
-        U *x = data + (size_t)(w / tiles) * dist;
+        const unsigned t = pe.tile((unsigned)(w % pe.pairs)), tr = rev_t(t);
+        U *x = data + (size_t)(w / pe.pairs) * dist;
         const unsigned long long wn = advance(w + gridDim.x);
         __syncthreads();  // the previous pair's readers are done
         if (t != tr) {
@@ -311,7 +317,7 @@ template <typename U, int BETA, int NTH>
 static hipError_t launch_bitrev_persistent3(U *data, unsigned log_n, size_t batch, size_t dist, hipStream_t stream) {
     constexpr int B = 1 << BETA;
     const unsigned tiles = 1u << (log_n - 2 * BETA);
-    const unsigned long long total = (unsigned long long)tiles * batch;
+    const unsigned long long total = PairEnum(log_n - 2 * BETA).pairs * batch;  // work items: the enumerated tile pairs
     unsigned long long grid = 256ull;  // one workgroup per CU: the LDS buffer is 129 KiB
     if (grid > total) grid = total;
     const size_t lds = sizeof(U) * B * (B + 1);
@@ -326,7 +332,7 @@ template <typename U, int BETA, int NTH, bool SPREAD>
 static hipError_t launch_bitrev_persistent2(U *data, unsigned log_n, size_t batch, size_t dist, hipStream_t stream,
                                             unsigned wg_per_cu) {
     const unsigned tiles = 1u << (log_n - 2 * BETA);
-    const unsigned long long total = (unsigned long long)tiles * batch;
+    const unsigned long long total = PairEnum(log_n - 2 * BETA).pairs * batch;  // work items: the enumerated tile pairs
     unsigned long long grid = 256ull * wg_per_cu;
     if (grid > total) grid = total;
     hipLaunchKernelGGL((bitrev_persistent2_kernel<U, BETA, NTH, SPREAD>), dim3((unsigned)grid), dim3(NTH), 0, stream, data,
@@ -338,7 +344,7 @@ template <typename U, int BETA, int NTH>
 static hipError_t launch_bitrev_persistent(U *data, unsigned log_n, size_t batch, size_t dist, hipStream_t stream,
                                            unsigned wg_per_cu) {
     const unsigned tiles = 1u << (log_n - 2 * BETA);
-    const unsigned long long total = (unsigned long long)tiles * batch;
+    const unsigned long long total = PairEnum(log_n - 2 * BETA).pairs * batch;  // work items: the enumerated tile pairs
     unsigned long long grid = 256ull * wg_per_cu;
     if (grid > total) grid = total;
     hipLaunchKernelGGL((bitrev_persistent_kernel<U, BETA, NTH>), dim3((unsigned)grid), dim3(NTH), 0, stream, data, log_n,
@@ -380,18 +386,30 @@ static hipError_t launch_bitrev_u(U *data, unsigned log_n, size_t batch, size_t 
 //                        (2^26: 3.9 vs 3.6 TB/s)
 //   f64, N >= 2^27       128 x 128 tiles held in registers (1 KiB rows): 2^27 3.4 -> 4.1 TB/s, 2^28 3.9 -> 4.0, 2^30 3.8 -> 4.0;
 //                        below that there are too few tiles per CU for its one workgroup per CU (2^26: 3.7 vs 3.9)
+#ifndef PHAST_BITREV_P3_MIN_LOG   // tuning (tools/ab.sh with build(extra=...)): thresholds of the generations
+#define PHAST_BITREV_P3_MIN_LOG 27
+#endif
+#ifndef PHAST_BITREV_P2_MIN_LOG
+#define PHAST_BITREV_P2_MIN_LOG 25
+#endif
+#ifndef PHAST_BITREV_F32_P2_MIN_LOG
+#define PHAST_BITREV_F32_P2_MIN_LOG 99
+#endif
 template <> hipError_t launch_bitrev<double>(double *data, unsigned log_n, size_t batch, size_t dist, hipStream_t s) {
     auto *p = reinterpret_cast<unsigned long long *>(data);
     if (log_n < 12) return launch_bitrev_u<unsigned long long, 5, 256>(p, log_n, batch, dist, s);
     const bool even = (dist & 1) == 0 && (reinterpret_cast<size_t>(data) & 15) == 0;  // 16-byte accesses need it
-    if (even && log_n >= 27) return launch_bitrev_persistent3<unsigned long long, 7, 1024>(p, log_n, batch, dist, s);
-    if (even && (((size_t)batch << log_n) >= ((size_t)1 << 25)))
+    if (even && log_n >= PHAST_BITREV_P3_MIN_LOG) return launch_bitrev_persistent3<unsigned long long, 7, 1024>(p, log_n, batch, dist, s);
+    if (even && (((size_t)batch << log_n) >= ((size_t)1 << PHAST_BITREV_P2_MIN_LOG)))
         return launch_bitrev_persistent2<unsigned long long, 6, 256, true>(p, log_n, batch, dist, s, 4);
     return launch_bitrev_persistent<unsigned long long, 6, 512>(p, log_n, batch, dist, s, 4);
 }
 template <> hipError_t launch_bitrev<float>(float *data, unsigned log_n, size_t batch, size_t dist, hipStream_t s) {
     auto *p = reinterpret_cast<unsigned *>(data);
     if (log_n < 12) return launch_bitrev_u<unsigned, 6, 512>(p, log_n, batch, dist, s);
+    const bool even = (dist & 3) == 0 && (reinterpret_cast<size_t>(data) & 15) == 0;
+    if (even && (((size_t)batch << log_n) >= ((size_t)1 << PHAST_BITREV_F32_P2_MIN_LOG)))
+        return launch_bitrev_persistent2<unsigned, 6, 256, true>(p, log_n, batch, dist, s, 4);
     return launch_bitrev_persistent<unsigned, 6, 512>(p, log_n, batch, dist, s, 4);
 }
 
