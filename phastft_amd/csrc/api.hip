@@ -351,6 +351,8 @@ struct Workspace {
     }
 };
 
+// Device memory for a scratch: PHAST_SCRATCH_ALLOC=contiguous asks the driver for physically contiguous memory
+// (hipExtMallocWithFlags + hipDeviceMallocContiguous) -- experiment, tools/placement_probe.py
 template <typename T> struct Planner {
     size_t n = 0;
     unsigned log_n = 0;
@@ -623,12 +625,12 @@ template <typename T> struct Planner {
     // more than one transform (where there is one), else the latency plan
     const std::vector<PassDesc> &plan_for(size_t batch) const {
         if (passes_lat.empty() || passes.empty()) return passes;
+        if (batch <= 2 && !passes_one.empty()) return passes_one;  // ranked for one transform, whatever its size (plan.hpp: single_plan)
         unsigned tl = 0;
         for (const PassDesc &p : passes) tl = std::max(tl, p.lr + p.lc);
         // 4-byte elements: the same tile holds half the bytes, and the measured crossover sits one octave higher (one f32
         // transform of 2^24 points: 149.7 us on the latency tiles, 180.0 on the throughput tiles)
         if (batch * n >= throughput_work(tl) * (sizeof(T) == 4 && tl < 15 ? 2 : 1)) return passes;
-        if (batch <= 2 && !passes_one.empty()) return passes_one;
         if (batch > 1 && !passes_mid.empty()) return passes_mid;
         return passes_lat;
     }

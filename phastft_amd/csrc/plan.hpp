@@ -215,36 +215,47 @@ inline void heuristic_plan(unsigned L, bool latency, std::vector<unsigned> &lrs,
     }
 }
 
-// The plan for ONE transform (and two): round 2.  Measured with one transform in flight only -- with four or more the
-// older latency / mid plans win again (2^19 x 8: 48 GSamples/s on these against 69 on the two-pass latency plan,
-// profiles/r02_sweep_batch_wave_quad.log), so Planner::plan_for uses it for batch <= 2.  Returns false where the latency
-// plan already is the right one.
+// The plan for ONE transform (and two).  Round 2 ranked candidate plans by timing one buffer in place; from 2^21 to 2^24
+// points that buffer sits in the 256 MiB Infinity Cache, which a caller's transform of fresh data never does.  Round 4
+// ranked EVERY plan that exists as kernels -- factorisation x tile size PER PASS x points per thread, wave / quad tiles
+// included -- by the time of one transform over a cold ring of distinct buffers (tools/sweep_single_cold.py,
+// profiles/r04_sweep_single_cold_{f64,f32}.log) and kept what an interleaved re-measurement confirmed
+// (tools/confirm_single.py with three scratch allocations per plan, profiles/r04_confirm_single.log; two runs of
+// tools/size_ladder.py per library, profiles/r04_single_plans_ladder_ab.log).  What holds: a 256-row first pass on
+// 8192-point tiles (32 columns = 256-byte row pieces in f64), a NARROW middle pass on 4096-point tiles (more workgroups in
+// flight while it runs in place in the scratch) and a 128-row last pass beat the balanced splits on one tile size:
+//   f64  2^14 13.7 -> 12.2 us, 2^15 14.3 -> 11.2, 2^21 45.6 -> 42.5, 2^22 89 -> 79, 2^23 175 -> 159, 2^24 351 -> 319,
+//        2^25 700 -> 658, 2^27 2700 -> 2560, 2^28 5630 -> 5450       (2^16 .. 2^20 and 2^26: the old choice stands)
+//   f32  2^19 19.6 -> 17.2, 2^25 362 -> 353                        (2^24, 2^26 .. 2^28: within the noise, not adopted)
+// From 2^25 points on a single sweep ranks the luck of each planner's scratch allocation more than the plan (+-5 %,
+// profiles/r04_placement_probe.log) -- the sweep's own gains of 6 .. 11 % at f64 2^26 and f32 2^26 / 2^28 did not survive.
+// Measured with one transform in flight -- with four or more of 2^19 / 2^20 points the older latency / mid plans win again
+// (2^19 x 8: 48 GSamples/s on the wave plan against 69 on the two-pass latency plan, profiles/r02_sweep_batch_wave_quad.log),
+// so Planner::plan_for uses it for batch <= 2.  Returns false where the latency plan already is the right one.
 template <typename T>
 inline bool single_plan(unsigned L, std::vector<unsigned> &lrs, std::vector<unsigned> &tls, unsigned &lp) {
-    const bool f64 = sizeof(T) == 8;
-    if (f64 && L >= 19 && L <= 23) {
-        // one f64 transform of 2^19..2^23 points as three passes built from WAVE tiles (64 x 16, one wave, cross-lane
-        // swaps: wave_fft.hpp) and the four-wave 256 x 16 kernel (quad_fft.hpp), generic LDS tiles for the 128-row passes
-        // and 256-row first passes (profiles/r02_sweep_wave_quad_single.log):
-        //   2^19 22.9 us (two 1024/512-row passes: 27.4), 2^20 26.5 (27.4 .. 29.7), 2^21 42.3 (43.5), 2^22 82.1 (98.7),
-        //   2^23 182.7 (188.4)
-        static const unsigned plans[5][7] = {
-            {6, 7, 6, 10, 11, 10, 3}, {6, 8, 6, 10, 12, 10, 3}, {8, 7, 6, 12, 12, 10, 3}, {8, 8, 6, 13, 12, 10, 4}, {8, 7, 8, 12, 12, 12, 3}};
-        const unsigned *p = plans[L - 19];
-        lrs = {p[0], p[1], p[2]};
-        tls = {p[3], p[4], p[5]};
-        lp = p[6] | kWaveTiles;
-        return true;
-    }
-    if (!f64 && (L == 22 || L == 23)) {
-        // one f32 transform (profiles/r02_sweep_f32_single.log): 2^22 43.7 us with 128x64 / 256x32 / 128x64 tiles at
-        // 16 points per thread (54.0 with the 4096-point tiles), 2^23 80.6 (85.3); 2^24 runs the 4096-point latency tiles
-        // instead of the throughput plan (149.7 vs 180.0 us, see plan_for)
-        lrs = L == 22 ? std::vector<unsigned>{7, 8, 7} : std::vector<unsigned>{8, 8, 7};
-        tls.assign(1, L == 22 ? 13 : 12);
-        lp = 4;
-        return true;
-    }
+    struct E {
+        unsigned L, a, b, c, ta, tb, tc, lp;  // c = 0: two passes
+    };
+    constexpr unsigned W = kWaveTiles;  // 64 x 16 wave tiles (wave_fft.hpp) and the four-wave 256 x 16 pass (quad_fft.hpp)
+    static const E f64[] = {{14, 6, 8, 0, 10, 12, 0, 4 | W},  {15, 7, 8, 0, 10, 12, 0, 3 | W},  {19, 6, 7, 6, 10, 11, 10, 3 | W}, {20, 6, 8, 6, 10, 12, 10, 3 | W},
+                            {21, 6, 8, 7, 10, 12, 12, 3 | W}, {22, 8, 7, 7, 13, 12, 13, 4},     {23, 7, 9, 7, 13, 12, 13, 4},     {24, 8, 9, 7, 13, 12, 13, 4},
+                            {25, 8, 9, 8, 12, 12, 14, 4},     {27, 8, 10, 9, 13, 14, 14, 5},    {28, 9, 9, 10, 14, 14, 14, 5}};
+    static const E f32[] = {{19, 6, 7, 6, 12, 12, 12, 3}, {22, 7, 8, 7, 13, 13, 13, 4}, {23, 8, 8, 7, 12, 12, 12, 4}, {25, 8, 9, 8, 14, 13, 14, 4}};
+    const E *tab = sizeof(T) == 8 ? f64 : f32;
+    const size_t cnt = (sizeof(T) == 8 ? sizeof f64 : sizeof f32) / sizeof(E);
+    for (size_t i = 0; i < cnt; ++i)
+        if (tab[i].L == L) {
+            const E &e = tab[i];
+            lrs = {e.a, e.b};
+            tls = {e.ta, e.tb};
+            if (e.c) {
+                lrs.push_back(e.c);
+                tls.push_back(e.tc);
+            }
+            lp = e.lp;
+            return true;
+        }
     return false;
 }
 
@@ -263,21 +274,31 @@ inline bool single_plan(unsigned L, std::vector<unsigned> &lrs, std::vector<unsi
 template <typename T>
 inline bool real_plan(unsigned L, bool c2r, std::vector<unsigned> &lrs, std::vector<unsigned> &tls, unsigned &lp) {
     struct E {
-        unsigned L, a, b, c, ta, tb, tc, lp;
+        unsigned L, a, b, c, ta, tb, tc, lp;  // c = 0: two passes
     };
-    static const E r2c32[] = {{24, 8, 9, 7, 12, 13, 12, 4}, {25, 8, 9, 8, 13, 13, 13, 4}, {26, 9, 9, 8, 13, 13, 13, 4}, {27, 10, 9, 8, 13, 13, 13, 4}};
+    constexpr unsigned W = kWaveTiles;
+    // (r2c32 2^19 and c2r64 2^21: the C2C single_plan of that size has no fused form of the pass the real transform needs --
+    //  a third pass in front of the untangle sweep, a wave tile as the first pass of C2R -- these keep the plans they had:
+    //  r2c_fft_f32 2^20 20.6 us against 21.6, c2r_fft_f64 2^22 47.4 against 51.8, profiles/r04_single_plans_ladder_ab.log)
+    static const E r2c32[] = {{19, 10, 9, 0, 12, 12, 0, 3},    {24, 8, 9, 7, 12, 13, 12, 4}, {25, 8, 9, 8, 13, 13, 13, 4},
+                              {26, 9, 9, 8, 13, 13, 13, 4},    {27, 10, 9, 8, 13, 13, 13, 4}};
     static const E r2c64[] = {{22, 8, 7, 7, 13, 13, 13, 4}, {23, 9, 8, 6, 12, 12, 12, 3}, {24, 9, 9, 6, 12, 13, 12, 4}, {25, 9, 9, 7, 12, 13, 12, 4},
                               {26, 9, 9, 8, 13, 13, 13, 4}, {27, 9, 10, 8, 13, 13, 13, 4}};
     static const E c2r32[] = {{22, 8, 7, 7, 13, 12, 12, 4}, {24, 8, 8, 8, 13, 13, 13, 4}, {25, 8, 9, 8, 13, 13, 13, 4}};
-    static const E c2r64[] = {{22, 8, 7, 7, 12, 13, 13, 4}, {23, 8, 8, 7, 12, 12, 13, 4}, {24, 8, 8, 8, 12, 12, 12, 4}, {25, 8, 9, 8, 13, 13, 13, 4},
-                              {26, 8, 9, 9, 13, 13, 12, 4}};
+    static const E c2r64[] = {{21, 8, 7, 6, 12, 12, 10, 3 | W}, {22, 8, 7, 7, 12, 13, 13, 4}, {23, 8, 8, 7, 12, 12, 13, 4}, {24, 8, 8, 8, 12, 12, 12, 4},
+                              {25, 8, 9, 8, 13, 13, 13, 4},     {26, 8, 9, 9, 13, 13, 12, 4}};
     const E *tab = sizeof(T) == 4 ? (c2r ? c2r32 : r2c32) : (c2r ? c2r64 : r2c64);
     const size_t cnt = sizeof(T) == 4 ? (c2r ? sizeof c2r32 : sizeof r2c32) / sizeof(E) : (c2r ? sizeof c2r64 : sizeof r2c64) / sizeof(E);
     for (size_t i = 0; i < cnt; ++i)
         if (tab[i].L == L) {
-            lrs = {tab[i].a, tab[i].b, tab[i].c};
-            tls = {tab[i].ta, tab[i].tb, tab[i].tc};
-            lp = tab[i].lp;
+            const E &e = tab[i];
+            lrs = {e.a, e.b};
+            tls = {e.ta, e.tb};
+            if (e.c) {
+                lrs.push_back(e.c);
+                tls.push_back(e.tc);
+            }
+            lp = e.lp;
             return true;
         }
     return false;

@@ -36,7 +36,9 @@ struct Rng {
 
 int main() {
     const int T = 8, ITERS = 160, K = 4;  // K distinct inputs per planner
-    const size_t n_a = 1 << 15, n_b = 1 << 17, n_r = 1 << 16, h1 = n_r / 2 + 1;
+    // (sizes whose plan does not depend on the batch: 2^14, 2^15 and 2^19 ... run ONE transform on a plan of its own,
+    //  plan.hpp: single_plan -- another factorisation, other last bits than the same transform inside a batch of six)
+    const size_t n_a = 1 << 16, n_b = 1 << 17, n_r = 1 << 16, h1 = n_r / 2 + 1;
     phast_planner_dit64 *pa = nullptr, *pb = nullptr;
     phast_planner_r2c32 *pr = nullptr;
     CHECK(phast_planner_dit64_new(n_a, &pa));

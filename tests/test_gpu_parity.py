@@ -750,8 +750,12 @@ def test_wave_tiles_all_passes_batched_inverse_and_interleaved(gpu, oracle):
     oracle.fft_64_dit(r, m, oracle.FORWARD)
     h = d.cpu().numpy()
     assert rel_l2(h.real.copy(), h.imag.copy(), r, m) <= F64_REL
-    # the default latency plans of 2^18 and 2^20 ARE wave-tile plans
-    for k in (19, 20, 21, 22, 23):
+    # the plans for ONE transform of 2^14, 2^15 and 2^19 .. 2^21 points ARE wave- / quad-tile plans (round 4: from 2^22 on the
+    # cold-ring sweep put generic tiles back, plan.hpp: single_plan)
+    for k in (14, 15, 19, 20, 21):
         lat = gpu.PlannerDit64(1 << k).describe().split("single=")[1]
         assert " w16 " in lat or " q16 " in lat, (k, lat)
+    for k in (22, 23, 24, 25, 28):
+        lat = gpu.PlannerDit64(1 << k).describe().split("single=")[1]
+        assert " w16 " not in lat and " q16 " not in lat and lat.startswith("3p["), (k, lat)
     assert " q16 " in gpu.PlannerDit64(1 << 20).describe().split("single=")[1]

@@ -362,9 +362,10 @@ def test_strided_batch_with_fused_input_twiddle(gpu, oracle, k, s, total_log, co
         assert rel_l2(g_re[:, c], g_im[:, c], r, m) <= tol, (k, s, c)
 
 
-@pytest.mark.parametrize("k", [21, 22, 23, 24])
+@pytest.mark.parametrize("k", [15, 16, 20, 21, 22])
 def test_real_transforms_f64_through_wave_and_quad_plans(gpu, oracle, k):
-    """One f64 real transform whose inner N/2-point complex transform runs a wave-/quad-tile latency plan (2^20 … 2^23):
+    """One f64 real transform whose inner N/2-point complex transform runs a wave-/quad-tile plan (2^14, 2^15, 2^19 … 2^21;
+    round 4 moved 2^22 and 2^23 to generic tiles, plan.hpp: single_plan):
     the first pass reads the real signal as (even, odd) pairs (wave tiles or generic), the last pass of C2R stores (im, re)
     pairs scaled by 1/(N/2) (wave tiles / the four-wave kernel).  R2C against an independent rfft (1e-13) and the oracle
     (1e-9: its twiddle drift), C2R against the oracle and the independent model."""
