@@ -733,15 +733,33 @@ template <typename T> struct Planner {
         return PHAST_OK;
     }
 
-    int init(size_t num_points) {
+    // N = 2^kSmallMaxLog (8192 points) only: the same length as a MULTI-pass planner, for ONE transform (or two).  The one-pass
+    // kernel keeps a whole transform in one workgroup -- right for batches (one sweep over the data), but a single 8192-point
+    // transform is then ONE workgroup's chain of six LDS round trips: 16.2 us (f64) where the two-pass wave / quad plan of
+    // 2^14 points takes 12.1 (profiles/r04_size_ladder.log).  PHAST_SMALL_TWIN=0: tools (A/B).
+    std::unique_ptr<Planner<T>> twin;
+    static bool twin_enabled() {
+        static const bool v = [] {
+            const char *e = std::getenv("PHAST_SMALL_TWIN");
+            return !(e && *e == '0');
+        }();
+        return v;
+    }
+
+    int init(size_t num_points, bool force_multi = false, bool with_twin = true) {
         n = num_points;
         log_n = ilog2(n);
         int rc = ensure_device(&device);
         if (rc) return rc;
-        if (log_n <= kSmallMaxLog) {
+        if (log_n <= kSmallMaxLog && !(force_multi && log_n == kSmallMaxLog)) {
             std::vector<cx_t<T>> h = host_twr<T>((unsigned)n);  // W_N^j two-level table of the one-pass kernel
             table_bytes = h.size() * sizeof(cx_t<T>);
-            return upload<T>(h, &d_small_tw);
+            rc = upload<T>(h, &d_small_tw);
+            if (rc == PHAST_OK && with_twin && log_n == kSmallMaxLog && twin_enabled()) {
+                twin.reset(new (std::nothrow) Planner<T>());
+                if (twin && twin->init(n, true) != PHAST_OK) twin.reset();  // an optimisation: without it the one-pass kernel serves
+            }
+            return rc;
         }
         return default_plans();
     }
@@ -905,6 +923,7 @@ template <typename T> struct Planner {
         std::lock_guard<std::mutex> lk(mu);
         size_t b = table_bytes + old_table_bytes;
         for (auto &w : pool) b += w->device_bytes();
+        if (twin) b += twin->device_bytes();
         return b;
     }
 
@@ -1055,10 +1074,6 @@ template <typename T> struct Planner {
 
     std::string describe() const {
         char buf[512];
-        if (passes.empty()) {
-            std::snprintf(buf, sizeof buf, "n=2^%u one pass (whole transforms on chip)", log_n);
-            return buf;
-        }
         std::string s = "n=2^" + std::to_string(log_n);
         auto add = [&](const char *tag, const std::vector<PassDesc> &v) {
             s += std::string(" ") + tag + "=" + std::to_string(v.size()) + "p";
@@ -1068,6 +1083,11 @@ template <typename T> struct Planner {
                 s += buf;
             }
         };
+        if (passes.empty()) {
+            s += " one pass (whole transforms on chip)";
+            if (twin) add("single", twin->plan_for(1));
+            return s;
+        }
         add("throughput", passes);
         if (!passes_mid.empty()) add("mid", passes_mid);
         if (!passes_lat.empty()) add("latency", passes_lat);
@@ -1131,6 +1151,8 @@ template <typename T> struct Planner {
              size_t out_dist, unsigned out_mode, size_t batch, double scale, hipStream_t stream,
              PassTimer *timer = nullptr) const {
         if (batch == 0) return PHAST_OK;
+        if (twin && batch <= 2)  // one 8192-point transform: two passes over the whole chip instead of one workgroup
+            return twin->exec(in_re, in_im, in_dist, in_mode, out_re, out_im, out_dist, out_mode, batch, scale, stream, timer);
         PHAST_ON_DEVICE(device);
         Lease L;
         if (!passes.empty()) {  // (the one-pass kernel keeps whole transforms on chip: nothing to check out)
@@ -1276,16 +1298,22 @@ template <typename T> struct PlannerR2c {
         DeviceGuard on(dit.device);
         if (d_tw3) hipFree(d_tw3);
     }
-    int init(size_t n_) {
+    std::unique_ptr<PlannerR2c<T>> twin;  // N/2 = 8192 only: the multi-pass form for ONE real transform (Planner::twin)
+    int init(size_t n_, bool force_multi = false) {
         n = n_;
-        int rc = dit.init(n / 2);
+        int rc = dit.init(n / 2, force_multi, false);
         if (rc) return rc;
         if (!dit.passes.empty()) {
             rc = dit.make_c2r_plans();
             if (rc) return rc;
         }
         tw_bits = tw3_bits_for(ilog2(n));
-        return upload<T>(host_tw3<T>(ilog2(n), tw_bits), &d_tw3);
+        rc = upload<T>(host_tw3<T>(ilog2(n), tw_bits), &d_tw3);
+        if (rc == PHAST_OK && !force_multi && dit.log_n == kSmallMaxLog && Planner<T>::twin_enabled()) {
+            twin.reset(new (std::nothrow) PlannerR2c<T>());
+            if (twin && twin->init(n, true) != PHAST_OK) twin.reset();
+        }
+        return rc;
     }
     // unfused C2R: the preprocess workspace for `batch` transforms in the leased workspace; an outgrown one is retired
     // (freed once idle, Workspace::reap), growth is geometric
@@ -1335,6 +1363,7 @@ template <typename T> struct PlannerR2c {
     int r2c(const T *d_in, T *d_ore, T *d_oim, size_t batch, size_t in_dist, size_t out_dist, hipStream_t s,
             PassTimer *timer = nullptr) const {
         if (in_dist & 1) return PHAST_ERR_INVALID_ARG;  // the input is read as (even, odd) pairs
+        if (twin && batch <= 2) return twin->r2c(d_in, d_ore, d_oim, batch, in_dist, out_dist, s, timer);
         PHAST_ON_DEVICE(dit.device);
         Lease L;
         if (!dit.passes.empty()) {
@@ -1378,6 +1407,7 @@ template <typename T> struct PlannerR2c {
     int c2r(const T *d_ire, const T *d_iim, T *d_out, size_t batch, size_t in_dist, size_t out_dist,
             hipStream_t s, PassTimer *timer = nullptr) const {
         if (out_dist & 1) return PHAST_ERR_INVALID_ARG;
+        if (twin && batch <= 2) return twin->c2r(d_ire, d_iim, d_out, batch, in_dist, out_dist, s, timer);
         PHAST_ON_DEVICE(dit.device);
         Lease L;
         if (!dit.passes.empty()) {
@@ -1489,6 +1519,7 @@ static int fft_dev_many(T *const *d_re, T *const *d_im, size_t count, size_t n, 
     for (size_t i = 0; i < count; ++i)
         if (!d_re[i] || !d_im[i]) return PHAST_ERR_INVALID_ARG;
     if (count == 0) return PHAST_OK;
+    if (pl->twin) pl = pl->twin.get();  // 8192 points: the plan of a single-transform call (Planner::twin)
     PHAST_ON_DEVICE(pl->device);
     typename Planner<T>::Lease L;  // one workspace for the whole list: the transforms follow each other on the stream
     if (!pl->passes.empty()) {
@@ -1703,6 +1734,7 @@ static int fft_host(T *re, size_t re_len, T *im, size_t im_len, int direction, c
     if (!is_pow2(re_len)) return PHAST_ERR_NOT_POW2;          // dit.rs:285
     if (ilog2(re_len) != pl->log_n) return PHAST_ERR_PLANNER_SIZE;  // dit.rs:289
     const size_t n = re_len, bytes = n * sizeof(T), total = 2 * bytes;
+    if (pl->twin) pl = pl->twin.get();  // ONE transform of 8192 points: the plan (and the bits) of the _dev call
     PHAST_ON_DEVICE(pl->device);
     typename Planner<T>::Lease L;
     int rc = pl->check_out(L, nullptr, 1);
@@ -1746,6 +1778,7 @@ template <typename T> static int fft_interleaved_host(T *signal, size_t n, int d
     if (direction != PHAST_FORWARD && direction != PHAST_REVERSE) return PHAST_ERR_INVALID_ARG;
     if (!is_pow2(n)) return PHAST_ERR_NOT_POW2;
     if (ilog2(n) != pl->log_n) return PHAST_ERR_PLANNER_SIZE;
+    if (pl->twin) pl = pl->twin.get();
     PHAST_ON_DEVICE(pl->device);
     typename Planner<T>::Lease L;
     int rc = pl->check_out(L, nullptr, 1);
@@ -1864,6 +1897,7 @@ static int r2c_host(const T *in, size_t in_len, T *ore, size_t ore_len, T *oim, 
     if (in_len != n) return PHAST_ERR_R2C_INPUT_LEN;
     if (ore_len != half + 1) return PHAST_ERR_R2C_OUT_RE_LEN;
     if (oim_len != half + 1) return PHAST_ERR_R2C_OUT_IM_LEN;
+    if (pl->twin) pl = pl->twin.get();
     PHAST_ON_DEVICE(pl->dit.device);
     typename Planner<T>::Lease L;
     int rc = pl->dit.check_out(L, nullptr, 1);
@@ -1905,6 +1939,7 @@ static int c2r_host(const T *ire, size_t ire_len, const T *iim, size_t iim_len, 
     if (iim_len != half + 1) return PHAST_ERR_C2R_IN_IM_LEN;
     if (check_scratch && sre_len != half) return PHAST_ERR_C2R_SCRATCH_RE;
     if (check_scratch && sim_len != half) return PHAST_ERR_C2R_SCRATCH_IM;
+    if (pl->twin) pl = pl->twin.get();
     PHAST_ON_DEVICE(pl->dit.device);
     typename Planner<T>::Lease L;
     int rc = pl->dit.check_out(L, nullptr, 1);
@@ -2167,7 +2202,11 @@ int phast_options_guess(size_t input_size, phast_options *out) {
         return rc;                                                                                                 \
     }                                                                                                              \
     int phast_planner_r2c##SFX##_describe(const phast_planner_r2c##SFX *p, char *buf, size_t len) {                \
-        return p ? describe_to<T>(&p->dit, buf, len) : PHAST_ERR_INVALID_ARG;                                      \
+        if (!p || !buf || !len) return PHAST_ERR_INVALID_ARG;                                                      \
+        std::string s = p->dit.describe();                                                                         \
+        if (p->twin) s += " | one transform: " + p->twin->dit.describe();                                          \
+        std::snprintf(buf, len, "%s", s.c_str());                                                                  \
+        return PHAST_OK;                                                                                           \
     }
 
 PHAST_PLANNER_API(64, double)

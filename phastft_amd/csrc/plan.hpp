@@ -177,7 +177,7 @@ inline void heuristic_plan(unsigned L, bool latency, std::vector<unsigned> &lrs,
     lrs.clear();
     tls.assign(1, 12);
     lp = 4;
-    if (L <= kSmallMaxLog) return;
+    if (L < kSmallMaxLog) return;  // (L = kSmallMaxLog: the multi-pass twin of the one-pass kernel's largest size, api.hip)
     auto split = [&](unsigned np) {
         lrs.clear();
         for (unsigned i = 0; i < np; ++i) lrs.push_back(L / np + (i < L % np ? 1 : 0));  // balanced, larger first
@@ -238,7 +238,8 @@ inline bool single_plan(unsigned L, std::vector<unsigned> &lrs, std::vector<unsi
         unsigned L, a, b, c, ta, tb, tc, lp;  // c = 0: two passes
     };
     constexpr unsigned W = kWaveTiles;  // 64 x 16 wave tiles (wave_fft.hpp) and the four-wave 256 x 16 pass (quad_fft.hpp)
-    static const E f64[] = {{14, 6, 8, 0, 10, 12, 0, 4 | W},  {15, 7, 8, 0, 10, 12, 0, 3 | W},  {19, 6, 7, 6, 10, 11, 10, 3 | W}, {20, 6, 8, 6, 10, 12, 10, 3 | W},
+    static const E f64[] = {{13, 6, 7, 0, 10, 11, 0, 3 | W},  // (8192 points: Planner::twin, api.hip)
+                            {14, 6, 8, 0, 10, 12, 0, 4 | W},  {15, 7, 8, 0, 10, 12, 0, 3 | W},  {19, 6, 7, 6, 10, 11, 10, 3 | W}, {20, 6, 8, 6, 10, 12, 10, 3 | W},
                             {21, 6, 8, 7, 10, 12, 12, 3 | W}, {22, 8, 7, 7, 13, 12, 13, 4},     {23, 7, 9, 7, 13, 12, 13, 4},     {24, 8, 9, 7, 13, 12, 13, 4},
                             {25, 8, 9, 8, 12, 12, 14, 4},     {27, 8, 10, 9, 13, 14, 14, 5},    {28, 9, 9, 10, 14, 14, 14, 5}};
     static const E f32[] = {{19, 6, 7, 6, 12, 12, 12, 3}, {22, 7, 8, 7, 13, 13, 13, 4}, {23, 8, 8, 7, 12, 12, 12, 4}, {25, 8, 9, 8, 14, 13, 14, 4}};

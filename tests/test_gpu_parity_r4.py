@@ -348,3 +348,99 @@ def test_r2c_f64_large_fused_vs_c2c_route(gpu, k):
     back = torch.empty_like(x)
     gpu.c2r_fft_f64_with_planner(ore, oim, back, pl)
     assert float((back - x).abs().max()) < 1e-10
+
+
+# ---------------------------------------------------------------- ONE transform of 8192 points: the multi-pass twin
+@pytest.mark.parametrize("dt", ["f64", "f32"])
+def test_one_transform_of_8192_points_runs_the_multi_pass_twin(gpu, oracle, dt):
+    """N = 2^13 is the largest size of the one-pass kernel (one workgroup per transform): right for batches, 16 us for ONE
+    transform.  A planner of that size keeps a multi-pass twin (`api.hip: Planner::twin`) that serves batch <= 2 -- through
+    every entry point, so that the same transform gives the same bits from host slices, device pointers and a captured graph;
+    batches keep the one-pass kernel (other factorisation: equal to rounding level).  The real transforms of 16384 points
+    (inner length 8192) follow the same rule."""
+    import torch
+
+    f64 = dt == "f64"
+    npdt, tdt = (np.float64, torch.float64) if f64 else (np.float32, torch.float32)
+    tol = 1e-13 if f64 else 1e-5   # the suites' F64_REL / F32_REL against the oracle
+    n = 1 << 13
+    pl = (gpu.PlannerDit64 if f64 else gpu.PlannerDit32)(n)
+    assert "one pass" in pl.describe() and " single=2p[" in pl.describe(), pl.describe()
+    fft = gpu.fft_64_dit_with_planner if f64 else gpu.fft_32_dit_with_planner
+    offt = oracle.fft_64_dit if f64 else oracle.fft_32_dit
+    h_re, h_im = oracle.fill(n, npdt, seed=0x813, transform_id=3)
+    w_re, w_im = h_re.copy(), h_im.copy()
+    offt(w_re, w_im, oracle.FORWARD)
+
+    def err(a, b):
+        return float(np.sqrt((np.abs(a.astype(np.float64) - w_re) ** 2 + np.abs(b.astype(np.float64) - w_im) ** 2).sum()
+                             / (w_re.astype(np.float64) ** 2 + w_im.astype(np.float64) ** 2).sum()))
+
+    # host slices, device pointers, a captured graph: one plan, one set of bits
+    a_re, a_im = h_re.copy(), h_im.copy()
+    fft(a_re, a_im, gpu.Direction.Forward, pl)
+    assert err(a_re, a_im) <= tol
+    d_re, d_im = torch.from_numpy(h_re.copy()).cuda(), torch.from_numpy(h_im.copy()).cuda()
+    fft(d_re, d_im, gpu.Direction.Forward, pl)
+    assert np.array_equal(d_re.cpu().numpy(), a_re) and np.array_equal(d_im.cpu().numpy(), a_im)
+    g_re, g_im = torch.from_numpy(h_re.copy()).cuda(), torch.from_numpy(h_im.copy()).cuda()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            fft(g_re, g_im, gpu.Direction.Forward, pl)
+    torch.cuda.current_stream().wait_stream(side)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(g_re, d_re) and torch.equal(g_im, d_im)
+    assert pl.device_bytes() > 2 * n * (8 if f64 else 4)          # the twin's scratch and tables are counted
+    # the inverse through the twin: back to the input
+    fft(d_re, d_im, gpu.Direction.Reverse, pl)
+    assert float((d_re.cpu() - torch.from_numpy(h_re)).abs().max()) <= (1e-13 if f64 else 1e-5)
+    # a batch of five keeps the one-pass kernel: the same transform to rounding level, five times the same bits
+    b_re = torch.from_numpy(np.tile(h_re, 5)).cuda()
+    b_im = torch.from_numpy(np.tile(h_im, 5)).cuda()
+    gpu.fft_dit_batched(b_re, b_im, n, gpu.Direction.Forward, pl)
+    rows_re, rows_im = b_re.cpu().numpy().reshape(5, n), b_im.cpu().numpy().reshape(5, n)
+    for b in range(5):
+        assert err(rows_re[b], rows_im[b]) <= tol
+        assert np.array_equal(rows_re[b], rows_re[0]) and np.array_equal(rows_im[b], rows_im[0])
+    # real transforms of 16384 points
+    m = 2 * n
+    rp = (gpu.PlannerR2c64 if f64 else gpu.PlannerR2c32)(m)
+    assert "one transform:" in rp.describe(), rp.describe()
+    r2c = gpu.r2c_fft_f64_with_planner if f64 else gpu.r2c_fft_f32_with_planner
+    c2r = gpu.c2r_fft_f64_with_planner if f64 else gpu.c2r_fft_f32_with_planner
+    x, _ = oracle.fill(m, npdt, seed=0x814, transform_id=5)
+    ref = np.fft.rfft(x.astype(np.float64))
+    ore, oim = np.zeros(m // 2 + 1, npdt), np.zeros(m // 2 + 1, npdt)
+    r2c(x, ore, oim, rp)                                           # host slices
+    e = np.sqrt((np.abs(ore - ref.real) ** 2 + np.abs(oim - ref.imag) ** 2).sum() / (np.abs(ref) ** 2).sum())
+    assert e <= (1e-13 if f64 else 1e-5), e
+    t_x = torch.from_numpy(x.copy()).cuda()
+    t_re, t_im = torch.zeros(m // 2 + 1, dtype=tdt, device="cuda"), torch.zeros(m // 2 + 1, dtype=tdt, device="cuda")
+    r2c(t_x, t_re, t_im, rp)                                       # device pointers: the same bits
+    assert np.array_equal(t_re.cpu().numpy(), ore) and np.array_equal(t_im.cpu().numpy(), oim)
+    back = np.zeros(m, npdt)
+    c2r(ore, oim, back, rp)
+    assert float(np.abs(back - x).max()) <= (1e-12 if f64 else 2e-5)
+    xb = torch.from_numpy(np.tile(x, 4)).cuda()                     # a batch of four: the one-pass kernel with the fused untangle
+    bre = torch.zeros(4 * (m // 2 + 1), dtype=tdt, device="cuda")
+    bim = torch.zeros_like(bre)
+    gpu.r2c_fft_batched(xb, bre, bim, rp, 4)
+    got = bre.cpu().numpy().reshape(4, -1), bim.cpu().numpy().reshape(4, -1)
+    for b in range(4):
+        e = np.sqrt((np.abs(got[0][b] - ref.real) ** 2 + np.abs(got[1][b] - ref.imag) ** 2).sum() / (np.abs(ref) ** 2).sum())
+        assert e <= (1e-13 if f64 else 1e-5), (b, e)
+
+
+def test_small_twin_switch_restores_the_one_pass_kernel(gpu):
+    """PHAST_SMALL_TWIN=0 (tools: A/B): no twin, one 8192-point transform runs in the one-pass kernel"""
+    code = ("import sys; sys.path.insert(0, %r)\nimport phastft_amd as P\n"
+            "print(P.PlannerDit64(8192).describe()); print(P.PlannerR2c32(16384).describe())" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                       env=dict(_plain_env(), PHAST_SMALL_TWIN="0"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("n=2^13")]
+    assert len(lines) == 2 and all("single" not in ln and "one transform" not in ln for ln in lines), r.stdout
