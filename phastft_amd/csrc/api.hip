@@ -366,6 +366,7 @@ template <typename T> struct Planner {
     // R2C only: the plan of ONE (or two) real transforms where plan.hpp (real_plan) has a better one than the C2C choice;
     // passes_c2r_one is C2R's (from the same table, else the reversal above)
     std::vector<PassDesc> passes_r2c;
+    bool r2c_table_fuses = false;  // passes_r2c was ranked with its fused last pass below the general threshold (plan.hpp: kFuseBelow)
     void *d_small_tw = nullptr;
     // elements per transform and plane in the scratch: n plus the padding of the intermediate layouts (plan.hpp:
     // scratch_pad_bytes); the largest over this planner's plans, fixed before the first allocation grows past it
@@ -812,8 +813,10 @@ template <typename T> struct Planner {
             std::vector<unsigned> lrs, tls;
             unsigned lp = 4;
             if (!real_plan<T>(log_n, c2r != 0, lrs, tls, lp)) continue;
-            int rc = set_plan(lrs, tls, c2r ? 5 : 7, lp);
+            const bool fuse_below = (lp & kFuseBelow) != 0;
+            int rc = set_plan(lrs, tls, c2r ? 5 : 7, lp & ~kFuseBelow);
             if (rc != PHAST_OK && rc != PHAST_ERR_INVALID_ARG) return rc;
+            if (!c2r) r2c_table_fuses = rc == PHAST_OK && fuse_below;
         }
         // 2. C2R, two-pass plans: the reversed order
         for (int k = 0; k < 2 && rev; ++k) {
@@ -1144,7 +1147,9 @@ template <typename T> struct Planner {
     }
     bool fuse_pays(size_t batch) const {
         const unsigned min_log = fuse_min_log() ? fuse_min_log() : 23u;
-        return r2c_fuse_enabled() && batch * n >= ((size_t)1 << min_log);
+        if (!r2c_fuse_enabled()) return false;
+        if (batch <= 2 && r2c_table_fuses && !passes_r2c.empty()) return true;  // a plan cut for it: 2048-point last-pass tiles
+        return batch * n >= ((size_t)1 << min_log);
     }
     // a _dev call: checks a workspace out for the enqueue
     int exec(const void *in_re, const void *in_im, size_t in_dist, unsigned in_mode, void *out_re, void *out_im,

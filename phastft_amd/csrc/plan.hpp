@@ -123,6 +123,7 @@ inline bool shape_exists(unsigned lr, unsigned lc, unsigned lp, size_t elem_byte
 }
 
 constexpr unsigned kWaveTiles = 0x10;  // flag in a plan's points-per-thread code, see make_passes
+constexpr unsigned kFuseBelow = 0x20;  // real_plan only: ranked WITH the fused R2C last pass below the general threshold (api.hip: fuse_pays)
 
 // Padding of the planner's scratch.  The intermediate arrays between the passes are the one part of the data whose layout
 // is ours: S[r][q] (two passes) / S[u][r][q] (three).  With power-of-two pitches the rows a tile reads in the next pass are
@@ -277,17 +278,26 @@ inline bool real_plan(unsigned L, bool c2r, std::vector<unsigned> &lrs, std::vec
     struct E {
         unsigned L, a, b, c, ta, tb, tc, lp;  // c = 0: two passes
     };
-    constexpr unsigned W = kWaveTiles;
+    constexpr unsigned W = kWaveTiles, F = kFuseBelow;
     // (r2c32 2^19 and c2r64 2^21: the C2C single_plan of that size has no fused form of the pass the real transform needs --
     //  a third pass in front of the untangle sweep, a wave tile as the first pass of C2R -- these keep the plans they had:
     //  r2c_fft_f32 2^20 20.6 us against 21.6, c2r_fft_f64 2^22 47.4 against 51.8, profiles/r04_single_plans_ladder_ab.log)
-    static const E r2c32[] = {{19, 10, 9, 0, 12, 12, 0, 3},    {24, 8, 9, 7, 12, 13, 12, 4}, {25, 8, 9, 8, 13, 13, 13, 4},
-                              {26, 9, 9, 8, 13, 13, 13, 4},    {27, 10, 9, 8, 13, 13, 13, 4}};
-    static const E r2c64[] = {{22, 8, 7, 7, 13, 13, 13, 4}, {23, 9, 8, 6, 12, 12, 12, 3}, {24, 9, 9, 6, 12, 13, 12, 4}, {25, 9, 9, 7, 12, 13, 12, 4},
-                              {26, 9, 9, 8, 13, 13, 13, 4}, {27, 9, 10, 8, 13, 13, 13, 4}};
-    static const E c2r32[] = {{22, 8, 7, 7, 13, 12, 12, 4}, {24, 8, 8, 8, 13, 13, 13, 4}, {25, 8, 9, 8, 13, 13, 13, 4}};
-    static const E c2r64[] = {{21, 8, 7, 6, 12, 12, 10, 3 | W}, {22, 8, 7, 7, 12, 13, 13, 4}, {23, 8, 8, 7, 12, 12, 13, 4}, {24, 8, 8, 8, 12, 12, 12, 4},
-                              {25, 8, 9, 8, 13, 13, 13, 4},     {26, 8, 9, 9, 13, 13, 12, 4}};
+    // R2C 2^20 .. 2^22 (F): the fused last pass runs half as many workgroups, each with two tiles -- on 4096-point tiles that
+    // leaves one workgroup per CU below 2^23 points and lost to the separate sweep (round 3).  On 2048-point last-pass tiles
+    // it wins from 2^20 points on (tools/sweep_real.py with SWEEP_TLS=11,12,13, profiles/r04_r2c_fuse_small_tiles.log):
+    //   r2c_fft_f32 2^21 31.5 -> 29.9 us, 2^22 42.9 -> 39.7, 2^23 65 -> 52;  r2c_fft_f64 2^22 68.6 -> 51.3, 2^23 119 -> 85
+    // C2R 2^20 / 2^21 on 2048-point tiles (more workgroups for a latency-bound transform): f64 29.4 -> 24.0, 36.2 -> 33.2,
+    //   f32 21.8 -> 20.3, 26.8 -> 23.9
+    static const E r2c32[] = {{19, 10, 9, 0, 12, 12, 0, 3},     {20, 7, 7, 6, 12, 12, 11, 3 | F}, {21, 7, 8, 6, 12, 12, 11, 3 | F},
+                              {22, 8, 8, 6, 13, 13, 12, 4 | F}, {24, 8, 9, 7, 12, 13, 12, 4},     {25, 8, 9, 8, 13, 13, 13, 4},
+                              {26, 9, 9, 8, 13, 13, 13, 4},     {27, 10, 9, 8, 13, 13, 13, 4}};
+    static const E r2c64[] = {{21, 9, 6, 6, 12, 11, 11, 3 | F}, {22, 8, 8, 6, 11, 11, 11, 3 | F}, {23, 9, 8, 6, 12, 12, 12, 3},
+                              {24, 9, 9, 6, 12, 13, 12, 4},     {25, 9, 9, 7, 12, 13, 12, 4},     {26, 9, 9, 8, 13, 13, 13, 4},
+                              {27, 9, 10, 8, 13, 13, 13, 4}};
+    static const E c2r32[] = {{19, 6, 7, 6, 11, 11, 11, 3}, {20, 6, 7, 7, 11, 12, 12, 3}, {22, 8, 7, 7, 13, 12, 12, 4},
+                              {24, 8, 8, 8, 13, 13, 13, 4}, {25, 8, 9, 8, 13, 13, 13, 4}};
+    static const E c2r64[] = {{19, 7, 6, 6, 11, 11, 11, 3},     {20, 7, 6, 7, 11, 11, 11, 3}, {21, 8, 7, 6, 12, 12, 10, 3 | W}, {22, 8, 7, 7, 12, 13, 13, 4},
+                              {23, 8, 8, 7, 12, 12, 13, 4},     {24, 8, 8, 8, 12, 12, 12, 4}, {25, 8, 9, 8, 13, 13, 13, 4},     {26, 8, 9, 9, 13, 13, 12, 4}};
     const E *tab = sizeof(T) == 4 ? (c2r ? c2r32 : r2c32) : (c2r ? c2r64 : r2c64);
     const size_t cnt = sizeof(T) == 4 ? (c2r ? sizeof c2r32 : sizeof r2c32) / sizeof(E) : (c2r ? sizeof c2r64 : sizeof r2c64) / sizeof(E);
     for (size_t i = 0; i < cnt; ++i)

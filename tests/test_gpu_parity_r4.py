@@ -264,7 +264,8 @@ def test_r2c_f32_2p27_fused_every_output(gpu, oracle):
     assert float((back - x).abs().max()) < 2e-4
 
 
-@pytest.mark.parametrize("k,dt", [(23, "f64"), (24, "f64"), (25, "f64"), (26, "f64"), (23, "f32"), (25, "f32"), (26, "f32")])
+@pytest.mark.parametrize("k,dt", [(20, "f64"), (21, "f64"), (22, "f64"), (23, "f64"), (24, "f64"), (25, "f64"), (26, "f64"),
+                                  (20, "f32"), (21, "f32"), (22, "f32"), (23, "f32"), (25, "f32"), (26, "f32")])
 def test_real_transform_plans_every_output(gpu, k, dt):
     """One R2C / C2R transform runs the plan ranked for the real transform itself where `plan.hpp: real_plan` has one (round 4;
     `r2c-single=` / `c2r-single=` in describe()).  Every bin of r2c_fft against an independent float64 real FFT (rel-L2 and
@@ -279,6 +280,13 @@ def test_real_transform_plans_every_output(gpu, k, dt):
     pl = (gpu.PlannerR2c64 if dt == "f64" else gpu.PlannerR2c32)(n)
     desc = pl.describe()
     assert "r2c-single=" in desc or "c2r-single=" in desc, desc
+    if (dt, k) in (("f64", 22), ("f64", 23), ("f32", 21), ("f32", 22), ("f32", 23)):
+        # below 2^23 points in flight the untangle is fused only where the plan was cut for it (2048-point last-pass tiles,
+        # plan.hpp: kFuseBelow): three kernels, no sweep
+        probe = torch.zeros(n, dtype=tdt, device="cuda")
+        p_re, p_im = torch.zeros(h1, dtype=tdt, device="cuda"), torch.zeros(h1, dtype=tdt, device="cuda")
+        assert len(pl.time_passes(probe, p_re, p_im, reps=1)) == 3, desc
+        del probe, p_re, p_im
     x = torch.empty(n, dtype=tdt, device="cuda")
     gpu.fill_uniform(x, None, n, seed=0x4ea1, first_id=k)
     ore = torch.full((h1,), 7.0, dtype=tdt, device="cuda")

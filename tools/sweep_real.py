@@ -2,7 +2,9 @@
 """Plans of the inner transform of a REAL transform, ranked by the time of c2r_fft and r2c_fft (cold ring, HIP events):
 the C2C plans were chosen for planar input and output; R2C reads (re, im) pairs and C2R writes them, and the fused first /
 last passes have costs of their own (c2r_fused.hpp, r2c_fused.hpp).
-    python tools/sweep_real.py f32 24 [top]"""
+    python tools/sweep_real.py f32 24 [top]
+SWEEP_TLS=11,12,13 widens the tile sizes tried per pass (default 12,13); with PHAST_R2C_FUSE_MIN_LOG=20 the fused last pass
+runs below its usual threshold -- does it pay there on 2048-point tiles (twice the workgroups)?"""
 import itertools, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -56,7 +58,7 @@ for np_ in (2, 3):
         if sum(lrs) != Li:
             continue
         for lp in (3, 4):
-            for tls in itertools.product((12, 13), repeat=np_):
+            for tls in itertools.product(tuple(int(t) for t in os.environ.get("SWEEP_TLS", "12,13").split(",")), repeat=np_):
                 if all(tl - lr >= 3 and tl - lr <= 7 for lr, tl in zip(lrs, tls)):
                     cands.add((lrs, tls, lp))
 for lrs, tls, lp in sorted(cands):
