@@ -228,6 +228,9 @@ inline void heuristic_plan(unsigned L, bool latency, std::vector<unsigned> &lrs,
 //   f64  2^14 13.7 -> 12.2 us, 2^15 14.3 -> 11.2, 2^21 45.6 -> 42.5, 2^22 89 -> 79, 2^23 175 -> 159, 2^24 351 -> 319,
 //        2^25 700 -> 658, 2^27 2700 -> 2560, 2^28 5630 -> 5450       (2^16 .. 2^20 and 2^26: the old choice stands)
 //   f32  2^19 19.6 -> 17.2, 2^25 362 -> 353                        (2^24, 2^26 .. 2^28: within the noise, not adopted)
+// and, with 2048-point tiles in the sweep (SWEEP_TLS=10,11,12,13, profiles/r04_sweep_single_cold_tl11.log: a latency-bound
+// transform wants workgroups, 2^16 points are 16 tiles of 4096): f64 2^16 14.6 -> 11.4, 2^17 16.1 -> 14.3; f32 2^14 9.5 -> 8.4,
+// 2^15 9.75 -> 9.1, 2^19 17.2 -> 16.4
 // From 2^25 points on a single sweep ranks the luck of each planner's scratch allocation more than the plan (+-5 %,
 // profiles/r04_placement_probe.log) -- the sweep's own gains of 6 .. 11 % at f64 2^26 and f32 2^26 / 2^28 did not survive.
 // Measured with one transform in flight -- with four or more of 2^19 / 2^20 points the older latency / mid plans win again
@@ -240,10 +243,11 @@ inline bool single_plan(unsigned L, std::vector<unsigned> &lrs, std::vector<unsi
     };
     constexpr unsigned W = kWaveTiles;  // 64 x 16 wave tiles (wave_fft.hpp) and the four-wave 256 x 16 pass (quad_fft.hpp)
     static const E f64[] = {{13, 6, 7, 0, 10, 11, 0, 3 | W},  // (8192 points: Planner::twin, api.hip)
-                            {14, 6, 8, 0, 10, 12, 0, 4 | W},  {15, 7, 8, 0, 10, 12, 0, 3 | W},  {19, 6, 7, 6, 10, 11, 10, 3 | W}, {20, 6, 8, 6, 10, 12, 10, 3 | W},
+                            {14, 6, 8, 0, 10, 12, 0, 4 | W},  {15, 7, 8, 0, 10, 12, 0, 3 | W},  {16, 8, 8, 0, 11, 11, 0, 3},      {17, 8, 9, 0, 11, 12, 0, 3},
+                            {19, 6, 7, 6, 10, 11, 10, 3 | W}, {20, 6, 8, 6, 10, 12, 10, 3 | W},
                             {21, 6, 8, 7, 10, 12, 12, 3 | W}, {22, 8, 7, 7, 13, 12, 13, 4},     {23, 7, 9, 7, 13, 12, 13, 4},     {24, 8, 9, 7, 13, 12, 13, 4},
                             {25, 8, 9, 8, 12, 12, 14, 4},     {27, 8, 10, 9, 13, 14, 14, 5},    {28, 9, 9, 10, 14, 14, 14, 5}};
-    static const E f32[] = {{19, 6, 7, 6, 12, 12, 12, 3}, {22, 7, 8, 7, 13, 13, 13, 4}, {23, 8, 8, 7, 12, 12, 12, 4}, {25, 8, 9, 8, 14, 13, 14, 4}};
+    static const E f32[] = {{14, 7, 7, 0, 11, 11, 0, 3},  {15, 8, 7, 0, 12, 11, 0, 3},  {19, 6, 7, 6, 11, 11, 11, 3}, {22, 7, 8, 7, 13, 13, 13, 4}, {23, 8, 8, 7, 12, 12, 12, 4}, {25, 8, 9, 8, 14, 13, 14, 4}};
     const E *tab = sizeof(T) == 8 ? f64 : f32;
     const size_t cnt = (sizeof(T) == 8 ? sizeof f64 : sizeof f32) / sizeof(E);
     for (size_t i = 0; i < cnt; ++i)

@@ -59,6 +59,8 @@ for L in Ls:
     d0 = measure(pl)
     res = [(d0, "default: " + pl.describe())]
     tile_logs = (10, 12, 13, 14) if es == 8 else (12, 13, 14, 15)
+    if os.environ.get("SWEEP_TLS"):  # e.g. SWEEP_TLS=10,11,12,13: 2048-point tiles for the small sizes
+        tile_logs = tuple(int(t) for t in os.environ["SWEEP_TLS"].split(","))
     lps = (3, 4, 5, 3 | WAVE, 4 | WAVE) if es == 8 else (3, 4, 5)
     count = 0
     for k in (2, 3):
