@@ -626,7 +626,11 @@ template <typename T> struct Planner {
     // more than one transform (where there is one), else the latency plan
     const std::vector<PassDesc> &plan_for(size_t batch) const {
         if (passes_lat.empty() || passes.empty()) return passes;
-        if (batch <= 2 && !passes_one.empty()) return passes_one;  // ranked for one transform, whatever its size (plan.hpp: single_plan)
+        // ranked for ONE transform, whatever its size (plan.hpp: single_plan) -- and still ahead for a few small ones: up to
+        // 2^19 points in flight, or four transforms, below 2^21 points (tools/small_batch_plans.py,
+        // profiles/r04_small_batch_plans.log: 2^15 x 8 f64 14.6 -> 12.4 us, 2^16 x 4 15.0 -> 13.5, 2^19 x 3 42.7 -> 36.0;
+        // from 2^21 points per transform on, four in flight already prefer the throughput tiles)
+        if (!passes_one.empty() && (batch <= 2 || (log_n <= 20 && (batch <= 4 || batch * n <= ((size_t)1 << 19))))) return passes_one;
         unsigned tl = 0;
         for (const PassDesc &p : passes) tl = std::max(tl, p.lr + p.lc);
         // 4-byte elements: the same tile holds half the bytes, and the measured crossover sits one octave higher (one f32
@@ -734,7 +738,7 @@ template <typename T> struct Planner {
         return PHAST_OK;
     }
 
-    // N = 2^kSmallMaxLog (8192 points) only: the same length as a MULTI-pass planner, for ONE transform (or two).  The one-pass
+    // N = 2^kSmallMaxLog (8192 points) only: the same length as a MULTI-pass planner, for up to 128 transforms.  The one-pass
     // kernel keeps a whole transform in one workgroup -- right for batches (one sweep over the data), but a single 8192-point
     // transform is then ONE workgroup's chain of six LDS round trips: 16.2 us (f64) where the two-pass wave / quad plan of
     // 2^14 points takes 12.1 (profiles/r04_size_ladder.log).  PHAST_SMALL_TWIN=0: tools (A/B).
@@ -743,6 +747,15 @@ template <typename T> struct Planner {
         static const bool v = [] {
             const char *e = std::getenv("PHAST_SMALL_TWIN");
             return !(e && *e == '0');
+        }();
+        return v;
+    }
+    // ... and a batch of them is one workgroup EACH: below half the chip's CUs the twin still wins (2^13 x 128 f64: 17.8 us
+    // against 21.8, x 32: 11.3 against 17.3; profiles/r04_small_twin_batch.log).  PHAST_SMALL_TWIN_MAX_BATCH: tools.
+    static size_t twin_max_batch() {
+        static const size_t v = [] {
+            const char *e = std::getenv("PHAST_SMALL_TWIN_MAX_BATCH");
+            return (e && *e) ? (size_t)std::atoll(e) : (size_t)128;
         }();
         return v;
     }
@@ -1156,7 +1169,7 @@ template <typename T> struct Planner {
              size_t out_dist, unsigned out_mode, size_t batch, double scale, hipStream_t stream,
              PassTimer *timer = nullptr) const {
         if (batch == 0) return PHAST_OK;
-        if (twin && batch <= 2)  // one 8192-point transform: two passes over the whole chip instead of one workgroup
+        if (twin && batch <= twin_max_batch())  // one 8192-point transform: two passes over the whole chip instead of one workgroup
             return twin->exec(in_re, in_im, in_dist, in_mode, out_re, out_im, out_dist, out_mode, batch, scale, stream, timer);
         PHAST_ON_DEVICE(device);
         Lease L;
@@ -1368,7 +1381,7 @@ template <typename T> struct PlannerR2c {
     int r2c(const T *d_in, T *d_ore, T *d_oim, size_t batch, size_t in_dist, size_t out_dist, hipStream_t s,
             PassTimer *timer = nullptr) const {
         if (in_dist & 1) return PHAST_ERR_INVALID_ARG;  // the input is read as (even, odd) pairs
-        if (twin && batch <= 2) return twin->r2c(d_in, d_ore, d_oim, batch, in_dist, out_dist, s, timer);
+        if (twin && batch <= Planner<T>::twin_max_batch()) return twin->r2c(d_in, d_ore, d_oim, batch, in_dist, out_dist, s, timer);
         PHAST_ON_DEVICE(dit.device);
         Lease L;
         if (!dit.passes.empty()) {
@@ -1412,7 +1425,7 @@ template <typename T> struct PlannerR2c {
     int c2r(const T *d_ire, const T *d_iim, T *d_out, size_t batch, size_t in_dist, size_t out_dist,
             hipStream_t s, PassTimer *timer = nullptr) const {
         if (out_dist & 1) return PHAST_ERR_INVALID_ARG;
-        if (twin && batch <= 2) return twin->c2r(d_ire, d_iim, d_out, batch, in_dist, out_dist, s, timer);
+        if (twin && batch <= Planner<T>::twin_max_batch()) return twin->c2r(d_ire, d_iim, d_out, batch, in_dist, out_dist, s, timer);
         PHAST_ON_DEVICE(dit.device);
         Lease L;
         if (!dit.passes.empty()) {

@@ -36,9 +36,10 @@ struct Rng {
 
 int main() {
     const int T = 8, ITERS = 160, K = 4;  // K distinct inputs per planner
-    // (sizes whose plan does not depend on the batch: 2^14, 2^15 and 2^19 ... run ONE transform on a plan of its own,
-    //  plan.hpp: single_plan -- another factorisation, other last bits than the same transform inside a batch of six)
+    // (ONE transform -- or a few -- runs a plan of its own at most sizes, plan.hpp: single_plan: another factorisation, other
+    //  last bits than the same transform inside a larger batch.  The references below are therefore kept PER BATCH SIZE.)
     const size_t n_a = 1 << 16, n_b = 1 << 17, n_r = 1 << 16, h1 = n_r / 2 + 1;
+    const size_t MAXB = 6;
     phast_planner_dit64 *pa = nullptr, *pb = nullptr;
     phast_planner_r2c32 *pr = nullptr;
     CHECK(phast_planner_dit64_new(n_a, &pa));
@@ -59,13 +60,39 @@ int main() {
         CHECK(phast_r2c_fft_f32_with_planner(r_in[k].data(), n_r, R_re[k].data(), h1, R_im[k].data(), h1, pr));
         CHECK(phast_c2r_fft_f32_with_planner(R_re[k].data(), h1, R_im[k].data(), h1, R_back[k].data(), n_r, pr));
     }
+    // _dev references: [planner][input][batch - 1] = the transform of input k as every row of a batch of `batch` copies gives it
+    std::vector<std::vector<std::vector<std::vector<double>>>> D_re(2), D_im(2);
+    {
+        double *t_re, *t_im;
+        CHECK(hipMalloc((void **)&t_re, MAXB * n_b * 8));
+        CHECK(hipMalloc((void **)&t_im, MAXB * n_b * 8));
+        for (int big = 0; big < 2; ++big) {
+            const size_t n = big ? n_b : n_a;
+            D_re[big].assign(K, std::vector<std::vector<double>>(MAXB, std::vector<double>(n)));
+            D_im[big].assign(K, std::vector<std::vector<double>>(MAXB, std::vector<double>(n)));
+            for (int k = 0; k < K; ++k)
+                for (size_t batch = 1; batch <= MAXB; ++batch) {
+                    const auto &ir = big ? b_re[k] : a_re[k], &ii = big ? b_im[k] : a_im[k];
+                    for (size_t b = 0; b < batch; ++b) {
+                        CHECK(hipMemcpy(t_re + b * n, ir.data(), n * 8, hipMemcpyHostToDevice));
+                        CHECK(hipMemcpy(t_im + b * n, ii.data(), n * 8, hipMemcpyHostToDevice));
+                    }
+                    CHECK(phast_fft_64_dit_dev(t_re, t_im, n, batch, n, PHAST_FORWARD, big ? pb : pa, nullptr));
+                    CHECK(hipDeviceSynchronize());
+                    CHECK(hipMemcpy(D_re[big][k][batch - 1].data(), t_re + (batch - 1) * n, n * 8, hipMemcpyDeviceToHost));
+                    CHECK(hipMemcpy(D_im[big][k][batch - 1].data(), t_im + (batch - 1) * n, n * 8, hipMemcpyDeviceToHost));
+                }
+        }
+        (void)hipFree(t_re);
+        (void)hipFree(t_im);
+    }
     std::atomic<int> bad{0};
     std::atomic<long> ops{0};
     auto worker = [&](int t) {
         Rng r{(unsigned long long)(777 + 31 * t)};
         hipStream_t s;
         CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-        const size_t maxb = 6;
+        const size_t maxb = MAXB;
         double *d_re, *d_im;
         float *d_x, *d_ore, *d_oim, *d_y;
         CHECK(hipMalloc((void **)&d_re, maxb * n_b * 8));
@@ -94,7 +121,7 @@ int main() {
                 CHECK(hipMemcpyAsync(h_re.data(), d_re, batch * n * 8, hipMemcpyDeviceToHost, s));
                 CHECK(hipMemcpyAsync(h_im.data(), d_im, batch * n * 8, hipMemcpyDeviceToHost, s));
                 CHECK(hipStreamSynchronize(s));
-                const auto &wr = big ? B_re[k] : A_re[k], &wi = big ? B_im[k] : A_im[k];
+                const auto &wr = D_re[big][k][batch - 1], &wi = D_im[big][k][batch - 1];
                 for (size_t b = 0; b < batch; ++b)
                     if (std::memcmp(h_re.data() + b * n, wr.data(), n * 8) || std::memcmp(h_im.data() + b * n, wi.data(), n * 8)) bad++;
             } else if (op == 3) {  // R2C on host slices

@@ -362,9 +362,9 @@ def test_r2c_f64_large_fused_vs_c2c_route(gpu, k):
 @pytest.mark.parametrize("dt", ["f64", "f32"])
 def test_one_transform_of_8192_points_runs_the_multi_pass_twin(gpu, oracle, dt):
     """N = 2^13 is the largest size of the one-pass kernel (one workgroup per transform): right for batches, 16 us for ONE
-    transform.  A planner of that size keeps a multi-pass twin (`api.hip: Planner::twin`) that serves batch <= 2 -- through
-    every entry point, so that the same transform gives the same bits from host slices, device pointers and a captured graph;
-    batches keep the one-pass kernel (other factorisation: equal to rounding level).  The real transforms of 16384 points
+    transform.  A planner of that size keeps a multi-pass twin (`api.hip: Planner::twin`) that serves up to 128 transforms --
+    through every entry point, so that the same transform gives the same bits from host slices, device pointers and a captured
+    graph; larger batches keep the one-pass kernel (other factorisation: equal to rounding level).  The real transforms of 16384 points
     (inner length 8192) follow the same rule."""
     import torch
 
@@ -406,14 +406,16 @@ def test_one_transform_of_8192_points_runs_the_multi_pass_twin(gpu, oracle, dt):
     # the inverse through the twin: back to the input
     fft(d_re, d_im, gpu.Direction.Reverse, pl)
     assert float((d_re.cpu() - torch.from_numpy(h_re)).abs().max()) <= (1e-13 if f64 else 1e-5)
-    # a batch of five keeps the one-pass kernel: the same transform to rounding level, five times the same bits
-    b_re = torch.from_numpy(np.tile(h_re, 5)).cuda()
-    b_im = torch.from_numpy(np.tile(h_im, 5)).cuda()
-    gpu.fft_dit_batched(b_re, b_im, n, gpu.Direction.Forward, pl)
-    rows_re, rows_im = b_re.cpu().numpy().reshape(5, n), b_im.cpu().numpy().reshape(5, n)
-    for b in range(5):
-        assert err(rows_re[b], rows_im[b]) <= tol
-        assert np.array_equal(rows_re[b], rows_re[0]) and np.array_equal(rows_im[b], rows_im[0])
+    # batches: up to 128 transforms on the twin (one workgroup each would leave half the chip idle), the one-pass kernel
+    # beyond -- the same transform to rounding level either way, every row of a batch the same bits
+    for batch in (5, 160):
+        b_re = torch.from_numpy(np.tile(h_re, batch)).cuda()
+        b_im = torch.from_numpy(np.tile(h_im, batch)).cuda()
+        gpu.fft_dit_batched(b_re, b_im, n, gpu.Direction.Forward, pl)
+        rows_re, rows_im = b_re.cpu().numpy().reshape(batch, n), b_im.cpu().numpy().reshape(batch, n)
+        for b in range(batch):
+            assert np.array_equal(rows_re[b], rows_re[0]) and np.array_equal(rows_im[b], rows_im[0])
+        assert err(rows_re[0], rows_im[0]) <= tol and err(rows_re[-1], rows_im[-1]) <= tol
     # real transforms of 16384 points
     m = 2 * n
     rp = (gpu.PlannerR2c64 if f64 else gpu.PlannerR2c32)(m)
@@ -433,14 +435,15 @@ def test_one_transform_of_8192_points_runs_the_multi_pass_twin(gpu, oracle, dt):
     back = np.zeros(m, npdt)
     c2r(ore, oim, back, rp)
     assert float(np.abs(back - x).max()) <= (1e-12 if f64 else 2e-5)
-    xb = torch.from_numpy(np.tile(x, 4)).cuda()                     # a batch of four: the one-pass kernel with the fused untangle
-    bre = torch.zeros(4 * (m // 2 + 1), dtype=tdt, device="cuda")
-    bim = torch.zeros_like(bre)
-    gpu.r2c_fft_batched(xb, bre, bim, rp, 4)
-    got = bre.cpu().numpy().reshape(4, -1), bim.cpu().numpy().reshape(4, -1)
-    for b in range(4):
-        e = np.sqrt((np.abs(got[0][b] - ref.real) ** 2 + np.abs(got[1][b] - ref.imag) ** 2).sum() / (np.abs(ref) ** 2).sum())
-        assert e <= (1e-13 if f64 else 1e-5), (b, e)
+    for batch in (4, 130):                                          # the twin; the one-pass kernel with the untangle as its epilogue
+        xb = torch.from_numpy(np.tile(x, batch)).cuda()
+        bre = torch.zeros(batch * (m // 2 + 1), dtype=tdt, device="cuda")
+        bim = torch.zeros_like(bre)
+        gpu.r2c_fft_batched(xb, bre, bim, rp, batch)
+        got = bre.cpu().numpy().reshape(batch, -1), bim.cpu().numpy().reshape(batch, -1)
+        for b in (0, batch // 2, batch - 1):
+            e = np.sqrt((np.abs(got[0][b] - ref.real) ** 2 + np.abs(got[1][b] - ref.imag) ** 2).sum() / (np.abs(ref) ** 2).sum())
+            assert e <= (1e-13 if f64 else 1e-5), (batch, b, e)
 
 
 def test_small_twin_switch_restores_the_one_pass_kernel(gpu):
