@@ -1017,7 +1017,10 @@ template <typename T> struct Planner {
     hipError_t launch_pass(const PassDesc &p, const TileArgs &ta, hipStream_t stream, hipEvent_t e0, hipEvent_t e1) const {
         unsigned grid = (unsigned)(g_wg_per_cu_override > 0 ? g_wg_per_cu_override : p.blocks_per_cu) * (unsigned)cus_of(device);
         if (grid > ta.tiles_total) grid = ta.tiles_total;
-        if (grid >= 8) grid &= ~7u;  // keep tile%8 == workgroup%8 (XCD affinity of the tile order)
+        // keep tile%8 == workgroup%8 (XCD affinity of the tile order) -- where that order is in force (TileBody::locate: tile
+        // counts that are a multiple of 8); rounding 12 tiles down to 8 workgroups made four of them run two tiles in a row:
+        // 3 x 2^14 f64 23.2 us where 4 x 2^14 takes 14.1 (profiles/r04_small_batch_plans.log)
+        if (grid >= 8 && (ta.tiles_total & 7u) == 0u) grid &= ~7u;
         return p.wave      ? launch_wave<T>(p.transpose, stream, ta, false, nullptr, nullptr, e0, e1)
                : p.quad    ? launch_quad<T>(grid, stream, ta, false, nullptr, nullptr, e0, e1)
                : p.transpose ? Types<T>::launch_a(p.lr, p.lc, (int)p.lp, grid, stream, ta, false, nullptr, nullptr, e0, e1)
@@ -1273,7 +1276,7 @@ template <typename T> struct Planner {
                     fa.twu = p.d_twu;
                     unsigned grid = (unsigned)p.c2r_blocks * (unsigned)cus_of(device);
                     if (grid > ta.tiles_total) grid = ta.tiles_total;
-                    if (grid >= 8) grid &= ~7u;
+                    if (grid >= 8 && (ta.tiles_total & 7u) == 0u) grid &= ~7u;
                     hipError_t e = launch_c2r_first<T>((int)p.lr, (int)p.lc, (int)p.lp, grid, stream, ta, fa, false, nullptr, e0, e1);
                     if (e != hipSuccess) return hip_fail(e, "c2r_first_pass launch");
                     continue;
