@@ -363,6 +363,7 @@ template <typename T> struct Planner {
     // C2R only (PlannerR2c::init): passes_one / passes_lat with the pass ORDER reversed, where that gives the first pass --
     // which reads the caller's planar half-spectrum -- the wide rows the C2C order gives the last (see make_c2r_plans)
     std::vector<PassDesc> passes_c2r_one, passes_c2r_lat;
+    std::vector<PassDesc> passes_r2c_tp, passes_c2r_tp;  // batches of real transforms in the throughput regime (plan.hpp: real_batch_plan)
     // R2C only: the plan of ONE (or two) real transforms where plan.hpp (real_plan) has a better one than the C2C choice;
     // passes_c2r_one is C2R's (from the same table, else the reversal above)
     std::vector<PassDesc> passes_r2c;
@@ -608,6 +609,8 @@ template <typename T> struct Planner {
         free_passes(passes_one);
         free_passes(passes_c2r_one);
         free_passes(passes_c2r_lat);
+        free_passes(passes_r2c_tp);
+        free_passes(passes_c2r_tp);
         free_passes(passes_r2c);
         for (void *t : old_tables) hipFree(t);
         old_tables.clear();
@@ -647,6 +650,7 @@ template <typename T> struct Planner {
     const std::vector<PassDesc> &plan_for_r2c(size_t batch, bool fusing = true) const {
         if (batch <= 2 && !passes_r2c.empty()) return passes_r2c;  // ranked for R2C itself (plan.hpp: real_plan)
         const std::vector<PassDesc> &ps = plan_for(batch);
+        if (&ps == &passes && !passes_r2c_tp.empty()) return passes_r2c_tp;  // ... and for batches of them (real_batch_plan)
         if (fusing && !ps.empty() && ps.back().r2c_blocks == 0 && log_n <= 25 && !passes_lat.empty() && passes_lat.back().r2c_blocks > 0 &&
             r2c_lat_ok())
             return passes_lat;
@@ -655,6 +659,7 @@ template <typename T> struct Planner {
     // C2R, the same on the other side: a plan whose FIRST pass is a wave tile has no fused form of it (c2r_fused.hpp)
     const std::vector<PassDesc> &plan_for_c2r(size_t batch) const {
         const std::vector<PassDesc> &ps0 = plan_for(batch);
+        if (&ps0 == &passes && batch > 2 && !passes_c2r_tp.empty() && passes_c2r_tp.front().c2r_blocks > 0) return passes_c2r_tp;
         const std::vector<PassDesc> &ps = (batch <= 2 && !passes_c2r_one.empty())                 ? passes_c2r_one
                                           : (&ps0 == &passes_lat && !passes_c2r_lat.empty()) ? passes_c2r_lat
                                                                                              : ps0;
@@ -712,8 +717,12 @@ template <typename T> struct Planner {
             retire_passes(passes_one);
             retire_passes(passes_c2r_one);
             passes_one = std::move(ps);
-        } else if (which >= 5 && which <= 7) {  // the real transforms' own plans: additional, table_bytes and pitch below
-            std::vector<PassDesc> &dst = which == 5 ? passes_c2r_one : which == 6 ? passes_c2r_lat : passes_r2c;
+        } else if (which >= 5 && which <= 9) {  // the real transforms' own plans: additional, table_bytes and pitch below
+            std::vector<PassDesc> &dst = which == 5   ? passes_c2r_one
+                                         : which == 6 ? passes_c2r_lat
+                                         : which == 7 ? passes_r2c
+                                         : which == 8 ? passes_c2r_tp
+                                                      : passes_r2c_tp;
             retire_passes(dst);
             dst = std::move(ps);
             table_bytes += tb;
@@ -729,6 +738,8 @@ template <typename T> struct Planner {
                 retire_passes(passes_c2r_one);
                 retire_passes(passes_c2r_lat);
                 retire_passes(passes_r2c);
+                retire_passes(passes_r2c_tp);
+                retire_passes(passes_c2r_tp);
             }
         }
         table_bytes = tb;
@@ -830,6 +841,14 @@ template <typename T> struct Planner {
             int rc = set_plan(lrs, tls, c2r ? 5 : 7, lp & ~kFuseBelow);
             if (rc != PHAST_OK && rc != PHAST_ERR_INVALID_ARG) return rc;
             if (!c2r) r2c_table_fuses = rc == PHAST_OK && fuse_below;
+        }
+        // 1b. ... and of batches of them in the throughput regime (plan.hpp: real_batch_plan)
+        for (int c2r = 0; c2r < 2 && table; ++c2r) {
+            std::vector<unsigned> lrs, tls;
+            unsigned lp = 4;
+            if (!real_batch_plan<T>(log_n, c2r != 0, lrs, tls, lp)) continue;
+            int rc = set_plan(lrs, tls, c2r ? 8 : 9, lp);
+            if (rc != PHAST_OK && rc != PHAST_ERR_INVALID_ARG) return rc;
         }
         // 2. C2R, two-pass plans: the reversed order
         for (int k = 0; k < 2 && rev; ++k) {
@@ -1114,6 +1133,8 @@ template <typename T> struct Planner {
         if (!passes_c2r_one.empty()) add("c2r-single", passes_c2r_one);
         if (!passes_c2r_lat.empty()) add("c2r-latency", passes_c2r_lat);
         if (!passes_r2c.empty()) add("r2c-single", passes_r2c);
+        if (!passes_r2c_tp.empty()) add("r2c-batch", passes_r2c_tp);
+        if (!passes_c2r_tp.empty()) add("c2r-batch", passes_c2r_tp);
         return s;
     }
 
@@ -1384,7 +1405,9 @@ template <typename T> struct PlannerR2c {
     int r2c(const T *d_in, T *d_ore, T *d_oim, size_t batch, size_t in_dist, size_t out_dist, hipStream_t s,
             PassTimer *timer = nullptr) const {
         if (in_dist & 1) return PHAST_ERR_INVALID_ARG;  // the input is read as (even, odd) pairs
-        if (twin && batch <= Planner<T>::twin_max_batch()) return twin->r2c(d_in, d_ore, d_oim, batch, in_dist, out_dist, s, timer);
+        // (... and large batches too where the twin has a plan ranked for them: f32, plan.hpp: real_batch_plan)
+        if (twin && (batch <= Planner<T>::twin_max_batch() || (batch * (n / 2) >= ((size_t)1 << 24) && !twin->dit.passes_r2c_tp.empty())))
+            return twin->r2c(d_in, d_ore, d_oim, batch, in_dist, out_dist, s, timer);
         PHAST_ON_DEVICE(dit.device);
         Lease L;
         if (!dit.passes.empty()) {
@@ -1428,7 +1451,8 @@ template <typename T> struct PlannerR2c {
     int c2r(const T *d_ire, const T *d_iim, T *d_out, size_t batch, size_t in_dist, size_t out_dist,
             hipStream_t s, PassTimer *timer = nullptr) const {
         if (out_dist & 1) return PHAST_ERR_INVALID_ARG;
-        if (twin && batch <= Planner<T>::twin_max_batch()) return twin->c2r(d_ire, d_iim, d_out, batch, in_dist, out_dist, s, timer);
+        if (twin && (batch <= Planner<T>::twin_max_batch() || (batch * (n / 2) >= ((size_t)1 << 24) && !twin->dit.passes_c2r_tp.empty())))
+            return twin->c2r(d_ire, d_iim, d_out, batch, in_dist, out_dist, s, timer);
         PHAST_ON_DEVICE(dit.device);
         Lease L;
         if (!dit.passes.empty()) {
@@ -2019,7 +2043,10 @@ template <typename T>
 static int set_plan_c(Planner<T> *p, const unsigned *log_rows, const unsigned *tile_logs, size_t n_passes,
                       unsigned points_log) {
     if (!p) return PHAST_ERR_INVALID_ARG;
-    if (p->log_n <= kSmallMaxLog) return n_passes == 0 ? PHAST_OK : PHAST_ERR_INVALID_ARG;
+    if (p->passes.empty()) {  // a one-pass size: nothing to plan -- except in the multi-pass twin of 8192 points (tools)
+        if (p->twin) return set_plan_c<T>(p->twin.get(), log_rows, tile_logs, n_passes, points_log);
+        return n_passes == 0 ? PHAST_OK : PHAST_ERR_INVALID_ARG;
+    }
     std::vector<unsigned> lrs, tls;
     if (n_passes == 0) {
         return p->default_plans();
@@ -2218,8 +2245,9 @@ int phast_options_guess(size_t input_size, phast_options *out) {
     int phast_planner_r2c##SFX##_set_inner_plan(phast_planner_r2c##SFX *p, const unsigned *lr, const unsigned *tl,  \
                                                 size_t np, unsigned points_log) {                                  \
         if (!p) return PHAST_ERR_INVALID_ARG;                                                                      \
-        int rc = set_plan_c<T>(&p->dit, lr, tl, np, points_log);                                                   \
-        if (rc == PHAST_OK && np == 0 && !p->dit.passes.empty()) rc = p->dit.make_c2r_plans();                     \
+        PlannerR2c<T> *q = (p->dit.passes.empty() && p->twin) ? p->twin.get() : p;                                 \
+        int rc = set_plan_c<T>(&q->dit, lr, tl, np, points_log);                                                   \
+        if (rc == PHAST_OK && np == 0 && !q->dit.passes.empty()) rc = q->dit.make_c2r_plans();                     \
         return rc;                                                                                                 \
     }                                                                                                              \
     int phast_planner_r2c##SFX##_describe(const phast_planner_r2c##SFX *p, char *buf, size_t len) {                \

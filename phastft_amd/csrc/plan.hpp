@@ -319,6 +319,47 @@ inline bool real_plan(unsigned L, bool c2r, std::vector<unsigned> &lrs, std::vec
     return false;
 }
 
+// ... and for BATCHES of real transforms in the throughput regime (`L` = log2 of the inner length).  The C2C throughput plans
+// end (and begin) in 32-point-per-thread passes on 16384- / 32768-point tiles, most of which have no fused untangle /
+// preprocess form: batched R2C then ran three sweeps where two would do, and batched C2R kept a first pass cut for planar
+// input.  Ranked with 2^27 real samples in flight (tools/sweep_real_batch.py, profiles/r04_sweep_real_batch.log):
+// and kept where an alternating A/B of the table (PHAST_REAL_PLANS=0|1, profiles/r04_real_batch_ab.log) confirmed it:
+//   r2c_fft_f32  2^15 749 -> 567 us, 2^17 613 -> 535, 2^18 711 -> 547, 2^19 736 -> 509, 2^20 924 -> 597 (145 -> 225
+//                GSamples/s), 2^21 790 -> 686;   r2c_fft_f64  2^15 1401 -> 1088, 2^16 1168 -> 1001, 2^17 .. 2^20 + 8 .. 17 %
+//   c2r_fft_f32  2^17 566 -> 477, 2^18 .. 2^20 + 3 .. 7 %;   c2r_fft_f64  2^15 .. 2^20 + 2 .. 11 %
+//   (the three-pass f64 sizes 2^21 .. 2^23: 0 .. 12 % from run to run -- not adopted)
+// What wins: R2C -- a long first pass on big tiles, then a SHORT fused last pass (64 .. 512 rows on 4096- / 8192-point
+// tiles at 16 points per thread); C2R -- the mirror image, a short fused first pass.
+template <typename T>
+inline bool real_batch_plan(unsigned L, bool c2r, std::vector<unsigned> &lrs, std::vector<unsigned> &tls, unsigned &lp) {
+    struct E {
+        unsigned L, a, b, c, ta, tb, tc, lp;  // c = 0: two passes
+    };
+    static const E r2c32[] = {{13, 7, 6, 0, 12, 12, 0, 3},  {14, 8, 6, 0, 12, 12, 0, 3},  {15, 9, 6, 0, 14, 12, 0, 4},  {16, 10, 6, 0, 14, 12, 0, 4},
+                              {17, 9, 8, 0, 14, 13, 0, 5},  {18, 10, 8, 0, 15, 13, 0, 5}, {19, 10, 9, 0, 14, 13, 0, 4}, {20, 10, 10, 0, 15, 14, 0, 5}};
+    static const E r2c64[] = {{14, 8, 6, 0, 14, 12, 0, 4},  {15, 9, 6, 0, 14, 12, 0, 4},  {16, 9, 7, 0, 13, 12, 0, 4},  {17, 10, 7, 0, 14, 12, 0, 4},
+                              {18, 10, 8, 0, 14, 13, 0, 4}, {19, 10, 9, 0, 14, 13, 0, 4}};
+    static const E c2r32[] = {{13, 6, 7, 0, 12, 13, 0, 4},  {14, 6, 8, 0, 12, 13, 0, 4},  {15, 8, 7, 0, 13, 13, 0, 4},  {16, 8, 8, 0, 13, 14, 0, 4},
+                              {17, 8, 9, 0, 13, 14, 0, 5},  {18, 8, 10, 0, 13, 15, 0, 5}, {19, 10, 9, 0, 15, 14, 0, 5}, {20, 10, 10, 0, 15, 15, 0, 5}};
+    static const E c2r64[] = {{13, 6, 7, 0, 12, 13, 0, 4},  {14, 6, 8, 0, 12, 13, 0, 4},  {15, 7, 8, 0, 12, 14, 0, 4},  {16, 8, 8, 0, 12, 13, 0, 4},
+                              {17, 8, 9, 0, 13, 13, 0, 4},  {18, 8, 10, 0, 13, 14, 0, 4}, {19, 9, 10, 0, 14, 14, 0, 4}};
+    const E *tab = sizeof(T) == 4 ? (c2r ? c2r32 : r2c32) : (c2r ? c2r64 : r2c64);
+    const size_t cnt = sizeof(T) == 4 ? (c2r ? sizeof c2r32 : sizeof r2c32) / sizeof(E) : (c2r ? sizeof c2r64 : sizeof r2c64) / sizeof(E);
+    for (size_t i = 0; i < cnt; ++i)
+        if (tab[i].L == L) {
+            const E &e = tab[i];
+            lrs = {e.a, e.b};
+            tls = {e.ta, e.tb};
+            if (e.c) {
+                lrs.push_back(e.c);
+                tls.push_back(e.tc);
+            }
+            lp = e.lp;
+            return true;
+        }
+    return false;
+}
+
 // A third plan for "a few transforms in flight" where neither of the two above fits: N = 2^20, whose latency plan
 // takes three passes (best for ONE transform) while 2..15 transforms are better served by two passes of
 // 8192-point tiles (64 / 68 / 75 GSamples/s at 2 / 4 / 8 transforms against 47 / 44 / 49,

@@ -455,3 +455,38 @@ def test_small_twin_switch_restores_the_one_pass_kernel(gpu):
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("n=2^13")]
     assert len(lines) == 2 and all("single" not in ln and "one transform" not in ln for ln in lines), r.stdout
+
+
+# ---------------------------------------------------------------- batches of real transforms on their own plans
+@pytest.mark.parametrize("k,dt", [(14, "f32"), (14, "f64"), (15, "f32"), (15, "f64"), (17, "f32"), (18, "f64"), (20, "f32"), (20, "f64")])
+def test_batched_real_transforms_run_the_plans_ranked_for_batches(gpu, k, dt):
+    """`plan.hpp: real_batch_plan` (round 4): in the throughput regime a batch of R2C / C2R transforms runs a plan whose last /
+    first pass has the fused untangle / preprocess form (`r2c-batch=` / `c2r-batch=` in describe()) instead of the C2C
+    throughput plan + a sweep.  2^26 real samples in flight; rows at both ends and in the middle of the batch against an
+    independent float64 real FFT (rel-L2 and the worst single bin), every row of the round trip against the input."""
+    import torch
+
+    n = 1 << k
+    h1 = n // 2 + 1
+    batch = 1 << (26 - k)
+    ndt, tdt, tol, tol_bin, tol_back = ((np.float64, torch.float64, 1e-13, 1e-11, 1e-10) if dt == "f64" else
+                                        (np.float32, torch.float32, 1e-5, 2e-3, 2e-4))
+    pl = (gpu.PlannerR2c64 if dt == "f64" else gpu.PlannerR2c32)(n)
+    desc = pl.describe()
+    assert "r2c-batch=" in desc or "c2r-batch=" in desc, desc
+    x = torch.empty(batch * n, dtype=tdt, device="cuda")
+    gpu.fill_uniform(x, None, n, seed=0xba7c, first_id=k)
+    ore = torch.full((batch * h1,), 7.0, dtype=tdt, device="cuda")
+    oim = torch.full((batch * h1,), 7.0, dtype=tdt, device="cuda")
+    gpu.r2c_fft_batched(x, ore, oim, pl, batch)
+    for b in (0, 1, batch // 2, batch - 1):
+        ind = np.fft.rfft(x[b * n:(b + 1) * n].cpu().numpy().astype(np.float64))
+        g_re = ore[b * h1:(b + 1) * h1].cpu().numpy().astype(np.float64)
+        g_im = oim[b * h1:(b + 1) * h1].cpu().numpy().astype(np.float64)
+        den = np.sqrt(np.sum(ind.real ** 2 + ind.imag ** 2))
+        assert np.sqrt(np.sum((g_re - ind.real) ** 2 + (g_im - ind.imag) ** 2)) / den <= tol, (b, desc)
+        assert max(np.max(np.abs(g_re - ind.real)), np.max(np.abs(g_im - ind.imag))) / (den / np.sqrt(h1)) <= tol_bin, (b, desc)
+        assert g_im[0] == 0 and g_im[-1] == 0
+    back = torch.empty_like(x)
+    gpu.c2r_fft_batched(ore, oim, back, pl, batch)
+    assert float((back - x).abs().max()) < tol_back, desc
