@@ -258,9 +258,14 @@ hipError_t launch_row_inst(const RowArgs &a, hipStream_t stream, hipEvent_t ev_s
 // log2 N -> (log2 transforms per tile, log2 points per thread): 4096-point tiles from N = 64 up (8 points per
 // thread below 256, 16 from there); N <= 32 is one butterfly per thread, 256 (N = 32: 128) threads; N = 8192 is
 // one transform per workgroup with 32 points per thread.
+#ifndef PHAST_ROW13_LP
+// 8192 points in one workgroup: 16 points per thread on 512 threads (round 4; 32 per thread on 256 threads saved an LDS exchange
+// but left one wave per SIMD: batches of 2^13 f64 1403 -> 1276 us per 2^27 points, f32 875 -> 718; profiles/r04_row13_ab.log)
+#define PHAST_ROW13_LP 4
+#endif
 #define PHAST_ROW_SHAPES(X)                                                                                     \
     X(1, 8, 1) X(2, 8, 2) X(3, 8, 3) X(4, 8, 4) X(5, 7, 5) X(6, 6, 3) X(7, 5, 3) X(8, 4, 4) X(9, 3, 4) X(10, 2, 4) \
-    X(11, 1, 4) X(12, 0, 4) X(13, 0, 5)
+    X(11, 1, 4) X(12, 0, 4) X(13, 0, PHAST_ROW13_LP)
 
 inline unsigned row_tile_cols_log(unsigned log_n) {
 #define PHAST_ROW_LC(LR_, LC_, LP_) \

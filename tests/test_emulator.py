@@ -148,9 +148,10 @@ def test_small_kernel_lds_audit(emu, is_f64):
         r, w = C.c_int(), C.c_int()
         errors = emu.phast_emu_audit_small(is_f64, log_n, C.byref(r), C.byref(w))
         assert errors == 0, log_n
-        # N <= 16: a pad word every N < 32 words leaves 2-way conflicts; N = 4096 (one transform per workgroup, a
-        # 32-lane group spans 32 rows): one bank pair collides in the first exchange
-        worst = 2 if (log_n <= 4 or log_n == 12) else 1
+        # N <= 16: a pad word every N < 32 words leaves 2-way conflicts; N = 4096 and 8192 (one transform per workgroup at
+        # 16 points per thread, a 32-lane group spans 32 rows): one bank pair collides in the first exchange -- measured
+        # and accepted for 8192 in round 4 (16 points per thread on 512 threads beat 32 on 256 by 10-22 %, r04_row13_ab.log)
+        worst = 2 if (log_n <= 4 or log_n >= 12) else 1
         assert r.value <= worst and w.value <= worst, (log_n, r.value, w.value)
 
 
