@@ -351,8 +351,6 @@ struct Workspace {
     }
 };
 
-// Device memory for a scratch: PHAST_SCRATCH_ALLOC=contiguous asks the driver for physically contiguous memory
-// (hipExtMallocWithFlags + hipDeviceMallocContiguous) -- experiment, tools/placement_probe.py
 template <typename T> struct Planner {
     size_t n = 0;
     unsigned log_n = 0;
