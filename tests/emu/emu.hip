@@ -501,5 +501,45 @@ int phast_emu_default_plan(int is_f64, int latency, unsigned log_n, unsigned *lr
     for (size_t i = 0; i < v.size(); ++i) lrs[i] = v[i];
     return (int)v.size();
 }
+
+// Every entry of the plan tables (plan.hpp: single_plan, real_plan, real_batch_plan) must be a plan that EXISTS: rows adding
+// up to the length, every pass a shape that is instantiated, the geometry accepted by make_passes.  A typo in a table would
+// otherwise only show on the GPU as a planner that silently keeps its heuristic plan (set_plan -> INVALID_ARG is not an error
+// for an optional plan).  Returns the number of bad entries, *n_entries = entries seen.
+}  // extern "C"
+template <typename T> static int check_tables(int *n_entries) {
+    using namespace phast;
+    int bad = 0;
+    for (unsigned L = kSmallMaxLog; L <= 30; ++L)
+        for (int which = 0; which < 5; ++which) {
+            std::vector<unsigned> lrs, tls;
+            unsigned lp = 4;
+            const bool have = which == 0   ? single_plan<T>(L, lrs, tls, lp)
+                              : which <= 2 ? real_plan<T>(L, which == 2, lrs, tls, lp)
+                                           : real_batch_plan<T>(L, which == 4, lrs, tls, lp);
+            if (!have) continue;
+            ++*n_entries;
+            unsigned sum = 0;
+            for (unsigned r : lrs) sum += r;
+            std::vector<PassGeom> geo;
+            const bool ok = sum == L && lrs.size() == tls.size() && make_passes(L, lrs, tls, geo, lp & ~kFuseBelow, sizeof(T));
+            if (!ok) {
+                std::fprintf(stderr, "plan table %d, %zu-byte elements, L = %u: not a plan\n", which, sizeof(T), L);
+                ++bad;
+            } else if (sizeof(T) == 4) {
+                for (const PassGeom &g : geo)
+                    if (g.wave) {  // the product library refuses f32 wave tiles (api.hip: set_plan)
+                        std::fprintf(stderr, "plan table %d, f32, L = %u: asks for wave tiles\n", which, L);
+                        ++bad;
+                    }
+            }
+        }
+    return bad;
+}
+extern "C" {
+int phast_emu_check_plan_tables(int *n_entries) {
+    *n_entries = 0;
+    return check_tables<double>(n_entries) + check_tables<float>(n_entries);
+}
 #endif
 }

@@ -436,3 +436,14 @@ def test_every_instantiated_shape_as_fused_first_pass_of_c2r_and_last_pass_of_r2
                 assert np.sqrt(np.sum(np.abs(got - ref) ** 2) / np.sum(np.abs(ref) ** 2)) <= tol, (shape, plan)
                 ran_r2c += 1
     assert ran_c2r >= (35 if is_f64 else 40) and ran_r2c >= (24 if is_f64 else 36), (ran_c2r, ran_r2c)
+
+
+def test_every_plan_table_entry_is_a_plan_that_exists(emu):
+    """plan.hpp: single_plan / real_plan / real_batch_plan (round 4: 77 entries ranked on the GPU) -- rows add up to the length,
+    every pass is an instantiated shape, make_passes accepts the geometry; no f32 entry asks for the (experimental) wave tiles.
+    A bad entry would not fail anywhere else: an optional plan that cannot be built is skipped silently."""
+    n = C.c_int()
+    emu.phast_emu_check_plan_tables.argtypes = [C.POINTER(C.c_int)]
+    emu.phast_emu_check_plan_tables.restype = C.c_int
+    assert emu.phast_emu_check_plan_tables(C.byref(n)) == 0
+    assert n.value >= 70, n.value
