@@ -431,20 +431,40 @@ template <typename T> struct Planner {
             (void)hipGetLastError();  // hipErrorNotReady is an answer, not a failure
             return false;
         };
+        // under capture nothing may be allocated: a workspace "fits" if its scratch exists and was cut for the pitches of the
+        // plans as they are now (set_plan may have widened them since it was made; ensure_scratch would have to re-cut it)
+        const size_t per_now = 2 * sstride() * sizeof(T);
+        auto fits = [&](const Workspace &w) { return w.cap > 0 && w.per == per_now; };
         for (;;) {
-            if (which == 0)  // 1. the workspace this stream used last: stream order protects its buffers
+            if (which == 0 && !cap)  // 1. the workspace this stream used last: stream order protects its buffers
                 for (auto &w : pool)
-                    if (!w->busy && w->pending && w->stream == stream && (cap || !w->captured)) {
+                    if (!w->busy && w->pending && w->stream == stream && !w->captured) {
                         pick = w.get();
                         break;
                     }
-            if (!pick && cap) {
-                // 1b. under capture nothing executes now and nothing may be allocated or queried: any eager workspace will
-                // do (the largest: least likely to need growing) -- it belongs to the graph from here on, so no eager call
-                // can meet a replay in it.  What was enqueued in it BEFORE the capture is ordered before the replays by
-                // the caller (a capture stream is always forked from the stream that did the warm-up).
-                for (auto &w : pool)
-                    if (!w->busy && !w->captured && (!pick || w->cap > pick->cap)) pick = w.get();
+            if (cap) {
+                // 1b. under capture nothing executes now and nothing may be allocated or queried: the stream's own workspace
+                // or any eager one, whichever FITS and is largest (a larger batch runs in fewer chunks; the stream's own on
+                // a tie) -- it belongs to the graph from here on, so no eager call can meet a replay in it.  What was
+                // enqueued in it BEFORE the capture is ordered before the replays by the caller (a capture stream is always
+                // forked from the stream that did the warm-up).
+                for (auto &w : pool) {
+                    const bool own_ws = w->pending && w->stream == stream;
+                    if (w->busy || !fits(*w) || (w->captured && !own_ws)) continue;
+                    if (!pick || w->cap > pick->cap || (w->cap == pick->cap && own_ws)) pick = w.get();
+                }
+                // 1c. none fits (no eager call since the plan changed, or none at all): the stream's own, then any eager one --
+                // ensure_scratch will have to allocate and the capture fails with the runtime's message, as documented
+                // ("HIP graphs": run the call once eagerly before capturing it)
+                if (!pick)
+                    for (auto &w : pool)
+                        if (!w->busy && w->pending && w->stream == stream) {
+                            pick = w.get();
+                            break;
+                        }
+                if (!pick)
+                    for (auto &w : pool)
+                        if (!w->busy && !w->captured && (!pick || w->cap > pick->cap)) pick = w.get();
             }
             if (!pick && !cap)  // 2. one with nothing in flight (never one that belongs to a captured graph)
                 for (auto &w : pool)
@@ -896,6 +916,10 @@ template <typename T> struct Planner {
         size_t want = target;
         if (want > batch && batch >= reserve) want = batch;
         if (exact && want < batch) want = batch;  // work that cannot be cut into chunks (strided batches)
+        if (w.cap < want && !exact && w.cap >= std::max<size_t>(reserve, 1) && capturing(stream)) {
+            *cap_out = w.cap;  // under capture nothing may be allocated: the batch runs in the chunks this scratch allows
+            return PHAST_OK;
+        }
         if (w.cap < want) {
             if (!exact && w.cap && want < 2 * w.cap) want = std::min(2 * w.cap, std::max(target, want));
             const size_t floor_cap = exact ? want : std::max<size_t>(std::max<size_t>(reserve, 1), w.cap + 1);

@@ -490,3 +490,59 @@ def test_batched_real_transforms_run_the_plans_ranked_for_batches(gpu, k, dt):
     back = torch.empty_like(x)
     gpu.c2r_fft_batched(ore, oim, back, pl, batch)
     assert float((back - x).abs().max()) < tol_back, desc
+
+
+def test_capture_after_growth_and_after_a_plan_change_picks_a_workspace_that_fits(gpu, oracle):
+    """Nothing may be allocated under capture.  (1) A graph of ONE transform, then eager batches of eight (another, larger
+    workspace), then a graph of EIGHT on the same capture stream: the second capture must take the workspace that holds eight
+    (or run in the chunks the first one allows) -- never try to grow one.  (2) `set_plan` to a plan with other scratch pitches,
+    one eager call, capture again: the stream's old workspace no longer fits and must not be re-cut under capture.  Found by
+    a tuning script that re-planned one planner between graphs (`hipMalloc(scratch): operation not permitted when stream is
+    capturing`).  Every replay bit-identical to the eager result of the same plan."""
+    import torch
+
+    n = 1 << 18
+    pl = gpu.PlannerDit64(n)
+    h_re, h_im = oracle.fill(n, np.float64, seed=91, transform_id=2)
+
+    def fresh(batch):
+        return (torch.from_numpy(np.tile(h_re, batch)).cuda(), torch.from_numpy(np.tile(h_im, batch)).cuda())
+
+    def eager(batch):
+        a, b = fresh(batch)
+        gpu.fft_dit_batched(a, b, n, gpu.Direction.Forward, pl)
+        torch.cuda.synchronize()
+        return a, b
+
+    def capture(batch):
+        a, b = fresh(batch)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            gpu.fft_dit_batched(a, b, n, gpu.Direction.Forward, pl)
+        return g, a, b
+
+    want1 = eager(1)
+    g1, a1, b1 = capture(1)
+    want8 = eager(8)
+    g8, a8, b8 = capture(8)                      # same torch capture stream as g1
+    for g in (g1, g8):                           # (in place: one replay per set of inputs)
+        g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(a1, want1[0]) and torch.equal(b1, want1[1])
+    assert torch.equal(a8, want8[0]) and torch.equal(b8, want8[1])
+    # (2) another plan, other pitches
+    pl.set_plan((9, 9), 13, 4)
+    want1b = eager(1)
+    g1b, a1b, b1b = capture(1)
+    g1b.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(a1b, want1b[0]) and torch.equal(b1b, want1b[1])
+    ref_re, ref_im = h_re.copy(), h_im.copy()
+    oracle.fft_64_dit(ref_re, ref_im, oracle.FORWARD)
+    err = np.sqrt(((a1b.cpu().numpy() - ref_re) ** 2 + (b1b.cpu().numpy() - ref_im) ** 2).sum() / (ref_re ** 2 + ref_im ** 2).sum())
+    assert err <= 1e-13
+    # the first two graphs still replay (their workspaces and tables were never freed)
+    a1.copy_(torch.from_numpy(h_re)); b1.copy_(torch.from_numpy(h_im))
+    g1.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(a1, want1[0]) and torch.equal(b1, want1[1])
