@@ -226,7 +226,7 @@ inline void heuristic_plan(unsigned L, bool latency, std::vector<unsigned> &lrs,
 // 8192-point tiles (32 columns = 256-byte row pieces in f64), a NARROW middle pass on 4096-point tiles (more workgroups in
 // flight while it runs in place in the scratch) and a 128-row last pass beat the balanced splits on one tile size:
 //   f64  2^14 13.7 -> 12.2 us, 2^15 14.3 -> 11.2, 2^21 45.6 -> 42.5, 2^22 89 -> 79, 2^23 175 -> 159, 2^24 351 -> 319,
-//        2^25 700 -> 658, 2^27 2700 -> 2560, 2^28 5630 -> 5450       (2^16 .. 2^20 and 2^26: the old choice stands)
+//        2^25 700 -> 658, 2^27 2700 -> 2560, 2^28 5630 -> 5450       (2^18 .. 2^20 and 2^26: the old choice stands)
 //   f32  2^19 19.6 -> 17.2, 2^25 362 -> 353                        (2^24, 2^26 .. 2^28: within the noise, not adopted)
 // and, with 2048-point tiles in the sweep (SWEEP_TLS=10,11,12,13, profiles/r04_sweep_single_cold_tl11.log: a latency-bound
 // transform wants workgroups, 2^16 points are 16 tiles of 4096): f64 2^16 14.6 -> 11.4, 2^17 16.1 -> 14.3; f32 2^14 9.5 -> 8.4,
@@ -235,7 +235,9 @@ inline void heuristic_plan(unsigned L, bool latency, std::vector<unsigned> &lrs,
 // profiles/r04_placement_probe.log) -- the sweep's own gains of 6 .. 11 % at f64 2^26 and f32 2^26 / 2^28 did not survive.
 // Measured with one transform in flight -- with four or more of 2^19 / 2^20 points the older latency / mid plans win again
 // (2^19 x 8: 48 GSamples/s on the wave plan against 69 on the two-pass latency plan, profiles/r02_sweep_batch_wave_quad.log),
-// so Planner::plan_for uses it for batch <= 2.  Returns false where the latency plan already is the right one.
+// so Planner::plan_for uses it for ONE or two transforms -- and for small batches of small ones (up to four transforms, or
+// 2^19 points in flight, below 2^21 points: profiles/r04_small_batch_plans.log).  Returns false where the latency plan
+// already is the right one.
 template <typename T>
 inline bool single_plan(unsigned L, std::vector<unsigned> &lrs, std::vector<unsigned> &tls, unsigned &lp) {
     struct E {
