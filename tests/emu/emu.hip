@@ -104,8 +104,13 @@ static int emu_r2c_fused(const T *in, unsigned log_n, T *ore, T *oim, const unsi
     const unsigned tile_log = tile_log_and_lp & 0xff;
     unsigned lp = (tile_log_and_lp >> 8) ? (tile_log_and_lp >> 8) : 4;
     std::vector<unsigned> lrs(lrs_in, lrs_in + np_in), tls(1, tile_log);
-    if (lrs.empty()) {
-        if (tile_log != 1 || !single_plan<T>(L, lrs, tls, lp)) heuristic_plan<T>(L, tile_log <= 1, lrs, tls, lp);
+    if (lrs.empty()) {  // 0 = latency plan, 1 = the plan for one transform, 2 / 3 = the R2C tables (real_plan / real_batch_plan)
+        if (tile_log == 2 || tile_log == 3) {
+            if (!(tile_log == 2 ? real_plan<T>(L, false, lrs, tls, lp) : real_batch_plan<T>(L, false, lrs, tls, lp))) return 3;
+            lp &= ~kFuseBelow;
+        } else if (tile_log != 1 || !single_plan<T>(L, lrs, tls, lp)) {
+            heuristic_plan<T>(L, tile_log <= 1, lrs, tls, lp);
+        }
     }
     std::vector<PassGeom> ps;
     if (!make_passes(L, lrs, tls, ps, lp, sizeof(T))) return 1;
@@ -176,8 +181,13 @@ static int emu_c2r_fused(const T *ire, const T *iim, unsigned log_n, T *out, siz
     const unsigned tile_log = tile_log_and_lp & 0xff;
     unsigned lp = (tile_log_and_lp >> 8) ? (tile_log_and_lp >> 8) : 4;
     std::vector<unsigned> lrs(lrs_in, lrs_in + np_in), tls(1, tile_log);
-    if (lrs.empty()) {
-        if (tile_log != 1 || !single_plan<T>(L, lrs, tls, lp)) heuristic_plan<T>(L, tile_log <= 1, lrs, tls, lp);
+    if (lrs.empty()) {  // 0 = latency plan, 1 = the plan for one transform, 2 / 3 = the C2R tables (real_plan / real_batch_plan)
+        if (tile_log == 2 || tile_log == 3) {
+            if (!(tile_log == 2 ? real_plan<T>(L, true, lrs, tls, lp) : real_batch_plan<T>(L, true, lrs, tls, lp))) return 3;
+            lp &= ~kFuseBelow;
+        } else if (tile_log != 1 || !single_plan<T>(L, lrs, tls, lp)) {
+            heuristic_plan<T>(L, tile_log <= 1, lrs, tls, lp);
+        }
     }
     std::vector<PassGeom> ps;
     if (!make_passes(L, lrs, tls, ps, lp, sizeof(T))) return 1;

@@ -312,7 +312,7 @@ def test_r2c_fused_last_pass_vs_oracle_and_rfft(emu, oracle, log_n):
         o_re, o_im = np.zeros(n // 2 + 1, dtype), np.zeros(n // 2 + 1, dtype)
         (oracle.r2c_fft_f64 if dtype == np.float64 else oracle.r2c_fft_f32)(x.copy(), o_re, o_im)
         ref = np.fft.rfft(x.astype(np.float64))
-        for lrs, tl, lp in [((), 0, 0), ((), 1, 0)] + forced:
+        for lrs, tl, lp in [((), 0, 0), ((), 1, 0), ((), 2, 0), ((), 3, 0)] + forced:  # 2 / 3: plan.hpp's real_plan / real_batch_plan
             rc, ore, oim = _emu_r2c(emu, x, lrs, tl, lp)
             if rc == 3:  # this plan's last pass has no fused form (wave / quad tiles, 32 points per thread)
                 continue
@@ -358,7 +358,7 @@ def test_c2r_fused_first_pass_vs_oracle_and_irfft(emu, oracle, log_n):
         want = np.zeros(n, dtype)
         (oracle.c2r_fft_f64 if dtype == np.float64 else oracle.c2r_fft_f32)(ire.copy(), iim.copy(), want)
         ref = np.fft.irfft(ire.astype(np.float64) + 1j * iim.astype(np.float64), n)
-        for lrs, tl, lp in [((), 0, 0), ((), 1, 0), ((), 14, 0)] + forced:
+        for lrs, tl, lp in [((), 0, 0), ((), 1, 0), ((), 2, 0), ((), 3, 0), ((), 14, 0)] + forced:  # 2 / 3: real_plan / real_batch_plan
             rc, out = _emu_c2r(emu, ire, iim, n, lrs=lrs, tile_log=tl, points_log=lp)
             if rc in (1, 3):  # not a plan of this type (32768-point tiles are f32 only) / first pass without a fused form
                 continue
