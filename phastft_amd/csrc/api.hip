@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <memory>
 #include <mutex>
@@ -365,7 +366,9 @@ template <typename T> struct Planner {
     // R2C only: the plan of ONE (or two) real transforms where plan.hpp (real_plan) has a better one than the C2C choice;
     // passes_c2r_one is C2R's (from the same table, else the reversal above)
     std::vector<PassDesc> passes_r2c;
-    bool r2c_table_fuses = false;  // passes_r2c was ranked with its fused last pass below the general threshold (plan.hpp: kFuseBelow)
+    // passes_r2c was ranked with its fused last pass below the general threshold (plan.hpp: kFuseBelow); written by
+    // make_c2r_plans after the plan swap, read by calls in flight on other threads
+    std::atomic<bool> r2c_table_fuses{false};
     void *d_small_tw = nullptr;
     // elements per transform and plane in the scratch: n plus the padding of the intermediate layouts (plan.hpp:
     // scratch_pad_bytes); the largest over this planner's plans, fixed before the first allocation grows past it
