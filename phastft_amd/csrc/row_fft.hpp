@@ -58,25 +58,45 @@ template <typename T, int LR, int LC, int LP> struct RowBody {
     static size_t lds_bytes() { return (size_t)2 * PLANE * sizeof(T) + TWR * sizeof(cx); }
 
     // flat element f = i*NT + tid of the tile (i < P): transform f >> LR of the tile, point f & (ROWS - 1)
+    // (The layout is decided ONCE, outside the unrolled loop, and the pairs' swap after all loads of a chunk are out: with
+    //  the branch inside the loop every 16-byte pair load was followed by s_waitcnt vmcnt(0) -- sixteen serialised round trips
+    //  to memory per thread, one 4096-point transform on Complex<T> pairs 11.7 us where the planar one takes 8.6,
+    //  profiles/r04_interleaved_ladder.log.)
     PHAST_HD static void load_flat(const RowArgs &a, unsigned tile, int tid, Regs &r) {
         const unsigned long long xf0 = (unsigned long long)tile << LC;
-        static_for<0, P>([&](auto i) {
-            const unsigned f = (unsigned)(decltype(i)::value * NT + tid);
-            const unsigned long long xf = xf0 + (f >> LR);
-            T re = (T)0, im = (T)0;
-            if (xf < a.batch) {
-                const size_t off = (size_t)xf * a.in_dist + (f & (ROWS - 1));
-                if (!a.in_interleaved) {
+        if (!a.in_interleaved) {
+            static_for<0, P>([&](auto i) {
+                const unsigned f = (unsigned)(decltype(i)::value * NT + tid);
+                const unsigned long long xf = xf0 + (f >> LR);
+                T re = (T)0, im = (T)0;
+                if (xf < a.batch) {
+                    const size_t off = (size_t)xf * a.in_dist + (f & (ROWS - 1));
                     re = reinterpret_cast<const T *>(a.in_re)[off];
                     im = reinterpret_cast<const T *>(a.in_im)[off];
-                } else {
-                    const cx v = reinterpret_cast<const cx *>(a.in_re)[off];
-                    re = a.in_interleaved == 2 ? v.y : v.x;
-                    im = a.in_interleaved == 2 ? v.x : v.y;
                 }
-            }
-            r.re[i] = re;
-            r.im[i] = im;
+                r.re[i] = re;
+                r.im[i] = im;
+            });
+            return;
+        }
+        const bool swapped = a.in_interleaved == 2;
+        constexpr int CH = P < 8 ? P : 8;  // pairs in flight per chunk (their registers come on top of the tile's own)
+        static_for<0, P / CH>([&](auto c) {
+            constexpr int C0 = decltype(c)::value * CH;
+            cx v[CH];
+            static_for<0, CH>([&](auto i) {
+                const unsigned f = (unsigned)((C0 + decltype(i)::value) * NT + tid);
+                const unsigned long long xf = xf0 + (f >> LR);
+                cx w;
+                w.x = w.y = (T)0;
+                if (xf < a.batch) w = reinterpret_cast<const cx *>(a.in_re)[(size_t)xf * a.in_dist + (f & (ROWS - 1))];
+                v[decltype(i)::value] = w;
+            });
+            static_for<0, CH>([&](auto i) {
+                constexpr int I = decltype(i)::value;
+                r.re[C0 + I] = swapped ? v[I].y : v[I].x;
+                r.im[C0 + I] = swapped ? v[I].x : v[I].y;
+            });
         });
     }
     PHAST_HD static void park(T *st_re, T *st_im, int tid, const Regs &r) {
