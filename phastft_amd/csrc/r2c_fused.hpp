@@ -105,18 +105,26 @@ template <typename T, int LR, int LC, int LP, bool SEQ> struct R2cLastBody {
         gi *= (T)0.5;
         const cx *twu = reinterpret_cast<const cx *>(f.twu);
         const unsigned kl = Body::krow_lane(tid);
-        static_for<0, P>([&](auto q) {
-            constexpr int Q = decltype(q)::value;
-            const cx u = twu[kl + Body::template krow_const<Q>()];
-            const T wr = gr * u.x - gi * u.y, wi = gr * u.y + gi * u.x;  // 0.5 W_N^(kc M + g)
-            const T a_ = z.re[Q], b_ = z.im[Q], c_ = p.re[Q], d_ = -p.im[Q];
-            const T s_re = (T)0.5 * (a_ + c_), s_im = (T)0.5 * (b_ - d_);
-            const T t_re = b_ + d_, t_im = c_ - a_;
-            const T wzr = wr * t_re - wi * t_im, wzi = wr * t_im + wi * t_re;
-            z.re[Q] = s_re + wzr;
-            z.im[Q] = s_im + wzi;
-            p.re[Q] = s_re - wzr;
-            p.im[Q] = wzi - s_im;
+        // the table entries FOUR at a time: asked for one by one, next to their use, every one of the P loads (L1 / L2 hits, but
+        // a few hundred cycles each) was waited for before the next went out -- 16 waits in a row per tile pair in the ISA of
+        // the 16-point f64 kernels (round 4); two tiles' points leave no room for all P entries at once
+        constexpr int UC = P < 4 ? P : 4;
+        static_for<0, P / UC>([&](auto c) {
+            constexpr int C0 = decltype(c)::value * UC;
+            cx u[UC];
+            static_for<0, UC>([&](auto i) { u[decltype(i)::value] = twu[kl + Body::template krow_const<C0 + decltype(i)::value>()]; });
+            static_for<0, UC>([&](auto i) {
+                constexpr int I = decltype(i)::value, Q = C0 + I;
+                const T wr = gr * u[I].x - gi * u[I].y, wi = gr * u[I].y + gi * u[I].x;  // 0.5 W_N^(kc M + g)
+                const T a_ = z.re[Q], b_ = z.im[Q], c_ = p.re[Q], d_ = -p.im[Q];
+                const T s_re = (T)0.5 * (a_ + c_), s_im = (T)0.5 * (b_ - d_);
+                const T t_re = b_ + d_, t_im = c_ - a_;
+                const T wzr = wr * t_re - wi * t_im, wzi = wr * t_im + wi * t_re;
+                z.re[Q] = s_re + wzr;
+                z.im[Q] = s_im + wzi;
+                p.re[Q] = s_re - wzr;
+                p.im[Q] = wzi - s_im;
+            });
         });
     }
 
