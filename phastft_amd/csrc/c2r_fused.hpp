@@ -95,17 +95,25 @@ template <typename T, int LR, int LC, int LP, bool SEQ> struct C2rFirstBody {
                 m_re[I] = (qr + mrow)[moff];
                 m_im[I] = (qi + mrow)[moff];
             });
-            static_for<0, CH>([&](auto i) {
-                constexpr int I = decltype(i)::value, J = C0 + I;
-                const cx u = twu[J * M];
-                const T c_h = gr * u.x - gi * u.y, s_h = gr * u.y + gi * u.x;  // 0.5 W_N^(n M + g)
-                // algorithms/r2c.rs:263-433 (the arithmetic of r2c.hip: c2r_preprocess_kernel)
-                const T re_first = x_re[I], im_first = x_im[I], re_second = m_re[I], im_second = -m_im[I];
-                const T zx_re = (T)0.5 * (re_first + re_second), zx_im = (T)0.5 * (im_first + im_second);
-                const T dr = re_first - re_second, di = im_first - im_second;
-                const T zy_re = c_h * dr + s_h * di, zy_im = c_h * di - s_h * dr;
-                r.re[J] = zx_im + zy_re;  // positional re = z_im, positional im = z_re: the swap-trick inverse
-                r.im[J] = zx_re - zy_im;
+            // (the rows' table entries four at a time -- as r2c_fused.hpp: untangle; all CH of them with the data loads cost the
+            //  16-point f64 kernels a wave of occupancy, 139 -> 211 VGPRs: measured in kernel_resources.json, round 4)
+            constexpr int UC = CH < 4 ? CH : 4;
+            static_for<0, CH / UC>([&](auto g) {
+                constexpr int G0 = decltype(g)::value * UC;
+                cx tu[UC];
+                static_for<0, UC>([&](auto i) { tu[decltype(i)::value] = twu[(C0 + G0 + decltype(i)::value) * M]; });
+                static_for<0, UC>([&](auto i) {
+                    constexpr int I = G0 + decltype(i)::value, J = C0 + I;
+                    const cx u = tu[decltype(i)::value];
+                    const T c_h = gr * u.x - gi * u.y, s_h = gr * u.y + gi * u.x;  // 0.5 W_N^(n M + g)
+                    // algorithms/r2c.rs:263-433 (the arithmetic of r2c.hip: c2r_preprocess_kernel)
+                    const T re_first = x_re[I], im_first = x_im[I], re_second = m_re[I], im_second = -m_im[I];
+                    const T zx_re = (T)0.5 * (re_first + re_second), zx_im = (T)0.5 * (im_first + im_second);
+                    const T dr = re_first - re_second, di = im_first - im_second;
+                    const T zy_re = c_h * dr + s_h * di, zy_im = c_h * di - s_h * dr;
+                    r.re[J] = zx_im + zy_re;  // positional re = z_im, positional im = z_re: the swap-trick inverse
+                    r.im[J] = zx_re - zy_im;
+                });
             });
         });
     }
