@@ -160,7 +160,7 @@ def plan_of(plan_text: str, kind: str) -> str:
 
 
 def plan_kind(P, n: int, batch: int, plan_text: str, dtype: str = "f64") -> str:
-    """which of the planner's plans a call with `batch` transforms runs (api.hip: Planner::plan_for)"""
+    """which of the planner's plans a call with `batch` transforms runs (planner_plans.hpp: Planner::plan_for)"""
     if "latency=" not in plan_text:
         return "throughput" if "throughput=" in plan_text else "one-pass"
     import re
@@ -169,7 +169,7 @@ def plan_kind(P, n: int, batch: int, plan_text: str, dtype: str = "f64") -> str:
     tl = max(t.bit_length() - 1 for t in tiles)
     work = 1 << (25 if tl >= 15 else 24 if tl >= 13 else 22)   # plan.hpp: throughput_work
     if "f32" in dtype and tl < 15:
-        work *= 2                                                # api.hip: plan_for
+        work *= 2                                                # planner_plans.hpp: plan_for
     if batch * n >= work:
         return "throughput"
     if batch <= 2 and "single=" in plan_text:

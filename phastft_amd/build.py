@@ -23,7 +23,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libphastft_hip.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
-UNITS = ["api", "tile_f64_a", "tile_f64_bc", "tile_f64_bc_wide", "tile_f32_a", "tile_f32_bc", "tile_f32_bc_wide", "tile_f64_r2c", "tile_f32_r2c", "tile_f64_c2r", "tile_f32_c2r", "wave_f64", "quad_f64", "small_fft", "bitrev", "r2c", "fill", "probe", "twiddle"]
+UNITS = ["c_abi", "tile_f64_a", "tile_f64_bc", "tile_f64_bc_wide", "tile_f32_a", "tile_f32_bc", "tile_f32_bc_wide", "tile_f64_r2c", "tile_f32_r2c", "tile_f64_c2r", "tile_f32_c2r", "wave_f64", "quad_f64", "small_fft", "bitrev", "r2c", "fill", "probe", "twiddle"]
 # built only with --experimental (lib/libphastft_hip_exp.so): the f32 wave tiles -- parity-tested, slower than the generic tiles
 # for every plan measured (profiles/r03_sweep_wave_f32.log), so not part of the product library
 EXPERIMENTAL_UNITS = ["wave_f32"]
@@ -43,9 +43,28 @@ def hipcc() -> str:
     return exe
 
 
-def _deps() -> list[str]:
-    return [os.path.join(SRC, f) for f in os.listdir(SRC) if f.endswith((".hpp", ".h"))] + \
-           [os.path.join(INCLUDE, "phastft_hip.h"), os.path.abspath(__file__)]
+def _deps(src: str | None = None) -> list[str]:
+    """What a unit's object depends on: the headers it includes (followed recursively through csrc/ and include/), the
+    public header and this file -- a change to the host side (planner*.hpp ...) does not recompile the kernel units."""
+    fixed = [os.path.join(INCLUDE, "phastft_hip.h"), os.path.abspath(__file__)]
+    if src is None:
+        return [os.path.join(SRC, f) for f in os.listdir(SRC) if f.endswith((".hpp", ".h"))] + fixed
+    seen, todo = set(), [src]
+    while todo:
+        f = todo.pop()
+        try:
+            text = open(f).read()
+        except OSError:
+            continue
+        for inc in re.findall(r'^\s*#\s*include\s+"([^"]+)"', text, flags=re.M):
+            for base in (os.path.dirname(f), SRC, INCLUDE):
+                cand = os.path.normpath(os.path.join(base, inc))
+                if os.path.exists(cand):
+                    if cand not in seen:
+                        seen.add(cand)
+                        todo.append(cand)
+                    break
+    return sorted(seen) + fixed
 
 
 def _stale(target: str, sources: list[str]) -> bool:
@@ -58,7 +77,7 @@ def _stale(target: str, sources: list[str]) -> bool:
 def _compile(unit: str, force: bool, trace: bool = False, extra: tuple = (), tag: str = "") -> str:
     src = os.path.join(SRC, unit + ".hip")
     obj = os.path.join(OBJ, unit + ("_trace" if trace else "") + tag + ".o")
-    if force or _stale(obj, [src] + _deps()):
+    if force or _stale(obj, [src] + _deps(src)):
         cmd = [hipcc(), *FLAGS, *(["-DPHAST_TRACE"] if trace else []), *UNIT_FLAGS.get(unit, []), *extra, "-I", INCLUDE, "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

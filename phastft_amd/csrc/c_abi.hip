@@ -1,0 +1,353 @@
+// c_abi.hip -- the C ABI of include/phastft_hip.h over the host side of libphastft_hip.so (planner.hpp, exec.hpp, host_api.hpp).
+// Mirrors PhastFT's public surface (lib.rs:143-226, planner.rs, options.rs,
+// algorithms/r2c.rs:521-895, algorithms/bravo.rs:303-324); see DESIGN.md for the mapping.
+//
+// There is NO CPU fallback in this library: without a gfx950 device every compute entry point returns
+// PHAST_ERR_NO_DEVICE / PHAST_ERR_HIP.
+#include "host_util.hpp"
+#include "workspace.hpp"
+#include "planner.hpp"
+#include "planner_pool.hpp"
+#include "planner_plans.hpp"
+#include "exec.hpp"
+#include "planner_r2c.hpp"
+#include "entry.hpp"
+#include "host_api.hpp"
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+using namespace phast;
+
+struct phast_planner_dit64 : Planner<double> {};
+struct phast_planner_dit32 : Planner<float> {};
+struct phast_planner_r2c64 : PlannerR2c<double> {};
+struct phast_planner_r2c32 : PlannerR2c<float> {};
+
+// W_N^(r*c) tables of a four-step split (twiddle.hip)
+template <typename T> struct TwiddleGrid {
+    unsigned log_n = 0, tw_bits = 1;
+    int device = -1;
+    void *d_tw3 = nullptr;
+    ~TwiddleGrid() {
+        DeviceGuard on(device);
+        if (d_tw3) hipFree(d_tw3);
+    }
+    int init(size_t n) {
+        int rc = ensure_device(&device);
+        if (rc) return rc;
+        log_n = ilog2(n);
+        if (log_n > 32) return PHAST_ERR_INVALID_ARG;  // exponents are reduced to 32 bits
+        tw_bits = tw3_bits_for(log_n);
+        if (((size_t)3 << tw_bits) * sizeof(cx_t<T>) > (size_t)160 * 1024) return PHAST_ERR_INVALID_ARG;  // tables must fit one CU's LDS
+        return upload<T>(host_tw3<T>(log_n, tw_bits), &d_tw3);
+    }
+    int apply(T *d_re, T *d_im, size_t rows, size_t cols, size_t row_pitch, size_t row0, size_t col0, hipStream_t s) const {
+        if ((!d_re || !d_im) && rows * cols) return PHAST_ERR_INVALID_ARG;
+        if (row_pitch < cols) return PHAST_ERR_INVALID_ARG;
+        PHAST_ON_DEVICE(device);
+        TwiddleGridArgs a{};
+        a.re = d_re;
+        a.im = d_im;
+        a.tw3 = d_tw3;
+        a.rows = rows;
+        a.cols = cols;
+        a.row_pitch = row_pitch;
+        a.row0 = row0;
+        a.col0 = col0;
+        a.log_n = log_n;
+        a.tw_bits = tw_bits;
+        PHAST_HIP(launch_twiddle_grid<T>(a, s));
+        return PHAST_OK;
+    }
+};
+struct phast_twiddle_grid64 : TwiddleGrid<double> {};
+struct phast_twiddle_grid32 : TwiddleGrid<float> {};
+
+extern "C" {
+
+const char *phast_strerror(int code) {
+    switch (code) {
+    case PHAST_OK: return "ok";
+    case PHAST_ERR_NOT_POW2: return "assertion failed: num_points > 0 && num_points.is_power_of_two()";
+    case PHAST_ERR_LEN_MISMATCH: return "assertion `left == right` failed: reals.len() == imags.len()";
+    case PHAST_ERR_PLANNER_SIZE: return "assertion `left == right` failed: log_n == planner.log_n";
+    case PHAST_ERR_R2C_N: return "n must be a power of 2 >= 4";
+    case PHAST_ERR_R2C_INPUT_LEN: return "input length must match planner size";
+    case PHAST_ERR_R2C_OUT_RE_LEN: return "output_re must have length N/2 + 1";
+    case PHAST_ERR_R2C_OUT_IM_LEN: return "output_im must have length N/2 + 1";
+    case PHAST_ERR_C2R_OUTPUT_LEN: return "output length must match planner size";
+    case PHAST_ERR_C2R_IN_RE_LEN: return "input_re must have length N/2 + 1";
+    case PHAST_ERR_C2R_IN_IM_LEN: return "input_im must have length N/2 + 1";
+    case PHAST_ERR_C2R_SCRATCH_RE: return "scratch_re must have length N/2";
+    case PHAST_ERR_C2R_SCRATCH_IM: return "scratch_im must have length N/2";
+    case PHAST_ERR_ALLOC: return "host allocation failed";
+    case PHAST_ERR_HIP: return "HIP runtime error (see phast_last_hip_error)";
+    case PHAST_ERR_NO_DEVICE: return "no HIP device visible: libphastft_hip has no CPU fallback";
+    case PHAST_ERR_INVALID_ARG: return "invalid argument";
+    default: return "unknown error";
+    }
+}
+
+const char *phast_last_hip_error(void) { return g_hip_err; }
+
+int phast_hip_graph_upload(void *graph_exec, void *stream) {
+    if (!graph_exec) return PHAST_ERR_INVALID_ARG;
+    PHAST_HIP(hipGraphUpload(static_cast<hipGraphExec_t>(graph_exec), static_cast<hipStream_t>(stream)));
+    return PHAST_OK;
+}
+
+int phast_stream_probe_dev(const void *d_a, void *d_b, size_t bytes, int reps, double *out_gbps, void *stream) {
+    if (!d_a || !d_b || !out_gbps || reps < 1 || bytes < ((size_t)1 << 20) || (bytes & 15)) return PHAST_ERR_INVALID_ARG;
+    int dev = 0;
+    int rc = ensure_device(&dev);
+    if (rc) return rc;
+    PHAST_HIP(stream_probe(d_a, d_b, bytes, reps, cus_of(dev), out_gbps, static_cast<hipStream_t>(stream)));
+    return PHAST_OK;
+}
+
+void phast_debug_set_guard_bytes(size_t bytes) { g_guard_bytes = (bytes + 255) & ~(size_t)255; }
+
+void phast_debug_set_wg_per_cu(int wg_per_cu) { g_wg_per_cu_override = wg_per_cu; }
+void phast_debug_set_trace(unsigned long long *d_trace) { g_trace = d_trace; }
+
+int phast_device_info(char *name, size_t name_len, int *compute_units, size_t *lds_per_block,
+                      size_t *global_mem_bytes) {
+    int rc = ensure_device();
+    if (rc) return rc;
+    int dev = 0;
+    PHAST_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    PHAST_HIP(hipGetDeviceProperties(&prop, dev));
+    if (name && name_len) std::snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (lds_per_block) *lds_per_block = prop.sharedMemPerBlock;
+    if (global_mem_bytes) *global_mem_bytes = prop.totalGlobalMem;
+    return PHAST_OK;
+}
+
+void phast_options_default(phast_options *out) {
+    if (!out) return;
+    out->multithreaded_bit_reversal = 0;
+    out->smallest_parallel_chunk_size = 16384;
+}
+
+int phast_options_guess(size_t input_size, phast_options *out) {
+    if (!out) return PHAST_ERR_INVALID_ARG;
+    if (input_size == 0) return PHAST_ERR_NOT_POW2;  // usize::ilog2(0) panics (options.rs:40)
+    phast_options_default(out);
+    out->multithreaded_bit_reversal = ilog2(input_size) >= 16;
+    return PHAST_OK;
+}
+
+#define PHAST_PLANNER_API(SFX, T)                                                                                  \
+    int phast_planner_dit##SFX##_new(size_t n, phast_planner_dit##SFX **out) {                                     \
+        return planner_new(n, out);                                                                                \
+    }                                                                                                              \
+    int phast_planner_dit##SFX##_with_mode(size_t n, int mode, phast_planner_dit##SFX **out) {                     \
+        if (mode != PHAST_MODE_HEURISTIC && mode != PHAST_MODE_TUNE) return PHAST_ERR_INVALID_ARG;                 \
+        return planner_new(n, out);                                                                                \
+    }                                                                                                              \
+    void phast_planner_dit##SFX##_free(phast_planner_dit##SFX *p) { delete p; }                                    \
+    size_t phast_planner_dit##SFX##_device_bytes(const phast_planner_dit##SFX *p) {                                \
+        return p ? p->device_bytes() : 0;                                                                          \
+    }                                                                                                              \
+    int phast_planner_dit##SFX##_debug_check_guards(const phast_planner_dit##SFX *p, size_t *bad_bytes) {          \
+        if (!p || !bad_bytes) return PHAST_ERR_INVALID_ARG;                                                        \
+        return p->check_guards(bad_bytes);                                                                         \
+    }                                                                                                              \
+    int phast_planner_dit##SFX##_describe(const phast_planner_dit##SFX *p, char *buf, size_t len) {                \
+        return describe_to<T>(p, buf, len);                                                                        \
+    }                                                                                                              \
+    int phast_planner_dit##SFX##_reserve_batch(phast_planner_dit##SFX *p, size_t max_batch) {                      \
+        if (!p || max_batch == 0) return PHAST_ERR_INVALID_ARG;                                                    \
+        PHAST_ON_DEVICE(p->device);                                                                                \
+        p->reserve = max_batch;                                                                                    \
+        Planner<T>::Lease L;                                                                                       \
+        int rc = p->check_out(L, nullptr, 2);                                                                      \
+        if (rc) return rc;                                                                                         \
+        L.stream = nullptr; /* check_out waited for the workspace: whatever is retired below is idle */          \
+        size_t cap;                                                                                                \
+        return p->ensure_scratch(L, max_batch, &cap);                                                              \
+    }                                                                                                              \
+    int phast_planner_dit##SFX##_set_plan(phast_planner_dit##SFX *p, const unsigned *lr, const unsigned *tl,       \
+                                          size_t np, unsigned points_log) {                                        \
+        return set_plan_c<T>(p, lr, tl, np, points_log);                                                           \
+    }                                                                                                              \
+    int phast_planner_dit##SFX##_time_passes(const phast_planner_dit##SFX *p, T *d_re, T *d_im, size_t batch,       \
+                                             size_t dist, int reps, float *pass_ms, int *n_passes, void *stream) { \
+        return time_passes<T>(p, d_re, d_im, batch, dist, reps, pass_ms, n_passes,                                 \
+                              static_cast<hipStream_t>(stream));                                                   \
+    }                                                                                                              \
+    int phast_planner_r2c##SFX##_new(size_t n, phast_planner_r2c##SFX **out) {                                     \
+        return r2c_planner_new(n, out);                                                                            \
+    }                                                                                                              \
+    void phast_planner_r2c##SFX##_free(phast_planner_r2c##SFX *p) { delete p; }                                    \
+    int phast_planner_r2c##SFX##_time_passes(const phast_planner_r2c##SFX *p, const T *d_in, T *d_ore, T *d_oim,    \
+                                             size_t batch, size_t in_dist, size_t out_dist, int reps,              \
+                                             float *pass_ms, int *n_passes, void *stream) {                        \
+        return time_passes_r2c<T>(p, d_in, d_ore, d_oim, batch, in_dist, out_dist, reps, pass_ms, n_passes,        \
+                                  static_cast<hipStream_t>(stream));                                               \
+    }                                                                                                              \
+    int phast_planner_r2c##SFX##_time_c2r_passes(const phast_planner_r2c##SFX *p, const T *d_ire, const T *d_iim,   \
+                                                 T *d_out, size_t batch, size_t in_dist, size_t out_dist, int reps, \
+                                                 float *pass_ms, int *n_passes, void *stream) {                     \
+        return time_passes_c2r<T>(p, d_ire, d_iim, d_out, batch, in_dist, out_dist, reps, pass_ms, n_passes,        \
+                                  static_cast<hipStream_t>(stream));                                               \
+    }                                                                                                              \
+    int phast_planner_r2c##SFX##_set_inner_plan(phast_planner_r2c##SFX *p, const unsigned *lr, const unsigned *tl,  \
+                                                size_t np, unsigned points_log) {                                  \
+        if (!p) return PHAST_ERR_INVALID_ARG;                                                                      \
+        PlannerR2c<T> *q = (p->dit.passes.empty() && p->twin) ? p->twin.get() : p;                                 \
+        int rc = set_plan_c<T>(&q->dit, lr, tl, np, points_log);                                                   \
+        if (rc == PHAST_OK && np == 0 && !q->dit.passes.empty()) rc = q->dit.make_c2r_plans();                     \
+        return rc;                                                                                                 \
+    }                                                                                                              \
+    int phast_planner_r2c##SFX##_describe(const phast_planner_r2c##SFX *p, char *buf, size_t len) {                \
+        if (!p || !buf || !len) return PHAST_ERR_INVALID_ARG;                                                      \
+        std::string s = p->dit.describe();                                                                         \
+        if (p->twin) s += " | one transform: " + p->twin->dit.describe();                                          \
+        std::snprintf(buf, len, "%s", s.c_str());                                                                  \
+        return PHAST_OK;                                                                                           \
+    }
+
+PHAST_PLANNER_API(64, double)
+PHAST_PLANNER_API(32, float)
+
+#define PHAST_FFT_API(SFX, FS, T)                                                                                   \
+    int phast_fft_##SFX##_dit(T *re, size_t re_len, T *im, size_t im_len, int direction) {                          \
+        return fft_host_noplanner<T>(re, re_len, im, im_len, direction);                                            \
+    }                                                                                                               \
+    int phast_fft_##SFX##_dit_with_planner(T *re, size_t re_len, T *im, size_t im_len, int direction,               \
+                                           const phast_planner_dit##SFX *pl) {                                      \
+        return fft_host<T>(re, re_len, im, im_len, direction, pl);                                                  \
+    }                                                                                                               \
+    int phast_fft_##SFX##_dit_with_planner_and_opts(T *re, size_t re_len, T *im, size_t im_len, int direction,      \
+                                                    const phast_planner_dit##SFX *pl, const phast_options *opts) {  \
+        if (!opts) return PHAST_ERR_INVALID_ARG;                                                                    \
+        return fft_host<T>(re, re_len, im, im_len, direction, pl);                                                  \
+    }                                                                                                               \
+    int phast_fft_##SFX##_dit_dev(T *d_re, T *d_im, size_t n, size_t batch, size_t dist, int direction,             \
+                                  const phast_planner_dit##SFX *pl, void *stream) {                                 \
+        return fft_dev<T>(d_re, d_im, n, batch, dist, direction, pl, static_cast<hipStream_t>(stream));             \
+    }                                                                                                               \
+    int phast_fft_##SFX##_dit_many_dev(T *const *d_re, T *const *d_im, size_t count, size_t n, int direction,       \
+                                       const phast_planner_dit##SFX *pl, void *stream) {                            \
+        return fft_dev_many<T>(d_re, d_im, count, n, direction, pl, static_cast<hipStream_t>(stream));              \
+    }                                                                                                               \
+    int phast_fft_##SFX##_dit_strided_dev(T *d_re, T *d_im, size_t n, size_t batch, size_t dist, size_t stride,     \
+                                          int direction, const phast_planner_dit##SFX *pl, void *stream) {          \
+        return fft_strided_dev<T>(d_re, d_im, n, batch, dist, stride, direction, pl,                                \
+                                  static_cast<hipStream_t>(stream));                                                \
+    }                                                                                                               \
+    int phast_fft_##SFX##_dit_strided_tw_dev(T *d_re, T *d_im, size_t n, size_t batch, size_t dist, size_t stride,  \
+                                             int direction, const phast_planner_dit##SFX *pl, size_t tw_n,          \
+                                             size_t tw_col0, void *stream) {                                        \
+        if (tw_n == 0) return PHAST_ERR_INVALID_ARG;                                                                \
+        return fft_strided_dev<T>(d_re, d_im, n, batch, dist, stride, direction, pl,                                \
+                                  static_cast<hipStream_t>(stream), tw_n, tw_col0);                                 \
+    }                                                                                                               \
+    int phast_fft_##SFX##_interleaved(T *signal, size_t n, int direction) {                                         \
+        std::shared_ptr<Planner<T>> pl; /* lib.rs:121: a planner per call -- kept, see PlannerCache */             \
+        int rc = PlannerCache<Planner<T>>::instance().get(                                                          \
+            n, sizeof(T), [](size_t m, Planner<T> **o) { return planner_new(m, o); }, &pl);                         \
+        if (rc) return rc;                                                                                          \
+        return fft_interleaved_host<T>(signal, n, direction, pl.get());                                             \
+    }                                                                                                               \
+    int phast_fft_##SFX##_interleaved_with_planner(T *signal, size_t n, int direction,                              \
+                                                   const phast_planner_dit##SFX *pl) {                              \
+        return fft_interleaved_host<T>(signal, n, direction, pl);                                                   \
+    }                                                                                                               \
+    int phast_fft_##SFX##_interleaved_with_planner_and_opts(T *signal, size_t n, int direction,                     \
+                                                            const phast_planner_dit##SFX *pl,                       \
+                                                            const phast_options *opts) {                            \
+        if (!opts) return PHAST_ERR_INVALID_ARG;                                                                    \
+        return fft_interleaved_host<T>(signal, n, direction, pl);                                                   \
+    }                                                                                                               \
+    int phast_fft_##SFX##_interleaved_dev(T *d_signal, size_t n, size_t batch, size_t dist, int direction,          \
+                                          const phast_planner_dit##SFX *pl, void *stream) {                         \
+        return fft_interleaved_dev<T>(d_signal, n, batch, dist, direction, pl, static_cast<hipStream_t>(stream));   \
+    }                                                                                                               \
+    int phast_bit_rev_##FS(T *data, size_t len, unsigned log_n) { return bitrev_host<T>(data, len, log_n); }        \
+    int phast_bit_rev_##FS##_dev(T *d, unsigned log_n, size_t batch, size_t dist, void *stream) {                   \
+        if (!d || log_n > 31 || (batch > 1 && dist < ((size_t)1 << log_n))) return PHAST_ERR_INVALID_ARG;           \
+        int rc = ensure_device();                                                                                   \
+        if (rc) return rc;                                                                                          \
+        PHAST_HIP(launch_bitrev<T>(d, log_n, batch, dist, static_cast<hipStream_t>(stream)));                       \
+        return PHAST_OK;                                                                                            \
+    }                                                                                                               \
+    int phast_r2c_fft_##FS(const T *in, size_t in_len, T *ore, size_t ore_len, T *oim, size_t oim_len) {            \
+        std::shared_ptr<PlannerR2c<T>> pl; /* r2c.rs:522: planner from input_re.len() */                           \
+        int rc = PlannerCache<PlannerR2c<T>>::instance().get(                                                       \
+            in_len, sizeof(T), [](size_t m, PlannerR2c<T> **o) { return r2c_planner_new(m, o); }, &pl);             \
+        if (rc) return rc;                                                                                          \
+        return r2c_host<T>(in, in_len, ore, ore_len, oim, oim_len, pl.get());                                       \
+    }                                                                                                               \
+    int phast_r2c_fft_##FS##_with_planner(const T *in, size_t in_len, T *ore, size_t ore_len, T *oim,               \
+                                          size_t oim_len, const phast_planner_r2c##SFX *pl) {                       \
+        return r2c_host<T>(in, in_len, ore, ore_len, oim, oim_len, pl);                                             \
+    }                                                                                                               \
+    int phast_r2c_fft_##FS##_dev(const T *d_in, T *d_ore, T *d_oim, size_t batch, size_t in_dist, size_t out_dist,  \
+                                 const phast_planner_r2c##SFX *pl, void *stream) {                                  \
+        if (!pl || !d_in || !d_ore || !d_oim) return PHAST_ERR_INVALID_ARG;                                         \
+        if (batch > 1 && (in_dist < pl->n || out_dist < pl->n / 2 + 1)) return PHAST_ERR_INVALID_ARG;               \
+        return pl->r2c(d_in, d_ore, d_oim, batch, in_dist, out_dist, static_cast<hipStream_t>(stream));             \
+    }                                                                                                               \
+    int phast_c2r_fft_##FS(const T *ire, size_t ire_len, const T *iim, size_t iim_len, T *out, size_t out_len) {    \
+        std::shared_ptr<PlannerR2c<T>> pl; /* r2c.rs:696: planner from output.len() */                             \
+        int rc = PlannerCache<PlannerR2c<T>>::instance().get(                                                       \
+            out_len, sizeof(T), [](size_t m, PlannerR2c<T> **o) { return r2c_planner_new(m, o); }, &pl);            \
+        if (rc) return rc;                                                                                          \
+        return c2r_host<T>(ire, ire_len, iim, iim_len, out, out_len, pl.get(), false, 0, 0);                        \
+    }                                                                                                               \
+    int phast_c2r_fft_##FS##_with_planner(const T *ire, size_t ire_len, const T *iim, size_t iim_len, T *out,       \
+                                          size_t out_len, const phast_planner_r2c##SFX *pl) {                       \
+        return c2r_host<T>(ire, ire_len, iim, iim_len, out, out_len, pl, false, 0, 0);                              \
+    }                                                                                                               \
+    int phast_c2r_fft_##FS##_with_planner_and_scratch(const T *ire, size_t ire_len, const T *iim, size_t iim_len,   \
+                                                      T *out, size_t out_len, const phast_planner_r2c##SFX *pl,     \
+                                                      T *sre, size_t sre_len, T *sim, size_t sim_len) {             \
+        (void)sre;                                                                                                  \
+        (void)sim;                                                                                                  \
+        return c2r_host<T>(ire, ire_len, iim, iim_len, out, out_len, pl, true, sre_len, sim_len);                   \
+    }                                                                                                               \
+    int phast_c2r_fft_##FS##_dev(const T *d_ire, const T *d_iim, T *d_out, size_t batch, size_t in_dist,            \
+                                 size_t out_dist, const phast_planner_r2c##SFX *pl, void *stream) {                 \
+        if (!pl || !d_ire || !d_iim || !d_out) return PHAST_ERR_INVALID_ARG;                                        \
+        if (batch > 1 && (in_dist < pl->n / 2 + 1 || out_dist < pl->n)) return PHAST_ERR_INVALID_ARG;               \
+        return pl->c2r(d_ire, d_iim, d_out, batch, in_dist, out_dist, static_cast<hipStream_t>(stream));            \
+    }                                                                                                               \
+    int phast_fill_##FS##_dev(T *d_re, T *d_im, size_t n, size_t batch, size_t dist, unsigned long long seed,       \
+                              unsigned long long first_id, void *stream) {                                          \
+        if (!d_re) return PHAST_ERR_INVALID_ARG;                                                                    \
+        int rc = ensure_device();                                                                                   \
+        if (rc) return rc;                                                                                          \
+        PHAST_HIP(launch_fill<T>(d_re, d_im, n, batch, dist, seed, first_id, static_cast<hipStream_t>(stream)));    \
+        return PHAST_OK;                                                                                            \
+    }                                                                                                               \
+    int phast_digest_##FS##_dev(const T *d_re, const T *d_im, size_t n, size_t batch, size_t dist, size_t probe,    \
+                                double *d_digest, void *stream) {                                                   \
+        if (!d_re || !d_im || !d_digest) return PHAST_ERR_INVALID_ARG;                                              \
+        int rc = ensure_device();                                                                                   \
+        if (rc) return rc;                                                                                          \
+        PHAST_HIP(launch_digest<T>(d_re, d_im, n, batch, dist, probe, d_digest, static_cast<hipStream_t>(stream))); \
+        return PHAST_OK;                                                                                            \
+    }
+
+PHAST_FFT_API(64, f64, double)
+PHAST_FFT_API(32, f32, float)
+
+#define PHAST_TWIDDLE_API(SFX, T)                                                                                   \
+    int phast_twiddle_grid##SFX##_new(size_t n, phast_twiddle_grid##SFX **out) {                                    \
+        return planner_new(n, out);                                                                                 \
+    }                                                                                                               \
+    void phast_twiddle_grid##SFX##_free(phast_twiddle_grid##SFX *g) { delete g; }                                   \
+    int phast_twiddle_grid##SFX##_apply_dev(const phast_twiddle_grid##SFX *g, T *d_re, T *d_im, size_t rows,        \
+                                            size_t cols, size_t row_pitch, size_t row0, size_t col0, void *stream) { \
+        if (!g) return PHAST_ERR_INVALID_ARG;                                                                       \
+        return g->apply(d_re, d_im, rows, cols, row_pitch, row0, col0, static_cast<hipStream_t>(stream));           \
+    }
+PHAST_TWIDDLE_API(64, double)
+PHAST_TWIDDLE_API(32, float)
+
+}  // extern "C"

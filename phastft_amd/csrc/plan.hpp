@@ -1,4 +1,4 @@
-// plan.hpp -- host-only planning shared by the library (api.hip) and the CPU emulator (tests/emu/emu.hip):
+// plan.hpp -- host-only planning shared by the library (planner.hpp) and the CPU emulator (tests/emu/emu.hip):
 // twiddle tables in long double, the factorisation of N = 2^L into tile passes, and the address
 // geometry of every pass.  GPU counterpart of PlannerDit*::with_mode (planner.rs:65-100) -- but the
 // tables here are O(N^(1/3)) small (three-level factored twiddles) instead of the reference's 2(N-64)
@@ -123,7 +123,7 @@ inline bool shape_exists(unsigned lr, unsigned lc, unsigned lp, size_t elem_byte
 }
 
 constexpr unsigned kWaveTiles = 0x10;  // flag in a plan's points-per-thread code, see make_passes
-constexpr unsigned kFuseBelow = 0x20;  // real_plan only: ranked WITH the fused R2C last pass below the general threshold (api.hip: fuse_pays)
+constexpr unsigned kFuseBelow = 0x20;  // real_plan only: ranked WITH the fused R2C last pass below the general threshold (planner.hpp: fuse_pays)
 
 // Padding of the planner's scratch.  The intermediate arrays between the passes are the one part of the data whose layout
 // is ours: S[r][q] (two passes) / S[u][r][q] (three).  With power-of-two pitches the rows a tile reads in the next pass are
@@ -178,7 +178,7 @@ inline void heuristic_plan(unsigned L, bool latency, std::vector<unsigned> &lrs,
     lrs.clear();
     tls.assign(1, 12);
     lp = 4;
-    if (L < kSmallMaxLog) return;  // (L = kSmallMaxLog: the multi-pass twin of the one-pass kernel's largest size, api.hip)
+    if (L < kSmallMaxLog) return;  // (L = kSmallMaxLog: the multi-pass twin of the one-pass kernel's largest size, planner.hpp)
     auto split = [&](unsigned np) {
         lrs.clear();
         for (unsigned i = 0; i < np; ++i) lrs.push_back(L / np + (i < L % np ? 1 : 0));  // balanced, larger first
@@ -244,7 +244,7 @@ inline bool single_plan(unsigned L, std::vector<unsigned> &lrs, std::vector<unsi
         unsigned L, a, b, c, ta, tb, tc, lp;  // c = 0: two passes
     };
     constexpr unsigned W = kWaveTiles;  // 64 x 16 wave tiles (wave_fft.hpp) and the four-wave 256 x 16 pass (quad_fft.hpp)
-    static const E f64[] = {{13, 6, 7, 0, 10, 11, 0, 3 | W},  // (8192 points: Planner::twin, api.hip)
+    static const E f64[] = {{13, 6, 7, 0, 10, 11, 0, 3 | W},  // (8192 points: Planner::twin, planner.hpp)
                             {14, 6, 8, 0, 10, 12, 0, 4 | W},  {15, 7, 8, 0, 10, 12, 0, 3 | W},  {16, 8, 8, 0, 11, 11, 0, 3},      {17, 8, 9, 0, 11, 12, 0, 3},
                             {19, 6, 7, 6, 10, 11, 10, 3 | W}, {20, 6, 8, 6, 10, 12, 10, 3 | W},
                             {21, 6, 8, 7, 10, 12, 12, 3 | W}, {22, 8, 7, 7, 13, 12, 13, 4},     {23, 7, 9, 7, 13, 12, 13, 4},     {24, 8, 9, 7, 13, 12, 13, 4},

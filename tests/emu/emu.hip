@@ -538,7 +538,7 @@ template <typename T> static int check_tables(int *n_entries) {
                 ++bad;
             } else if (sizeof(T) == 4) {
                 for (const PassGeom &g : geo)
-                    if (g.wave) {  // the product library refuses f32 wave tiles (api.hip: set_plan)
+                    if (g.wave) {  // the product library refuses f32 wave tiles (planner_plans.hpp: set_plan)
                         std::fprintf(stderr, "plan table %d, f32, L = %u: asks for wave tiles\n", which, L);
                         ++bad;
                     }

@@ -1,6 +1,6 @@
 """Seeded random sweep over what the parametrised parity tests fix by hand: size, batch, distance between transforms,
 precision and direction of device-resident batches -- in particular the batch counts around which the planner switches
-between its single / latency / mid / throughput plans (api.hip: Planner::plan_for) -- each against numpy's pocketfft
+between its single / latency / mid / throughput plans (planner_plans.hpp: Planner::plan_for) -- each against numpy's pocketfft
 in double precision (forward unnormalised, reverse scaled by 1/N: algorithms/dit.rs:297-331)."""
 import numpy as np
 import pytest

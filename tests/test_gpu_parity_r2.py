@@ -73,7 +73,7 @@ def _check_shard(gpu, oracle, batch, sample_ids, seed=0xCAFE, first_id=0):
 def test_config5_shard_1024_x_2p20(gpu, oracle):
     """BASELINE configs[4], one GPU's share: 1024 contiguous f64 transforms of 2^20 in one batched call -- once with
     the default scratch (16 GiB: the whole shard in one chunk) and once with a 4 GiB scratch, which holds 256 of them so
-    that the chunk loop of Planner::exec (api.hip) runs four times: first / chunk-boundary / last transforms against the
+    that the chunk loop of Planner::exec (exec.hpp) runs four times: first / chunk-boundary / last transforms against the
     oracle, Parseval and the digest on all."""
     _check_shard(gpu, oracle, 1024, (0, 255, 256, 511, 512, 767, 768, 1023))
     old = os.environ.get("PHAST_SCRATCH_MB")

@@ -710,7 +710,7 @@ print("CACHE_OK %.3f ms per planner-less call at 2^20" % (1e3 * (time.perf_count
 @pytest.mark.parametrize("cache", ["1", "0"])
 def test_planner_less_calls_keep_their_planners(gpu, tmp_path, cache):
     """lib.rs:181 / r2c.rs:522,696 make a planner per call; here the most recently used planners are kept per type, size and
-    device (api.hip: PlannerCache) -- invisible to the caller: bit-identical results call after call and across
+    device (host_api.hpp: PlannerCache) -- invisible to the caller: bit-identical results call after call and across
     evictions, errors neither cached nor poisoning; PHAST_PLANNER_CACHE=0 is the per-call behaviour."""
     script = tmp_path / "cache.py"
     script.write_text(_PLANNER_CACHE)
@@ -756,7 +756,7 @@ print("ZC_DONE")
 
 def test_small_host_slice_calls_zero_copy_equals_staged(gpu, tmp_path):
     """Host-slice calls up to the pinned limit (1 MiB of planes) let the kernels read and write the planner's pinned mirror
-    over PCIe (api.hip: fft_host) instead of staging through device memory: the same kernels on the same values --
+    over PCIe (host_api.hpp: fft_host) instead of staging through device memory: the same kernels on the same values --
     bit-identical to the staged path (PHAST_ZERO_COPY=0), forward and back, both types, N = 2 ... 2^17 (one- and multi-pass
     plans, either side of the limit); one-kernel R2C / C2R likewise."""
     script = tmp_path / "zc.py"

@@ -362,7 +362,7 @@ def test_r2c_f64_large_fused_vs_c2c_route(gpu, k):
 @pytest.mark.parametrize("dt", ["f64", "f32"])
 def test_one_transform_of_8192_points_runs_the_multi_pass_twin(gpu, oracle, dt):
     """N = 2^13 is the largest size of the one-pass kernel (one workgroup per transform): right for batches, 16 us for ONE
-    transform.  A planner of that size keeps a multi-pass twin (`api.hip: Planner::twin`) that serves up to 128 transforms --
+    transform.  A planner of that size keeps a multi-pass twin (`planner.hpp: Planner::twin`) that serves up to 128 transforms --
     through every entry point, so that the same transform gives the same bits from host slices, device pointers and a captured
     graph; larger batches keep the one-pass kernel (other factorisation: equal to rounding level).  The real transforms of 16384 points
     (inner length 8192) follow the same rule."""

@@ -41,7 +41,7 @@ PY
     echo "$EXE3"
     ;;
 run)
-    # Two passes, each under its own timeout.  The planner cache of the planner-less entry points (api.hip: PlannerCache)
+    # Two passes, each under its own timeout.  The planner cache of the planner-less entry points (host_api.hpp: PlannerCache)
     # is deliberately never destroyed, so with it on, the leak checker's scan at exit walks the device mappings the cached
     # planners still hold and does not come back (15 minutes of a GPU box were lost finding that out): leaks are checked
     # with the cache off (every planner is freed before exit, as before round 3), the cache itself with the leak check off.
