@@ -92,19 +92,45 @@ template <typename T> struct Slice {
 PHASTFT_PLANNER(PlannerDit64, phast_planner_dit64,
                 explicit PlannerDit64(std::size_t num_points, PlannerMode mode = PlannerMode::Heuristic) {
                     check(phast_planner_dit64_with_mode(num_points, static_cast<int>(mode), &h_));
-                } static PlannerDit64 with_mode(std::size_t n, PlannerMode mode) { return PlannerDit64(n, mode); },
+                } static PlannerDit64 with_mode(std::size_t n, PlannerMode mode) { return PlannerDit64(n, mode); }
+                /* PlannerMode::Tune for another batch size / call kind (PHAST_TUNE_C2C, PHAST_TUNE_C2C_INTERLEAVED) */
+                phast_tune_report tune(std::size_t batch = 1, int kind = PHAST_TUNE_C2C) {
+                    phast_tune_report r{};
+                    check(phast_planner_dit64_tune(h_, batch, kind, &r));
+                    return r;
+                },
                 phast_planner_dit64_free)
 PHASTFT_PLANNER(PlannerDit32, phast_planner_dit32,
                 explicit PlannerDit32(std::size_t num_points, PlannerMode mode = PlannerMode::Heuristic) {
                     check(phast_planner_dit32_with_mode(num_points, static_cast<int>(mode), &h_));
-                } static PlannerDit32 with_mode(std::size_t n, PlannerMode mode) { return PlannerDit32(n, mode); },
+                } static PlannerDit32 with_mode(std::size_t n, PlannerMode mode) { return PlannerDit32(n, mode); }
+                /* PlannerMode::Tune for another batch size / call kind (PHAST_TUNE_C2C, PHAST_TUNE_C2C_INTERLEAVED) */
+                phast_tune_report tune(std::size_t batch = 1, int kind = PHAST_TUNE_C2C) {
+                    phast_tune_report r{};
+                    check(phast_planner_dit32_tune(h_, batch, kind, &r));
+                    return r;
+                },
                 phast_planner_dit32_free)
 // planner.rs:164-212
 PHASTFT_PLANNER(PlannerR2c64, phast_planner_r2c64,
-                explicit PlannerR2c64(std::size_t n) { check(phast_planner_r2c64_new(n, &h_)); },
+                explicit PlannerR2c64(std::size_t n, PlannerMode mode = PlannerMode::Heuristic) {
+                    check(phast_planner_r2c64_with_mode(n, static_cast<int>(mode), &h_));
+                }
+                phast_tune_report tune(std::size_t batch = 1, int kind = PHAST_TUNE_R2C) {
+                    phast_tune_report r{};
+                    check(phast_planner_r2c64_tune(h_, batch, kind, &r));
+                    return r;
+                },
                 phast_planner_r2c64_free)
 PHASTFT_PLANNER(PlannerR2c32, phast_planner_r2c32,
-                explicit PlannerR2c32(std::size_t n) { check(phast_planner_r2c32_new(n, &h_)); },
+                explicit PlannerR2c32(std::size_t n, PlannerMode mode = PlannerMode::Heuristic) {
+                    check(phast_planner_r2c32_with_mode(n, static_cast<int>(mode), &h_));
+                }
+                phast_tune_report tune(std::size_t batch = 1, int kind = PHAST_TUNE_R2C) {
+                    phast_tune_report r{};
+                    check(phast_planner_r2c32_tune(h_, batch, kind, &r));
+                    return r;
+                },
                 phast_planner_r2c32_free)
 #undef PHASTFT_PLANNER
 

@@ -51,7 +51,7 @@ extern "C" {
 #define PHAST_FORWARD 1  /* Direction::Forward */
 #define PHAST_REVERSE (-1) /* Direction::Reverse */
 #define PHAST_MODE_HEURISTIC 0 /* PlannerMode::Heuristic */
-#define PHAST_MODE_TUNE 1      /* PlannerMode::Tune (accepted, ignored -- as planner.rs:65 `_mode`) */
+#define PHAST_MODE_TUNE 1      /* PlannerMode::Tune: the planner measures its plans on the device at plan time (below) */
 
 /* ---- status codes: one per reference assert ---- */
 #define PHAST_OK 0
@@ -107,6 +107,45 @@ int phast_planner_dit32_describe(const phast_planner_dit32 *p, char *buf, size_t
 /* optional: size the scratch for `max_batch` transforms in flight (default 1); realloc on demand otherwise */
 int phast_planner_dit64_reserve_batch(phast_planner_dit64 *p, size_t max_batch);
 int phast_planner_dit32_reserve_batch(phast_planner_dit32 *p, size_t max_batch);
+/* HIP graphs: the workspaces that captured calls work in are kept until the planner is freed (the library cannot know when a
+ * graph dies).  A long-lived planner that is captured again and again may hand them back -- the caller promises that every
+ * graph captured on this planner so far is gone.  Returns the device bytes released. */
+size_t phast_planner_dit64_release_graph_workspaces(phast_planner_dit64 *p);
+size_t phast_planner_dit32_release_graph_workspaces(phast_planner_dit32 *p);
+
+/* ---- PlannerMode::Tune (planner.rs:18-32: "benchmarks both paths at plan time and picks whichever is faster, at the cost of
+ * additional planning time") ----
+ * The reference chooses between two codelet paths; here the choice is the PLAN -- how N = 2^L is cut into 2 or 3 passes, the
+ * tile size of every pass, points per thread, wave / quad tiles, and for r2c whether the untangle rides in the last pass.
+ * PHAST_MODE_HEURISTIC: static rules ranked on an MI355X (plus built-in / imported wisdom, below), zero planning overhead.
+ * PHAST_MODE_TUNE (`_with_mode`): as the reference's -- the planner times every plan that exists for its length on the
+ * current device, for ONE transform per call (the reference's only case), and keeps the fastest if it beats the static rule
+ * by more than 3 %.  Costs 0.1 .. 3 s (under 1 s at N = 2^20).  Nothing to measure for N <= 4096 (one kernel).
+ * `_tune` does the same for another batch size or call kind on an existing planner: a result covers batches in
+ * (2^(b-1), 2^b] around `batch_hint`.  Tuning is synchronous, allocates a ring of input sets (up to 1.25 GiB, or three sets)
+ * and must not run under stream capture.  Results are bit-identical for a given plan; which plan runs changes the last bits
+ * (same tolerance: every plan is tested against the oracle). */
+#define PHAST_TUNE_C2C 0             /* fft_*_dit* on planar arrays */
+#define PHAST_TUNE_C2C_INTERLEAVED 1 /* the Complex<T> forms (lib.rs:41-140) */
+#define PHAST_TUNE_R2C 2             /* r2c_fft_*   (PlannerR2c* only) */
+#define PHAST_TUNE_C2R 3             /* c2r_fft_*   (PlannerR2c* only) */
+typedef struct phast_tune_report {
+    int adopted;             /* 1: a measured plan replaced the static rule's for this (kind, batch bucket) */
+    unsigned candidates;     /* plans timed */
+    float us_heuristic;      /* per call, static rule's plan (median of the interleaved rounds) */
+    float us_best;           /* per call, the plan now in force */
+    double seconds;          /* what the tuning run took */
+    char plan[96];           /* "a,b[,c]@ta,tb[,tc]:p<points>[w][ fused]" or "heuristic" / "one pass" */
+} phast_tune_report;
+int phast_planner_dit64_tune(phast_planner_dit64 *p, size_t batch_hint, int kind, phast_tune_report *report /* or NULL */);
+int phast_planner_dit32_tune(phast_planner_dit32 *p, size_t batch_hint, int kind, phast_tune_report *report);
+/* Wisdom: what tuning runs found, as text (one line per type / kind / log2 length / batch bucket, csrc/wisdom.hpp).  Planners
+ * created after an import start with the plans it names (entries measured on a device with another CU count are ignored).
+ * PHAST_WISDOM=<path>: read at first use, rewritten after every tuning run.  The library also carries built-in wisdom measured
+ * on an MI355X (PHAST_BUILTIN_WISDOM=0 turns it off).  No device needed for these three calls. */
+int phast_wisdom_export(char *buf, size_t buf_len, size_t *needed /* bytes incl. NUL, or NULL */);
+int phast_wisdom_import(const char *text); /* PHAST_ERR_INVALID_ARG: not a wisdom text */
+void phast_wisdom_forget(void);            /* everything but the built-in layer */
 
 /* ---- planner.rs:164-212 ---- */
 typedef struct phast_planner_r2c64 phast_planner_r2c64; /* PlannerR2c64 */
@@ -115,6 +154,12 @@ int phast_planner_r2c64_new(size_t n, phast_planner_r2c64 **out); /* planner.rs:
 void phast_planner_r2c64_free(phast_planner_r2c64 *p);
 int phast_planner_r2c32_new(size_t n, phast_planner_r2c32 **out);
 void phast_planner_r2c32_free(phast_planner_r2c32 *p);
+/* (no reference counterpart: PlannerR2c*::new has no mode -- the same switch as PlannerDit*::with_mode, for r2c_fft and c2r_fft
+ * of one transform per call; `_tune`: kind = PHAST_TUNE_R2C or PHAST_TUNE_C2R) */
+int phast_planner_r2c64_with_mode(size_t n, int mode, phast_planner_r2c64 **out);
+int phast_planner_r2c32_with_mode(size_t n, int mode, phast_planner_r2c32 **out);
+int phast_planner_r2c64_tune(phast_planner_r2c64 *p, size_t batch_hint, int kind, phast_tune_report *report);
+int phast_planner_r2c32_tune(phast_planner_r2c32 *p, size_t batch_hint, int kind, phast_tune_report *report);
 
 /* ---- C2C, host slices: lib.rs:143-226, algorithms/dit.rs:263,338 ----
  * The forms without a planner argument make one per call in the reference (lib.rs:181,224).  Here a planner owns device

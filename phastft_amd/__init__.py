@@ -37,7 +37,7 @@ import numpy as np
 from . import _lib
 
 __all__ = [
-    "Direction", "PlannerMode", "Options", "PhastPanic", "PhastHipError",
+    "Direction", "PlannerMode", "TuneKind", "wisdom_export", "wisdom_import", "wisdom_forget", "Options", "PhastPanic", "PhastHipError",
     "PlannerDit64", "PlannerDit32", "PlannerR2c64", "PlannerR2c32",
     "fft_64_dit", "fft_32_dit", "fft_64_dit_with_planner", "fft_32_dit_with_planner",
     "fft_64_dit_with_planner_and_opts", "fft_32_dit_with_planner_and_opts",
@@ -59,10 +59,45 @@ class Direction(enum.IntEnum):
 
 
 class PlannerMode(enum.IntEnum):
-    """planner.rs:24-32 (``Tune`` is accepted and ignored, as in the reference: planner.rs:65)."""
+    """planner.rs:24-32.  ``Tune``: the planner times the plans that exist for its length on the device at plan time and
+    keeps the fastest (one transform per call; :meth:`PlannerDit64.tune` for other batch sizes and call kinds)."""
 
     Heuristic = 0
     Tune = 1
+
+
+class TuneKind(enum.IntEnum):
+    """PHAST_TUNE_* (include/phastft_hip.h): which call a tuning run measures."""
+
+    C2C = 0
+    C2CInterleaved = 1
+    R2C = 2
+    C2R = 3
+
+
+def _tune(fn, handle, batch: int, kind: "TuneKind") -> dict:
+    rep = _lib.PhastTuneReport()
+    _check(fn(handle, C.c_size_t(batch), C.c_int(int(kind)), C.byref(rep)))
+    return {"adopted": bool(rep.adopted), "candidates": int(rep.candidates), "us_heuristic": float(rep.us_heuristic),
+            "us_best": float(rep.us_best), "seconds": float(rep.seconds), "plan": rep.plan.decode()}
+
+
+def wisdom_export() -> str:
+    """Everything tuning runs (and imports, and the built-in layer) know, as text (csrc/wisdom.hpp)."""
+    need = C.c_size_t(0)
+    _check(_lib.lib().phast_wisdom_export(None, C.c_size_t(0), C.byref(need)))
+    buf = C.create_string_buffer(need.value)
+    _check(_lib.lib().phast_wisdom_export(buf, C.c_size_t(need.value), None))
+    return buf.value.decode()
+
+
+def wisdom_import(text: str) -> None:
+    """Planners created afterwards start with the plans the text names."""
+    _check(_lib.lib().phast_wisdom_import(text.encode()))
+
+
+def wisdom_forget() -> None:
+    _lib.lib().phast_wisdom_forget()
 
 
 ERR_INVALID_ARG = 16  # PHAST_ERR_INVALID_ARG (include/phastft_hip.h): e.g. a shape the strided kernels do not cover
@@ -209,6 +244,15 @@ class _PlannerDit:
     def reserve_batch(self, max_batch: int) -> None:
         _check(getattr(_lib.lib(), f"phast_planner_dit{self._sfx}_reserve_batch")(self._h, C.c_size_t(max_batch)))
 
+    def release_graph_workspaces(self) -> int:
+        """Hand back the workspaces captured graphs worked in (every graph captured on this planner must be gone)."""
+        return int(getattr(_lib.lib(), f"phast_planner_dit{self._sfx}_release_graph_workspaces")(self._h))
+
+    def tune(self, batch: int = 1, kind: TuneKind = TuneKind.C2C) -> dict:
+        """PlannerMode::Tune for ``batch`` transforms per call (covers batches in (2^(b-1), 2^b]) and the call kind
+        ``TuneKind.C2C`` / ``C2CInterleaved``: measures on the device, installs the winner, returns the report."""
+        return _tune(getattr(_lib.lib(), f"phast_planner_dit{self._sfx}_tune"), self._h, batch, kind)
+
     def set_plan(self, log_rows=(), tile_log=12, points_log=4) -> None:
         """Force the pass factorisation (tuning hook); ``()`` restores the heuristic.  ``tile_log`` is
         log2(points per tile): one int for all passes or one per pass; ``points_log`` = log2(points per thread)."""
@@ -246,15 +290,24 @@ class _PlannerR2c:
     _sfx = "64"
     _dtype = np.float64
 
-    def __init__(self, n: int):
+    def __init__(self, n: int, mode: PlannerMode = PlannerMode.Heuristic):
         self._h = C.c_void_p()
-        _check(getattr(_lib.lib(), f"phast_planner_r2c{self._sfx}_new")(C.c_size_t(n), C.byref(self._h)))
+        _check(getattr(_lib.lib(), f"phast_planner_r2c{self._sfx}_with_mode")(C.c_size_t(n), C.c_int(int(mode)), C.byref(self._h)))
         self.n = n
 
     @classmethod
     def new(cls, n: int):
         """planner.rs:194"""
         return cls(n)
+
+    @classmethod
+    def with_mode(cls, n: int, mode: PlannerMode):
+        """(no reference counterpart: the PlannerDit*::with_mode switch for the real transforms)"""
+        return cls(n, mode)
+
+    def tune(self, batch: int = 1, kind: TuneKind = TuneKind.R2C) -> dict:
+        """PlannerMode::Tune for ``batch`` real transforms per call, ``TuneKind.R2C`` or ``TuneKind.C2R``."""
+        return _tune(getattr(_lib.lib(), f"phast_planner_r2c{self._sfx}_tune"), self._h, batch, kind)
 
     def __del__(self):
         try:

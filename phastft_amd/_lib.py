@@ -39,6 +39,10 @@ phast_debug_set_guard_bytes phast_planner_dit64_debug_check_guards phast_planner
 phast_planner_r2c64_time_passes phast_planner_r2c32_time_passes phast_planner_r2c64_time_c2r_passes phast_planner_r2c32_time_c2r_passes phast_planner_r2c64_describe phast_planner_r2c32_describe phast_planner_r2c64_set_inner_plan phast_planner_r2c32_set_inner_plan
 phast_twiddle_grid64_new phast_twiddle_grid32_new phast_twiddle_grid64_free phast_twiddle_grid32_free
 phast_twiddle_grid64_apply_dev phast_twiddle_grid32_apply_dev
+phast_planner_dit64_release_graph_workspaces phast_planner_dit32_release_graph_workspaces
+phast_planner_dit64_tune phast_planner_dit32_tune phast_planner_r2c64_tune phast_planner_r2c32_tune
+phast_planner_r2c64_with_mode phast_planner_r2c32_with_mode
+phast_wisdom_export phast_wisdom_import phast_wisdom_forget
 """.split()
 
 
@@ -46,6 +50,13 @@ class PhastOptions(C.Structure):
     """`phast_options` (options.rs:10-24)."""
 
     _fields_ = [("multithreaded_bit_reversal", C.c_int), ("smallest_parallel_chunk_size", C.c_size_t)]
+
+
+class PhastTuneReport(C.Structure):
+    """`phast_tune_report` (include/phastft_hip.h: PlannerMode::Tune)."""
+
+    _fields_ = [("adopted", C.c_int), ("candidates", C.c_uint), ("us_heuristic", C.c_float), ("us_best", C.c_float),
+                ("seconds", C.c_double), ("plan", C.c_char * 96)]
 
 
 _lib = None
@@ -74,6 +85,10 @@ def lib() -> C.CDLL:
     l.phast_planner_dit32_device_bytes.restype = C.c_size_t
     for name in SYMBOLS:
         getattr(l, name)  # AttributeError here = header/library mismatch
+    l.phast_planner_dit64_release_graph_workspaces.restype = C.c_size_t
+    l.phast_planner_dit32_release_graph_workspaces.restype = C.c_size_t
+    l.phast_wisdom_forget.restype = None
+    l.phast_wisdom_import.argtypes = [C.c_char_p]
     l.phast_options_default.restype = None
     l.phast_debug_set_wg_per_cu.restype = None
     l.phast_debug_set_trace.restype = None

@@ -13,6 +13,7 @@
 #include "planner_r2c.hpp"
 #include "entry.hpp"
 #include "host_api.hpp"
+#include "tune.hpp"
 
 // ================================================================================================
 // C ABI
@@ -64,7 +65,38 @@ template <typename T> struct TwiddleGrid {
 struct phast_twiddle_grid64 : TwiddleGrid<double> {};
 struct phast_twiddle_grid32 : TwiddleGrid<float> {};
 
+// PlannerMode::Tune at construction: one transform per call (the reference's only case) -- unless wisdom already holds a
+// measurement for this type, length, kind and device
+template <typename P> static int tune_new(P *p, int kind) {
+    const size_t eb = sizeof(typename P::value_type);
+    if (WisdomStore::instance().lookup(eb, kind, p->wisdom_log_n(), 0, cus_of(p->device_of()), nullptr)) return PHAST_OK;
+    return p->tune(kind, 1, nullptr);
+}
+template <typename R> static void report_to_c(const R &r, phast_tune_report *rep) {
+    if (!rep) return;
+    rep->adopted = r.adopted;
+    rep->candidates = r.candidates;
+    rep->us_heuristic = r.us_heuristic;
+    rep->us_best = r.us_best;
+    rep->seconds = r.seconds;
+    std::snprintf(rep->plan, sizeof rep->plan, "%s", r.plan.c_str());
+}
+
 extern "C" {
+
+int phast_wisdom_export(char *buf, size_t buf_len, size_t *needed) {
+    const std::string text = WisdomStore::instance().export_text();
+    if (needed) *needed = text.size() + 1;
+    if (!buf || buf_len == 0) return needed ? PHAST_OK : PHAST_ERR_INVALID_ARG;
+    if (buf_len < text.size() + 1) return PHAST_ERR_INVALID_ARG;
+    std::memcpy(buf, text.c_str(), text.size() + 1);
+    return PHAST_OK;
+}
+int phast_wisdom_import(const char *text) {
+    if (!text) return PHAST_ERR_INVALID_ARG;
+    return WisdomStore::instance().import_text(text, 2) == 0 ? PHAST_OK : PHAST_ERR_INVALID_ARG;
+}
+void phast_wisdom_forget(void) { WisdomStore::instance().forget(); }
 
 const char *phast_strerror(int code) {
     switch (code) {
@@ -146,7 +178,20 @@ int phast_options_guess(size_t input_size, phast_options *out) {
     }                                                                                                              \
     int phast_planner_dit##SFX##_with_mode(size_t n, int mode, phast_planner_dit##SFX **out) {                     \
         if (mode != PHAST_MODE_HEURISTIC && mode != PHAST_MODE_TUNE) return PHAST_ERR_INVALID_ARG;                 \
-        return planner_new(n, out);                                                                                \
+        int rc = planner_new(n, out);                                                                              \
+        if (rc == PHAST_OK && mode == PHAST_MODE_TUNE) rc = tune_new(*out, kC2C);                                  \
+        if (rc != PHAST_OK && out && *out) {                                                                       \
+            delete *out;                                                                                           \
+            *out = nullptr;                                                                                        \
+        }                                                                                                          \
+        return rc;                                                                                                 \
+    }                                                                                                              \
+    int phast_planner_dit##SFX##_tune(phast_planner_dit##SFX *p, size_t batch, int kind, phast_tune_report *rep) { \
+        if (!p) return PHAST_ERR_INVALID_ARG;                                                                      \
+        Planner<T>::TuneReport r;                                                                                  \
+        int rc = p->tune(kind, batch, &r);                                                                         \
+        if (rc == PHAST_OK) report_to_c(r, rep);                                                                   \
+        return rc;                                                                                                 \
     }                                                                                                              \
     void phast_planner_dit##SFX##_free(phast_planner_dit##SFX *p) { delete p; }                                    \
     size_t phast_planner_dit##SFX##_device_bytes(const phast_planner_dit##SFX *p) {                                \
@@ -161,14 +206,10 @@ int phast_options_guess(size_t input_size, phast_options *out) {
     }                                                                                                              \
     int phast_planner_dit##SFX##_reserve_batch(phast_planner_dit##SFX *p, size_t max_batch) {                      \
         if (!p || max_batch == 0) return PHAST_ERR_INVALID_ARG;                                                    \
-        PHAST_ON_DEVICE(p->device);                                                                                \
-        p->reserve = max_batch;                                                                                    \
-        Planner<T>::Lease L;                                                                                       \
-        int rc = p->check_out(L, nullptr, 2);                                                                      \
-        if (rc) return rc;                                                                                         \
-        L.stream = nullptr; /* check_out waited for the workspace: whatever is retired below is idle */          \
-        size_t cap;                                                                                                \
-        return p->ensure_scratch(L, max_batch, &cap);                                                              \
+        return p->reserve_batch(max_batch);                                                                        \
+    }                                                                                                              \
+    size_t phast_planner_dit##SFX##_release_graph_workspaces(phast_planner_dit##SFX *p) {                          \
+        return p ? p->release_graph_workspaces() : 0;                                                              \
     }                                                                                                              \
     int phast_planner_dit##SFX##_set_plan(phast_planner_dit##SFX *p, const unsigned *lr, const unsigned *tl,       \
                                           size_t np, unsigned points_log) {                                        \
@@ -183,6 +224,24 @@ int phast_options_guess(size_t input_size, phast_options *out) {
         return r2c_planner_new(n, out);                                                                            \
     }                                                                                                              \
     void phast_planner_r2c##SFX##_free(phast_planner_r2c##SFX *p) { delete p; }                                    \
+    int phast_planner_r2c##SFX##_with_mode(size_t n, int mode, phast_planner_r2c##SFX **out) {                     \
+        if (mode != PHAST_MODE_HEURISTIC && mode != PHAST_MODE_TUNE) return PHAST_ERR_INVALID_ARG;                 \
+        int rc = r2c_planner_new(n, out);                                                                          \
+        if (rc == PHAST_OK && mode == PHAST_MODE_TUNE) rc = tune_new(*out, kR2C);                                  \
+        if (rc == PHAST_OK && mode == PHAST_MODE_TUNE) rc = tune_new(*out, kC2R);                                  \
+        if (rc != PHAST_OK && out && *out) {                                                                       \
+            delete *out;                                                                                           \
+            *out = nullptr;                                                                                        \
+        }                                                                                                          \
+        return rc;                                                                                                 \
+    }                                                                                                              \
+    int phast_planner_r2c##SFX##_tune(phast_planner_r2c##SFX *p, size_t batch, int kind, phast_tune_report *rep) { \
+        if (!p) return PHAST_ERR_INVALID_ARG;                                                                      \
+        Planner<T>::TuneReport r;                                                                                  \
+        int rc = p->tune(kind, batch, &r);                                                                         \
+        if (rc == PHAST_OK) report_to_c(r, rep);                                                                   \
+        return rc;                                                                                                 \
+    }                                                                                                              \
     int phast_planner_r2c##SFX##_time_passes(const phast_planner_r2c##SFX *p, const T *d_in, T *d_ore, T *d_oim,    \
                                              size_t batch, size_t in_dist, size_t out_dist, int reps,              \
                                              float *pass_ms, int *n_passes, void *stream) {                        \

@@ -43,14 +43,12 @@ int Planner<T>::exec_strided(T *re, T *im, unsigned s_bits, unsigned sb_bits, do
         sp->grid_log_n = grid_log_n;
         sp->passes.resize(geo.size());
         for (size_t i = 0; i < geo.size(); ++i) static_cast<PassGeom &>(sp->passes[i]) = geo[i];
-        rc = prepare_passes(sp->passes, nullptr);
+        rc = prepare_passes(sp->passes);
         if (rc) return rc;
         std::lock_guard<std::mutex> lk(mu);
         for (const auto &q : strided_plans)  // another thread may have built the same plan meanwhile
             if (q->s == s_bits && q->sb == sb_bits && q->grid_log_n == grid_log_n) plan = q.get();
-        if (plan) {
-            free_passes(sp->passes);
-        } else {
+        if (!plan) {
             strided_plans.push_back(std::move(sp));
             plan = strided_plans.back().get();
         }
@@ -122,7 +120,10 @@ template <typename T>
 int Planner<T>::exec(const void *in_re, const void *in_im, size_t in_dist, unsigned in_mode, void *out_re, void *out_im,
                      size_t out_dist, unsigned out_mode, size_t batch, double scale, hipStream_t stream, PassTimer *timer) const {
     if (batch == 0) return PHAST_OK;
-    if (twin && batch <= twin_max_batch())  // one 8192-point transform: two passes over the whole chip instead of one workgroup
+    // one 8192-point transform: two passes over the whole chip instead of one workgroup -- unless the call is being captured
+    // and the twin has no scratch yet: the one-pass kernel needs none, so a capture without a warm-up call keeps working as
+    // it did before the twin existed
+    if (twin && batch <= twin_max_batch() && !(capturing(stream) && !twin->capture_ready()))
         return twin->exec(in_re, in_im, in_dist, in_mode, out_re, out_im, out_dist, out_mode, batch, scale, stream, timer);
     PHAST_ON_DEVICE(device);
     Lease L;
@@ -141,7 +142,7 @@ int Planner<T>::exec(const void *in_re, const void *in_im, size_t in_dist, unsig
 template <typename T>
 int Planner<T>::exec_in(const Lease &L, const void *in_re, const void *in_im, size_t in_dist, unsigned in_mode, void *out_re,
                         void *out_im, size_t out_dist, unsigned out_mode, size_t batch, double scale, PassTimer *timer,
-                        const R2cFuse *fuse, bool *fused_out, size_t *np_out) const {
+                        const R2cFuse *fuse, bool *fused_out, size_t *np_out, const Choice *forced) const {
     if (fused_out) *fused_out = false;
     if (np_out) *np_out = 1;
     if (batch == 0) return PHAST_OK;
@@ -176,10 +177,11 @@ int Planner<T>::exec_in(const Lease &L, const void *in_re, const void *in_im, si
     const size_t sd = sstride();       // elements per transform and plane in the (padded) scratch
     T *s_re = reinterpret_cast<T *>(L.ws->d_scratch);  // plane layout: all re planes, then all im planes
     T *s_im = s_re + cap * sd;
-    // R2C: fused or not is decided ONCE per call, from the size of a full chunk -- a smaller tail chunk follows the others
-    // (the caller runs the untangle sweep over the whole batch or not at all)
-    const bool r2c_fuse = fuse && in_mode != 3 && fuse_pays(batch < cap ? batch : cap);
-    const std::vector<PassDesc> &passes = in_mode == 3 ? plan_for_c2r(batch) : fuse ? plan_for_r2c(batch, r2c_fuse) : plan_for(batch);
+    // which plan, and (R2C) fused or not: ONE decision per call (Planner::choose) -- or the caller's (a tuning run's candidate)
+    const int kind = in_mode == 3 ? kC2R : fuse ? kR2C : (in_mode || out_mode) ? kC2CI : kC2C;
+    const Choice ch = forced ? *forced : choose(kind, batch, batch < cap ? batch : cap);
+    const bool r2c_fuse = fuse && in_mode != 3 && ch.r2c_fuse;
+    const std::vector<PassDesc> &passes = *ch.passes;
     const size_t np = passes.size();
     if (np_out) *np_out = np;
     for (size_t b0 = 0; b0 < batch; b0 += cap) {

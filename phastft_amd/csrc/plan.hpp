@@ -5,7 +5,10 @@
 // scalars, because a streamed N-entry table would add ~50 % HBM traffic to a bandwidth-bound pass.
 #pragma once
 
+#include <algorithm>
 #include <cmath>
+#include <string>
+#include <utility>
 #include <vector>
 
 #include "common.hpp"
@@ -514,6 +517,140 @@ inline void geom_to_args(const PassGeom &p, unsigned log_n, size_t n_xforms, Til
     ta.cs_bits = ta.cb_bits = 0;
     ta.tiles_per_xform = 1u << (log_n - p.lr - p.lc);
     ta.tiles_total = (unsigned)((size_t)ta.tiles_per_xform * n_xforms);
+}
+
+// ---- plan specifications and the candidate set of a tuning run (PlannerMode::Tune, planner.rs:18-32) ----
+// A plan is written "a,b[,c]@ta,tb[,tc]:p<points per thread>[w]" -- log2(rows) of every pass, log2(points per tile) of every
+// pass, points per thread of the generic tiles, `w` = wave / quad tiles where a pass has their shape (kWaveTiles) -- the
+// notation of the sweep logs in profiles/ and of the wisdom text (wisdom.hpp).
+struct PlanSpec {
+    unsigned np = 0, lr[3] = {0, 0, 0}, tl[3] = {0, 0, 0};
+    unsigned lp = 4;  // log2(points per thread) | kWaveTiles
+    std::vector<unsigned> lrs() const { return std::vector<unsigned>(lr, lr + np); }
+    std::vector<unsigned> tls() const { return std::vector<unsigned>(tl, tl + np); }
+    bool operator==(const PlanSpec &o) const {
+        if (np != o.np || lp != o.lp) return false;
+        for (unsigned i = 0; i < np; ++i)
+            if (lr[i] != o.lr[i] || tl[i] != o.tl[i]) return false;
+        return true;
+    }
+};
+inline std::string spec_to_string(const PlanSpec &s) {
+    std::string out;
+    for (unsigned i = 0; i < s.np; ++i) out += (i ? "," : "") + std::to_string(s.lr[i]);
+    out += "@";
+    for (unsigned i = 0; i < s.np; ++i) out += (i ? "," : "") + std::to_string(s.tl[i]);
+    out += ":p" + std::to_string(1u << (s.lp & 0xfu));
+    if (s.lp & kWaveTiles) out += "w";
+    return out;
+}
+inline bool spec_from_string(const char *t, PlanSpec &s) {
+    s = PlanSpec();
+    auto list = [&](unsigned *dst, unsigned &cnt, char stop) {
+        cnt = 0;
+        for (;;) {
+            if (*t < '0' || *t > '9' || cnt == 3) return false;
+            unsigned v = 0;
+            while (*t >= '0' && *t <= '9') v = v * 10 + (unsigned)(*t++ - '0');
+            if (v > 31) return false;
+            dst[cnt++] = v;
+            if (*t == ',') {
+                ++t;
+                continue;
+            }
+            return *t++ == stop;
+        }
+    };
+    unsigned na = 0, nb = 0;
+    if (!t || !list(s.lr, na, '@') || !list(s.tl, nb, ':') || na != nb || na < 2) return false;
+    s.np = na;
+    if (*t++ != 'p') return false;
+    unsigned pts = 0;
+    while (*t >= '0' && *t <= '9') pts = pts * 10 + (unsigned)(*t++ - '0');
+    if (pts != 8 && pts != 16 && pts != 32) return false;
+    s.lp = pts == 8 ? 3u : pts == 16 ? 4u : 5u;
+    if (*t == 'w') {
+        s.lp |= kWaveTiles;
+        ++t;
+    }
+    return *t == '\0' || *t == ' ' || *t == '\n';
+}
+
+// What a candidate is expected to cost before anything is timed -- only to ORDER the candidates, so that a tuning run cut
+// short by its budget has seen the likely ones: a pass moves 4 * sizeof(T) bytes per point at the copy rate of its row width
+// (>= 256-byte rows 5.0 TB/s, 128 bytes 4.4, 64 bytes 3.3, 32 bytes 2.0) plus a kernel boundary.
+inline double plan_model_us(const std::vector<PassGeom> &ps, unsigned L, size_t batch, size_t elem_bytes) {
+    double us = 0;
+    const double points = (double)batch * (double)(1ull << L);
+    const double bytes = 4.0 * (double)elem_bytes * points;
+    for (const PassGeom &p : ps) {
+        const unsigned row = (unsigned)elem_bytes << p.lc;
+        const double tbps = row >= 256 ? 5.0 : row >= 128 ? 4.4 : row >= 64 ? 3.3 : 2.0;
+        // a launch with fewer threads than the chip holds (256 CUs x 512) is latency-bound: fewer points per thread help
+        const double threads = points / (double)(1u << p.lp);
+        const double fill = threads < 131072.0 ? std::sqrt(131072.0 / threads) : 1.0;
+        us += 1.5 + fill * bytes / (tbps * 1e6);
+    }
+    return us;
+}
+
+// Every plan of a 2^L-point transform that exists as kernels: 2 or 3 passes, tile FFTs of 64 .. 2048 rows, a tile size PER
+// PASS in [tl_lo, tl_hi], 8 / 16 / 32 points per thread, f64 also the one-wave 64 x 16 tiles and the four-wave 256 x 16 pass
+// -- what tools/sweep_single_cold.py and tools/sweep_real*.py enumerated by hand until round 5.  Sorted by plan_model_us.
+inline void enumerate_plans(unsigned L, size_t elem_bytes, size_t batch, unsigned tl_lo, unsigned tl_hi, std::vector<PlanSpec> &out) {
+    out.clear();
+    if (L <= kSmallMaxLog - 1 || L > 31) return;
+    const unsigned lps64[] = {3, 4, 5, 3 | kWaveTiles, 4 | kWaveTiles}, lps32[] = {3, 4, 5};
+    const unsigned *lps = elem_bytes == 8 ? lps64 : lps32;
+    const unsigned n_lps = elem_bytes == 8 ? 5 : 3;
+    std::vector<std::pair<double, PlanSpec>> scored;
+    std::vector<PassGeom> geo;
+    for (unsigned np = 2; np <= 3; ++np) {
+        unsigned lr[3] = {6, 6, 6};
+        for (;;) {  // odometer over the row digits
+            unsigned sum = 0;
+            for (unsigned i = 0; i < np; ++i) sum += lr[i];
+            if (sum == L) {
+                unsigned tl[3] = {tl_lo, tl_lo, tl_lo};
+                for (;;) {  // ... and over the tile sizes
+                    bool cols_ok = true, wave_shaped = false;
+                    for (unsigned i = 0; i < np; ++i) {
+                        if (tl[i] < lr[i] + 2 || tl[i] > lr[i] + 7) cols_ok = false;
+                        if ((lr[i] == 6 && tl[i] == (elem_bytes == 8 ? 10u : 11u)) || (elem_bytes == 8 && lr[i] == 8 && tl[i] == 12 && i > 0))
+                            wave_shaped = true;
+                    }
+                    for (unsigned k = 0; k < n_lps && cols_ok; ++k) {
+                        if ((lps[k] & kWaveTiles) && !wave_shaped) continue;  // the same plan as without the flag
+                        PlanSpec s;
+                        s.np = np;
+                        for (unsigned i = 0; i < np; ++i) {
+                            s.lr[i] = lr[i];
+                            s.tl[i] = tl[i];
+                        }
+                        s.lp = lps[k];
+                        if (!make_passes(L, s.lrs(), s.tls(), geo, s.lp, elem_bytes)) continue;
+                        scored.emplace_back(plan_model_us(geo, L, batch, elem_bytes), s);
+                    }
+                    unsigned i = 0;
+                    while (i < np && ++tl[i] > tl_hi) tl[i++] = tl_lo;
+                    if (i == np) break;
+                }
+            }
+            unsigned i = 0;
+            while (i < np && ++lr[i] > 11) lr[i++] = 6;
+            if (i == np) break;
+        }
+    }
+    std::stable_sort(scored.begin(), scored.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+    for (auto &e : scored) out.push_back(e.second);
+}
+
+// the tile sizes worth trying for `points` in flight (batch * n): a latency-bound call wants many small tiles, a full chip
+// the widest rows (section 5; the ranges the round-4 sweeps were run with)
+inline void tune_tile_range(size_t points, size_t elem_bytes, unsigned &tl_lo, unsigned &tl_hi) {
+    const unsigned lg = 63u - (unsigned)__builtin_clzll((unsigned long long)(points ? points : 1));
+    tl_lo = lg <= 21 ? 10u : lg <= 24 ? 11u : 12u;
+    tl_hi = lg <= 19 ? 13u : (elem_bytes == 4 && lg >= 22) ? 15u : 14u;
 }
 
 // ---- strided batches: 2^sb transforms of 2^L points, transform c at element c, its points 2^s elements apart ----

@@ -3,6 +3,10 @@
 // (the launches).
 #pragma once
 
+#include <map>
+#include <thread>
+
+#include "wisdom.hpp"
 #include "workspace.hpp"
 
 namespace phast {
@@ -11,6 +15,7 @@ namespace phast {
 // planner
 // ------------------------------------------------------------------------------------------------
 struct PassDesc : PassGeom {
+    // twiddle tables: entries of the planner's table cache (Planner::table) -- shared between plans, released with the planner
     void *d_tw3 = nullptr;
     void *d_twr = nullptr;
     int blocks_per_cu = 1;
@@ -38,6 +43,14 @@ static bool r2c_fuse_enabled() {  // PHAST_R2C_FUSE=0: keep the untangle as a sw
     static const bool v = [] {
         const char *e = std::getenv("PHAST_R2C_FUSE");
         return !(e && *e == '0');
+    }();
+    return v;
+}
+
+static const char *test_perturb_hook() {  // PHAST_TEST_PERTURB_TW3: tests only (Planner::table)
+    static const char *v = [] {
+        const char *e = std::getenv("PHAST_TEST_PERTURB_TW3");
+        return (e && *e) ? e : nullptr;
     }();
     return v;
 }
@@ -99,6 +112,9 @@ struct PassTimer {
 };
 
 template <typename T> struct Planner {
+    using value_type = T;
+    unsigned wisdom_log_n() const { return log_n; }
+    int device_of() const { return device; }
     size_t n = 0;
     unsigned log_n = 0;
     std::vector<PassDesc> passes;      // throughput plan; empty => small path
@@ -116,22 +132,55 @@ template <typename T> struct Planner {
     // make_c2r_plans after the plan swap, read by calls in flight on other threads
     std::atomic<bool> r2c_table_fuses{false};
     void *d_small_tw = nullptr;
+    bool is_inner_of_real = false;  // the N/2-point planner inside a PlannerR2c: its wisdom is keyed by the real length
     // elements per transform and plane in the scratch: n plus the padding of the intermediate layouts (plan.hpp:
     // scratch_pad_bytes); the largest over this planner's plans, fixed before the first allocation grows past it
     size_t scratch_stride = 0;
     size_t sstride() const { return scratch_stride ? scratch_stride : n; }
-    mutable size_t reserve = 1;
-    mutable size_t table_bytes = 0;
+    mutable std::atomic<size_t> reserve{1};
     int device = -1;  // the device this planner's tables and scratch live on (current at creation); calls run there
+    // Twiddle tables, keyed by what they hold: every plan of this planner -- the static ones, those a tuning run tries, those
+    // set_plan installs -- shares them; uploaded once, released with the planner.  (Until round 5 every plan owned copies and a
+    // replaced plan's tables were parked until the planner died, counted twice: ADVICE r04.)  A few dozen tables of at most
+    // 96 KiB each.
+    enum TableKind : unsigned { kTwr = 1, kTwq = 2, kTw3 = 3, kTwu = 4 };
+    mutable std::mutex tables_mu;
+    mutable std::map<unsigned long long, void *> tables;
+    mutable std::atomic<size_t> table_bytes{0};
+    int table(TableKind kind, unsigned a, unsigned b, void **out) const;
     // the workspace pool (see Workspace); `mu` guards the pool's bookkeeping, never a launch
     mutable std::mutex mu;
     mutable std::condition_variable cv;
     mutable std::vector<std::unique_ptr<Workspace>> pool;
     // plans are read by every call and replaced by set_plan (a tuning hook): shared for the enqueue, exclusive to swap
     mutable std::shared_mutex plan_mu;
-    // tables a set_plan replaced: kernels already enqueued (or captured) may still read them -- released with the planner
-    mutable std::vector<void *> old_tables;
-    mutable size_t old_table_bytes = 0;
+    // Plans a tuning run measured (tune.hpp) or wisdom supplied (wisdom.hpp), per call kind and batch bucket: looked up before
+    // the static rules (choose).  Entries are added under the exclusive hold of plan_mu and never move or go.
+    struct TunedPlan {
+        int kind = kC2C;
+        unsigned bucket = 0;
+        bool fuse = false;  // r2c: run the fused last pass
+        std::vector<PassDesc> passes;
+        PlanSpec spec;
+        float us = 0, us_heur = 0;
+    };
+    mutable std::vector<std::unique_ptr<TunedPlan>> tuned;
+    mutable std::mutex tune_mu;  // one tuning run at a time per planner
+    const TunedPlan *tuned_for(int kind, size_t batch) const {
+        const unsigned b = batch_bucket(batch);
+        for (const auto &t : tuned)
+            if (t->kind == kind && t->bucket == b) return t.get();
+        return nullptr;
+    }
+    // The plan a call runs and whether an R2C call fuses its untangle into the last pass: ONE decision per call, made here
+    // (until round 5 exec_in and PlannerR2c each had their own copy of the fuse rule: ADVICE r03).  `batch` = transforms of the
+    // call, `chunk` = transforms per launch (the scratch may hold fewer than the call brings).
+    struct Choice {
+        const std::vector<PassDesc> *passes = nullptr;
+        bool r2c_fuse = false;
+        const TunedPlan *tuned = nullptr;
+    };
+    Choice choose(int kind, size_t batch, size_t chunk, bool use_tuned = true) const;
     // plans of strided batches (column FFTs), built on first use per (log2 stride, log2 batch): see make_strided_passes;
     // guarded by `mu`, entries never move
     struct StridedPlan {
@@ -163,6 +212,9 @@ template <typename T> struct Planner {
     void check_in(Workspace *ws, hipStream_t stream, bool host_synchronised) const;
     int ensure_scratch(const Lease &L, size_t batch, size_t *cap_out, bool exact = false) const;
     int check_guards(size_t *bad_out) const;
+    bool capture_ready() const;
+    int reserve_batch(size_t max_batch);
+    size_t release_graph_workspaces();
 
     ~Planner() { release(); }
     // Host-slice calls up to this many staged bytes go through the pinned mirror (one memcpy each way on the host,
@@ -200,38 +252,17 @@ template <typename T> struct Planner {
         *out = w.d_stage;
         return PHAST_OK;
     }
-    static void free_passes(std::vector<PassDesc> &v) {
-        for (auto &p : v) {
-            if (p.d_tw3) hipFree(p.d_tw3);
-            if (p.d_twr) hipFree(p.d_twr);
-            if (p.d_twu) hipFree(p.d_twu);
-        }
-        v.clear();
-    }
-    void retire_passes(std::vector<PassDesc> &v) {  // plan_mu held exclusively
-        for (auto &p : v) {
-            for (void *t : {p.d_tw3, p.d_twr, p.d_twu})
-                if (t) old_tables.push_back(t);
-            old_table_bytes += (p.pre_tw ? ((size_t)3 << p.tw_bits) : 0) * sizeof(cx_t<T>) + 64 * sizeof(cx_t<T>) +
-                               (p.d_twu ? ((size_t)1 << p.lr) * sizeof(cx_t<T>) : 0);
-        }
-        v.clear();
-    }
+    // (plans do not own their tables -- see `tables`: dropping a plan is dropping its descriptors; kernels already enqueued or
+    // captured keep reading tables that live as long as the planner)
+    static void retire_passes(std::vector<PassDesc> &v) { v.clear(); }
     void release_passes() {
-        for (auto &sp : strided_plans) free_passes(sp->passes);
         strided_plans.clear();
-        free_passes(passes);
-        free_passes(passes_lat);
-        free_passes(passes_mid);
-        free_passes(passes_one);
-        free_passes(passes_c2r_one);
-        free_passes(passes_c2r_lat);
-        free_passes(passes_r2c_tp);
-        free_passes(passes_c2r_tp);
-        free_passes(passes_r2c);
-        for (void *t : old_tables) hipFree(t);
-        old_tables.clear();
-        old_table_bytes = 0;
+        tuned.clear();
+        for (auto *v : {&passes, &passes_lat, &passes_mid, &passes_one, &passes_c2r_one, &passes_c2r_lat, &passes_r2c_tp, &passes_c2r_tp, &passes_r2c})
+            v->clear();
+        for (auto &kv : tables) hipFree(kv.second);
+        tables.clear();
+        table_bytes = 0;
     }
     void release() {
         DeviceGuard on(device);
@@ -288,12 +319,29 @@ template <typename T> struct Planner {
     int init(size_t num_points, bool force_multi = false, bool with_twin = true);
     int default_plans();
     int make_c2r_plans();
-    int prepare_passes(std::vector<PassDesc> &ps, size_t *table_bytes_out) const;
+    int prepare_passes(std::vector<PassDesc> &ps) const;
+    int build_plan(const PlanSpec &spec, std::vector<PassDesc> &ps, size_t *scratch_need) const;
+    // wisdom -> tuned plans; measuring (tune.hpp).  `real_log_n`: log2 of the caller's length for kR2C / kC2R (this planner is the
+    // inner one), else 0
+    int apply_wisdom(unsigned real_log_n);
+    int install_tuned(int kind, unsigned bucket, const PlanSpec &spec, bool fuse, float us, float us_heur);
+    struct TuneReport {
+        int adopted = 0;  // a measured plan replaced the static rule's
+        unsigned candidates = 0;
+        float us_heuristic = 0, us_best = 0;
+        double seconds = 0;
+        std::string plan;
+    };
+    int install_built(int kind, unsigned bucket, const PlanSpec &spec, bool fuse, std::vector<PassDesc> &&ps, float us, float us_heur);
+    void remove_tuned(int kind, unsigned bucket);
+    template <typename Run, typename Refill>
+    int tune_core(int kind, size_t batch, unsigned wisdom_log_n, int ring, bool grows, Run &&run, Refill &&refill, TuneReport *rep);
+    int tune(int kind, size_t batch, TuneReport *rep);
     std::string describe() const;
     // live tables and scratch plus what is retired but not yet released
     size_t device_bytes() const {
         std::lock_guard<std::mutex> lk(mu);
-        size_t b = table_bytes + old_table_bytes;
+        size_t b = table_bytes;
         for (auto &w : pool) b += w->device_bytes();
         if (twin) b += twin->device_bytes();
         return b;
@@ -327,7 +375,8 @@ template <typename T> struct Planner {
                  unsigned out_mode, size_t batch, double scale, hipStream_t stream, PassTimer *timer = nullptr) const;
     int exec_in(const Lease &L, const void *in_re, const void *in_im, size_t in_dist, unsigned in_mode, void *out_re, void *out_im,
                     size_t out_dist, unsigned out_mode, size_t batch, double scale, PassTimer *timer = nullptr,
-                    const R2cFuse *fuse = nullptr, bool *fused_out = nullptr, size_t *np_out = nullptr) const;
+                    const R2cFuse *fuse = nullptr, bool *fused_out = nullptr, size_t *np_out = nullptr,
+                    const Choice *forced = nullptr) const;
 };
 
 }  // namespace phast

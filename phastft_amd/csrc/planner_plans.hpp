@@ -53,66 +53,185 @@ template <typename T> const std::vector<PassDesc> &Planner<T>::plan_for_c2r(size
 // 4 = the plan for one transform;
 // lp = log2(points per thread)
 template <typename T> int Planner<T>::set_plan(const std::vector<unsigned> &lrs, const std::vector<unsigned> &tls, int which, unsigned lp) {
-    std::vector<PassGeom> geo;
-    if (!make_passes(log_n, lrs, tls, geo, lp, sizeof(T))) return PHAST_ERR_INVALID_ARG;
-#ifndef PHAST_EXPERIMENTAL_WAVE_F32
-    if (sizeof(T) == 4)  // f32 wave tiles: measured, slower than the generic tiles everywhere, built with --experimental only
-        for (const PassGeom &g : geo)
-            if (g.wave) return PHAST_ERR_INVALID_ARG;
-#endif
-    PHAST_ON_DEVICE(device);
-    std::vector<PassDesc> ps(geo.size());
-    for (size_t i = 0; i < geo.size(); ++i) static_cast<PassGeom &>(ps[i]) = geo[i];
-    size_t tb = 0;
+    if (lrs.size() < 2 || lrs.size() > 3 || (tls.size() != 1 && tls.size() != lrs.size())) return PHAST_ERR_INVALID_ARG;
+    PlanSpec spec;
+    spec.np = (unsigned)lrs.size();
+    for (unsigned i = 0; i < spec.np; ++i) {
+        spec.lr[i] = lrs[i];
+        spec.tl[i] = tls.size() == 1 ? tls[0] : tls[i];
+    }
+    spec.lp = lp;
+    std::vector<PassDesc> ps;
+    size_t need = 0;
     {
-        int rc = prepare_passes(ps, &tb);
+        int rc = build_plan(spec, ps, &need);
         if (rc) return rc;
     }
-    const size_t need = (size_t)scratch_elems(geo, log_n);
     // every call reads the pass vectors under a shared hold of plan_mu for as long as it enqueues: a plan is never
-    // swapped under a launch sequence; kernels already enqueued (or captured) keep reading the old tables, which
-    // are therefore kept until the planner goes, not freed
+    // swapped under a launch sequence; kernels already enqueued (or captured) keep reading the tables, which live as long as
+    // the planner (Planner::table)
     std::unique_lock<std::shared_mutex> plans(plan_mu);
     if (which == 2) {
         retire_passes(passes_lat);
         retire_passes(passes_c2r_lat);  // derived from the plan that goes
         passes_lat = std::move(ps);
     } else if (which == 3) {
-        retire_passes(passes_mid);
         passes_mid = std::move(ps);
     } else if (which == 4) {
-        retire_passes(passes_one);
         retire_passes(passes_c2r_one);
         passes_one = std::move(ps);
-    } else if (which >= 5 && which <= 9) {  // the real transforms' own plans: additional, table_bytes and pitch below
+    } else if (which >= 5 && which <= 9) {  // the real transforms' own plans
         std::vector<PassDesc> &dst = which == 5   ? passes_c2r_one
                                      : which == 6 ? passes_c2r_lat
                                      : which == 7 ? passes_r2c
                                      : which == 8 ? passes_c2r_tp
                                                   : passes_r2c_tp;
-        retire_passes(dst);
         dst = std::move(ps);
-        table_bytes += tb;
-        if (need > sstride()) scratch_stride = need;
-        return PHAST_OK;
     } else {
-        retire_passes(passes);
         passes = std::move(ps);
-        if (which == 0) {  // one plan for every batch size
-            retire_passes(passes_lat);
-            retire_passes(passes_mid);
-            retire_passes(passes_one);
-            retire_passes(passes_c2r_one);
-            retire_passes(passes_c2r_lat);
-            retire_passes(passes_r2c);
-            retire_passes(passes_r2c_tp);
-            retire_passes(passes_c2r_tp);
-        }
+        if (which == 0)  // one plan for every batch size
+            for (auto *v : {&passes_lat, &passes_mid, &passes_one, &passes_c2r_one, &passes_c2r_lat, &passes_r2c, &passes_r2c_tp, &passes_c2r_tp})
+                retire_passes(*v);
     }
-    table_bytes = tb;
     // a plan with wider pitches than the scratches were cut for: every workspace re-cuts its scratch on next use
     // (ensure_scratch compares Workspace::per)
     if (need > sstride()) scratch_stride = need;
+    return PHAST_OK;
+}
+
+// descriptors, tables and launch parameters of the plan `spec` names; *scratch_need = elements per transform and plane its
+// (padded) intermediate layout takes.  PHAST_ERR_INVALID_ARG: not a plan of this length, or a tile that does not fit the LDS.
+template <typename T> int Planner<T>::build_plan(const PlanSpec &spec, std::vector<PassDesc> &ps, size_t *scratch_need) const {
+    std::vector<PassGeom> geo;
+    if (!make_passes(log_n, spec.lrs(), spec.tls(), geo, spec.lp, sizeof(T))) return PHAST_ERR_INVALID_ARG;
+#ifndef PHAST_EXPERIMENTAL_WAVE_F32
+    if (sizeof(T) == 4)  // f32 wave tiles: measured, slower than the generic tiles everywhere, built with --experimental only
+        for (const PassGeom &g : geo)
+            if (g.wave) return PHAST_ERR_INVALID_ARG;
+#endif
+    PHAST_ON_DEVICE(device);
+    ps.assign(geo.size(), PassDesc());
+    for (size_t i = 0; i < geo.size(); ++i) static_cast<PassGeom &>(ps[i]) = geo[i];
+    if (scratch_need) *scratch_need = (size_t)scratch_elems(geo, log_n);
+    return prepare_passes(ps);
+}
+
+// One of this planner's twiddle tables, uploaded on first use:
+//   kTwr (rows): W_rows^j two-level table of a tile FFT (plan.hpp: host_twr);  kTwq: the four-wave kernel's step twiddles;
+//   kTw3 (log_mod, bits): the three-level W_{2^log_mod} table of an inter-pass twiddle;  kTwu (lr): W_{2 * 2^lr}^k, the real
+//   transforms' fused passes.
+template <typename T> int Planner<T>::table(TableKind kind, unsigned a, unsigned b, void **out) const {
+    const unsigned long long key = ((unsigned long long)kind << 48) | ((unsigned long long)a << 24) | b;
+    std::lock_guard<std::mutex> lk(tables_mu);
+    auto it = tables.find(key);
+    if (it != tables.end()) {
+        *out = it->second;
+        return PHAST_OK;
+    }
+    std::vector<cx_t<T>> h;
+    switch (kind) {
+    case kTwr: h = host_twr<T>(a); break;
+    case kTwq: h = host_twq<T>(); break;
+    case kTw3: h = host_tw3<T>(a, b); break;
+    case kTwu:
+        h.resize((size_t)1 << a);
+        for (size_t k = 0; k < h.size(); ++k) h[k] = twiddle_t<T>(k, 2ull << a);
+        break;
+    }
+    if (const char *hook = test_perturb_hook()) {
+        // test-only (tests/test_gpu_parity_r5.py): PHAST_TEST_PERTURB_TW3=<relative error> moves entry 5 of level 0 of every
+        // three-level table -- the parity gates must be tight enough to notice a twiddle that is off by 1e-9
+        if (kind == kTw3 && h.size() > 5) h[5].x = (T)((double)h[5].x * (1.0 + std::atof(hook)));
+    }
+    void *d = nullptr;
+    int rc = upload<T>(h, &d);
+    if (rc) return rc;
+    tables.emplace(key, d);
+    table_bytes += h.size() * sizeof(cx_t<T>);
+    *out = d;
+    return PHAST_OK;
+}
+
+// ---- which plan a call runs ----
+template <typename T> typename Planner<T>::Choice Planner<T>::choose(int kind, size_t batch, size_t chunk, bool use_tuned) const {
+    Choice c;
+    if (const TunedPlan *t = use_tuned ? tuned_for(kind, batch) : nullptr) {  // measured (tune.hpp) or supplied as wisdom
+        c.passes = &t->passes;
+        c.r2c_fuse = kind == kR2C && t->fuse && r2c_fuse_enabled();
+        c.tuned = t;
+        return c;
+    }
+    switch (kind) {
+    case kR2C:
+        // fused or not is decided from the size of a full chunk -- a smaller tail chunk follows the others (the caller runs
+        // the untangle sweep over the whole batch or not at all)
+        c.r2c_fuse = fuse_pays(chunk);
+        c.passes = &plan_for_r2c(batch, c.r2c_fuse);
+        break;
+    case kC2R: c.passes = &plan_for_c2r(batch); break;
+    default: c.passes = &plan_for(batch); break;
+    }
+    return c;
+}
+
+// a measured (or imported) plan for (kind, bucket); replaces an earlier one for the same key
+template <typename T> int Planner<T>::install_tuned(int kind, unsigned bucket, const PlanSpec &spec, bool fuse, float us, float us_heur) {
+    std::vector<PassDesc> ps;
+    int rc = build_plan(spec, ps, nullptr);
+    if (rc) return rc;
+    return install_built(kind, bucket, spec, fuse, std::move(ps), us, us_heur);
+}
+template <typename T>
+int Planner<T>::install_built(int kind, unsigned bucket, const PlanSpec &spec, bool fuse, std::vector<PassDesc> &&ps, float us, float us_heur) {
+    std::unique_ptr<TunedPlan> t(new (std::nothrow) TunedPlan());
+    if (!t || ps.empty()) return PHAST_ERR_ALLOC;
+    size_t need = n;
+    for (const PassDesc &p : ps) need = std::max(need, (size_t)p.scratch_dist);
+    // an R2C plan marked `fuse` must have the fused last pass (a C2R plan without the fused first pass falls back to the
+    // preprocess sweep: legal, and measured as such by a tuning run)
+    t->fuse = kind == kR2C && fuse && ps.back().r2c_blocks > 0;
+    t->kind = kind;
+    t->bucket = bucket;
+    t->passes = std::move(ps);
+    t->spec = spec;
+    t->us = us;
+    t->us_heur = us_heur;
+    // exclusive: no call is enqueueing with a Choice that points into the entry that goes (calls hold plan_mu shared while
+    // they enqueue; kernels in flight read tables, which are the planner's)
+    std::unique_lock<std::shared_mutex> plans(plan_mu);
+    if (need > sstride()) scratch_stride = need;
+    for (auto &e : tuned)
+        if (e->kind == kind && e->bucket == bucket) {
+            e = std::move(t);
+            return PHAST_OK;
+        }
+    tuned.push_back(std::move(t));
+    return PHAST_OK;
+}
+template <typename T> void Planner<T>::remove_tuned(int kind, unsigned bucket) {
+    std::unique_lock<std::shared_mutex> plans(plan_mu);
+    for (size_t i = 0; i < tuned.size(); ++i)
+        if (tuned[i]->kind == kind && tuned[i]->bucket == bucket) {
+            tuned.erase(tuned.begin() + (long)i);
+            return;
+        }
+}
+
+// the wisdom store's entries for this planner's type and length become tuned plans (entries that name the static rule's plan
+// install nothing).  Entries that no longer build -- a tile shape that went -- are skipped.
+template <typename T> int Planner<T>::apply_wisdom(unsigned real_log_n) {
+    if (passes.empty()) return PHAST_OK;
+    const int cus = cus_of(device);
+    for (int kind : {(int)kC2C, (int)kC2CI, (int)kR2C, (int)kC2R}) {
+        const bool real = kind == kR2C || kind == kC2R;
+        if (real != (real_log_n != 0)) continue;
+        for (const auto &kv : WisdomStore::instance().lookup_all(sizeof(T), kind, real ? real_log_n : log_n, cus)) {
+            const WisdomEntry &e = kv.second;
+            if (e.heuristic) continue;
+            int rc = install_tuned(kind, kv.first, e.spec, e.fuse, e.us, e.us_heur);
+            if (rc != PHAST_OK && rc != PHAST_ERR_INVALID_ARG) return rc;
+        }
+    }
     return PHAST_OK;
 }
 
@@ -123,15 +242,17 @@ template <typename T> int Planner<T>::init(size_t num_points, bool force_multi, 
     if (rc) return rc;
     if (log_n <= kSmallMaxLog && !(force_multi && log_n == kSmallMaxLog)) {
         std::vector<cx_t<T>> h = host_twr<T>((unsigned)n);  // W_N^j two-level table of the one-pass kernel
-        table_bytes = h.size() * sizeof(cx_t<T>);
         rc = upload<T>(h, &d_small_tw);
+        if (rc == PHAST_OK) table_bytes += h.size() * sizeof(cx_t<T>);
         if (rc == PHAST_OK && with_twin && log_n == kSmallMaxLog && twin_enabled()) {
             twin.reset(new (std::nothrow) Planner<T>());
             if (twin && twin->init(n, true) != PHAST_OK) twin.reset();  // an optimisation: without it the one-pass kernel serves
         }
         return rc;
     }
-    return default_plans();
+    rc = default_plans();
+    if (rc == PHAST_OK && !is_inner_of_real) rc = apply_wisdom(0);
+    return rc;
 }
 
 // the library's own two plans (plan.hpp: heuristic_plan)
@@ -219,74 +340,46 @@ template <typename T> int Planner<T>::make_c2r_plans() {
     return PHAST_OK;
 }
 
-// tables + launch parameters of a pass list (shared by set_plan and the strided plans)
-template <typename T> int Planner<T>::prepare_passes(std::vector<PassDesc> &ps, size_t *table_bytes_out) const {
-    size_t tb = 0;
+// tables + launch parameters of a pass list (shared by build_plan and the strided plans)
+template <typename T> int Planner<T>::prepare_passes(std::vector<PassDesc> &ps) const {
     for (size_t i = 0; i < ps.size(); ++i) {
-        int rc = ps[i].quad ? upload<T>(host_twq<T>(), &ps[i].d_twr) : upload<T>(host_twr<T>(1u << ps[i].lr), &ps[i].d_twr);
-        if (rc == PHAST_OK && ps[i].pre_tw) {
-            rc = upload<T>(host_tw3<T>(ps[i].log_mod(), ps[i].tw_bits), &ps[i].d_tw3);
-            tb += ((size_t)3 << ps[i].tw_bits) * sizeof(cx_t<T>);
-        }
-        tb += 64 * sizeof(cx_t<T>);
-        if (rc == PHAST_OK) {
-            TileArgs ta{};
-            ta.tw_bits = ps[i].tw_bits;
-            hipError_t e = ps[i].wave ? launch_wave<T>(ps[i].transpose, nullptr, ta, true, &ps[i].blocks_per_cu, &ps[i].lds)
-                           : ps[i].quad ? launch_quad<T>(0, nullptr, ta, true, &ps[i].blocks_per_cu, &ps[i].lds)
-                           : ps[i].transpose
-                               ? Types<T>::launch_a(ps[i].lr, ps[i].lc, (int)ps[i].lp, 0, nullptr, ta, true, &ps[i].blocks_per_cu, &ps[i].lds)
-                               : Types<T>::launch_bc(ps[i].lr, ps[i].lc, (int)ps[i].lp, 0, nullptr, ta, true, &ps[i].blocks_per_cu, &ps[i].lds);
-            if (e != hipSuccess) rc = hip_fail(e, "occupancy query");
-            if (ps[i].blocks_per_cu < 1) ps[i].blocks_per_cu = 1;
-            if (rc == PHAST_OK && ps[i].lds > 160 * 1024) rc = PHAST_ERR_INVALID_ARG;  // tile does not fit one CU's LDS
-            // the fused R2C form of a LAST pass: generic tiles with <= 16 points per thread whose columns span at least
-            // two tiles (r2c_fused.hpp); anything else keeps the separate untangle sweep
-            const PassDesc &q = ps[i];
-            if (rc == PHAST_OK && i + 1 == ps.size() && i > 0 && !q.wave && !q.quad && !q.strided && q.pre_tw &&
-                q.log_s_in >= q.lc + 1 && r2c_shape_ok(q.lr, q.lc, q.lp, sizeof(T))) {
-                std::vector<cx_t<T>> h((size_t)1 << q.lr);
-                for (size_t k = 0; k < h.size(); ++k) h[k] = twiddle_t<T>(k, 2ull << q.lr);
-                rc = upload<T>(h, &ps[i].d_twu);
-                if (rc == PHAST_OK) {
-                    R2cFuseArgs fa{};
-                    int b = 0;
-                    hipError_t e2 = launch_r2c_last<T>((int)q.lr, (int)q.lc, (int)q.lp, 0, nullptr, ta, fa, true, &b);
-                    ps[i].r2c_blocks = e2 == hipSuccess ? b : 0;
-                    (void)hipGetLastError();
-                }
-            }
+        PassDesc &q = ps[i];
+        int rc = q.quad ? table(kTwq, 0, 0, &q.d_twr) : table(kTwr, 1u << q.lr, 0, &q.d_twr);
+        if (rc == PHAST_OK && q.pre_tw) rc = table(kTw3, q.log_mod(), q.tw_bits, &q.d_tw3);
+        if (rc) return rc;
+        TileArgs ta{};
+        ta.tw_bits = q.tw_bits;
+        hipError_t e = q.wave        ? launch_wave<T>(q.transpose, nullptr, ta, true, &q.blocks_per_cu, &q.lds)
+                       : q.quad      ? launch_quad<T>(0, nullptr, ta, true, &q.blocks_per_cu, &q.lds)
+                       : q.transpose ? Types<T>::launch_a(q.lr, q.lc, (int)q.lp, 0, nullptr, ta, true, &q.blocks_per_cu, &q.lds)
+                                     : Types<T>::launch_bc(q.lr, q.lc, (int)q.lp, 0, nullptr, ta, true, &q.blocks_per_cu, &q.lds);
+        if (e != hipSuccess) return hip_fail(e, "occupancy query");
+        if (q.blocks_per_cu < 1) q.blocks_per_cu = 1;
+        if (q.lds > 160 * 1024) return PHAST_ERR_INVALID_ARG;  // tile does not fit one CU's LDS
+        // the fused R2C form of a LAST pass: generic tiles with <= 16 points per thread whose columns span at least
+        // two tiles (r2c_fused.hpp); anything else keeps the separate untangle sweep
+        if (i + 1 == ps.size() && i > 0 && !q.wave && !q.quad && !q.strided && q.pre_tw && q.log_s_in >= q.lc + 1 &&
+            r2c_shape_ok(q.lr, q.lc, q.lp, sizeof(T))) {
+            rc = table(kTwu, q.lr, 0, &q.d_twu);
+            if (rc) return rc;
+            R2cFuseArgs fa{};
+            int b = 0;
+            hipError_t e2 = launch_r2c_last<T>((int)q.lr, (int)q.lc, (int)q.lp, 0, nullptr, ta, fa, true, &b);
+            q.r2c_blocks = e2 == hipSuccess ? b : 0;
+            (void)hipGetLastError();
         }
         // the fused C2R form of a FIRST pass of a contiguous transform: generic tiles, at least two of them per transform
-        if (rc == PHAST_OK) {
-            const PassDesc &q = ps[i];
-            if (i == 0 && ps.size() > 1 && !q.wave && !q.quad && !q.strided && q.transpose && !q.pre_tw &&
-                q.log_s_in >= q.lc + 1 && c2r_shape_ok(q.lr, q.lc, q.lp, sizeof(T))) {
-                std::vector<cx_t<T>> h((size_t)1 << q.lr);
-                for (size_t k = 0; k < h.size(); ++k) h[k] = twiddle_t<T>(k, 2ull << q.lr);
-                rc = upload<T>(h, &ps[i].d_twu);
-                if (rc == PHAST_OK) {
-                    TileArgs ta{};
-                    ta.tw_bits = q.tw_bits;
-                    C2rFuseArgs fa{};
-                    int b = 0;
-                    hipError_t e2 = launch_c2r_first<T>((int)q.lr, (int)q.lc, (int)q.lp, 0, nullptr, ta, fa, true, &b);
-                    ps[i].c2r_blocks = e2 == hipSuccess ? b : 0;
-                    (void)hipGetLastError();
-                }
-            }
-        }
-        if (rc != PHAST_OK) {
-            for (auto &p : ps) {
-                if (p.d_tw3) hipFree(p.d_tw3);
-                if (p.d_twr) hipFree(p.d_twr);
-                if (p.d_twu) hipFree(p.d_twu);
-                p.d_tw3 = p.d_twr = p.d_twu = nullptr;
-            }
-            return rc;
+        if (i == 0 && ps.size() > 1 && !q.wave && !q.quad && !q.strided && q.transpose && !q.pre_tw && q.log_s_in >= q.lc + 1 &&
+            c2r_shape_ok(q.lr, q.lc, q.lp, sizeof(T))) {
+            rc = table(kTwu, q.lr, 0, &q.d_twu);
+            if (rc) return rc;
+            C2rFuseArgs fa{};
+            int b = 0;
+            hipError_t e2 = launch_c2r_first<T>((int)q.lr, (int)q.lc, (int)q.lp, 0, nullptr, ta, fa, true, &b);
+            q.c2r_blocks = e2 == hipSuccess ? b : 0;
+            (void)hipGetLastError();
         }
     }
-    if (table_bytes_out) *table_bytes_out = tb;
     return PHAST_OK;
 }
 
@@ -315,6 +408,8 @@ template <typename T> std::string Planner<T>::describe() const {
     if (!passes_r2c.empty()) add("r2c-single", passes_r2c);
     if (!passes_r2c_tp.empty()) add("r2c-batch", passes_r2c_tp);
     if (!passes_c2r_tp.empty()) add("c2r-batch", passes_c2r_tp);
+    for (const auto &t : tuned)
+        add((std::string("tuned:") + kind_name(t->kind) + "/b" + std::to_string(t->bucket) + (t->fuse ? "/fused" : "")).c_str(), t->passes);
     return s;
 }
 

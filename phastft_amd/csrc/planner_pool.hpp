@@ -31,6 +31,16 @@ template <typename T> int Planner<T>::check_out(Lease &L, hipStream_t stream, in
     // plans as they are now (set_plan may have widened them since it was made; ensure_scratch would have to re-cut it)
     const size_t per_now = 2 * sstride() * sizeof(T);
     auto fits = [&](const Workspace &w) { return w.cap > 0 && w.per == per_now; };
+    const std::thread::id me = std::this_thread::get_id();
+    // Under capture nothing executes now and nothing may be allocated or queried.  What the graph's replays will work in must
+    // not be in use by anybody else when they run: a workspace with nothing in flight, or whose work in flight is on this very
+    // stream, or is THIS thread's own (its warm-up call, usually on another stream than the capture's -- the caller orders that
+    // before the first replay, as every capture of already-running work requires).  Never one that another thread's stream is
+    // still working in: nothing would order that work before the replays.
+    auto capture_can_take = [&](const Workspace &w) {
+        const bool own_ws = w.pending && w.stream == stream;
+        return (!w.pending || own_ws || w.last_thread == me) && (!w.captured || own_ws);
+    };
     for (;;) {
         if (which == 0 && !cap)  // 1. the workspace this stream used last: stream order protects its buffers
             for (auto &w : pool)
@@ -39,28 +49,19 @@ template <typename T> int Planner<T>::check_out(Lease &L, hipStream_t stream, in
                     break;
                 }
         if (cap) {
-            // 1b. under capture nothing executes now and nothing may be allocated or queried: the stream's own workspace
-            // or any eager one, whichever FITS and is largest (a larger batch runs in fewer chunks; the stream's own on
-            // a tie) -- it belongs to the graph from here on, so no eager call can meet a replay in it.  What was
-            // enqueued in it BEFORE the capture is ordered before the replays by the caller (a capture stream is always
-            // forked from the stream that did the warm-up).
+            // 1b. the largest that FITS (a larger batch runs in fewer chunks; the stream's own on a tie) -- it belongs to the
+            // graph from here on, so no eager call can meet a replay in it
             for (auto &w : pool) {
+                if (w->busy || !fits(*w) || !capture_can_take(*w)) continue;
                 const bool own_ws = w->pending && w->stream == stream;
-                if (w->busy || !fits(*w) || (w->captured && !own_ws)) continue;
                 if (!pick || w->cap > pick->cap || (w->cap == pick->cap && own_ws)) pick = w.get();
             }
-            // 1c. none fits (no eager call since the plan changed, or none at all): the stream's own, then any eager one --
+            // 1c. none fits (no eager call since the plan changed, or none at all): one this call may take anyway --
             // ensure_scratch will have to allocate and the capture fails with the runtime's message, as documented
             // ("HIP graphs": run the call once eagerly before capturing it)
             if (!pick)
                 for (auto &w : pool)
-                    if (!w->busy && w->pending && w->stream == stream) {
-                        pick = w.get();
-                        break;
-                    }
-            if (!pick)
-                for (auto &w : pool)
-                    if (!w->busy && !w->captured && (!pick || w->cap > pick->cap)) pick = w.get();
+                    if (!w->busy && !w->captured && capture_can_take(*w) && (!pick || w->cap > pick->cap)) pick = w.get();
         }
         if (!pick && !cap)  // 2. one with nothing in flight (never one that belongs to a captured graph)
             for (auto &w : pool)
@@ -137,6 +138,7 @@ template <typename T> int Planner<T>::check_out(Lease &L, hipStream_t stream, in
         if (cap) pick->captured = true;
         pick->stream = work;
         pick->pending = true;
+        pick->last_thread = me;
         if (!cap) pick->reap(work);
     }
     return PHAST_OK;
@@ -186,13 +188,13 @@ template <typename T> int Planner<T>::ensure_scratch(const Lease &L, size_t batc
     size_t want = target;
     if (want > batch && batch >= reserve) want = batch;
     if (exact && want < batch) want = batch;  // work that cannot be cut into chunks (strided batches)
-    if (w.cap < want && !exact && w.cap >= std::max<size_t>(reserve, 1) && capturing(stream)) {
+    if (w.cap < want && !exact && w.cap >= std::max<size_t>(reserve.load(), 1) && capturing(stream)) {
         *cap_out = w.cap;  // under capture nothing may be allocated: the batch runs in the chunks this scratch allows
         return PHAST_OK;
     }
     if (w.cap < want) {
-        if (!exact && w.cap && want < 2 * w.cap) want = std::min(2 * w.cap, std::max(target, want));
-        const size_t floor_cap = exact ? want : std::max<size_t>(std::max<size_t>(reserve, 1), w.cap + 1);
+        if (!exact && w.cap && want < 2 * w.cap) want = std::min<size_t>(2 * w.cap, std::max(target, want));
+        const size_t floor_cap = exact ? want : std::max<size_t>(std::max<size_t>(reserve.load(), 1), w.cap + 1);
         const size_t guard = g_guard_bytes;
         void *d = nullptr;
         hipError_t e = hipMalloc(&d, want * per + 2 * guard);
@@ -205,7 +207,7 @@ template <typename T> int Planner<T>::ensure_scratch(const Lease &L, size_t batc
                 want = std::max(floor_cap, want / 2);
                 e = hipMalloc(&d, want * per + 2 * guard);
             }
-            if (e == hipErrorOutOfMemory && !exact && w.cap >= std::max<size_t>(reserve, 1)) {
+            if (e == hipErrorOutOfMemory && !exact && w.cap >= std::max<size_t>(reserve.load(), 1)) {
                 (void)hipGetLastError();  // cannot grow: keep working in the chunks the present scratch allows
                 *cap_out = w.cap;
                 return PHAST_OK;
@@ -244,6 +246,58 @@ template <typename T> int Planner<T>::check_guards(size_t *bad_out) const {
     }
     *bad_out = bad;
     return PHAST_OK;
+}
+
+// Can a call on this planner be CAPTURED right now without allocating -- is there a scratch, cut for the present plans, that a
+// capture may take?  (Planner::exec: the 8192-point twin under capture.)
+template <typename T> bool Planner<T>::capture_ready() const {
+    std::shared_lock<std::shared_mutex> plans(plan_mu);
+    const size_t per_now = 2 * sstride() * sizeof(T);
+    const std::thread::id me = std::this_thread::get_id();
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto &w : pool)
+        if (!w->busy && !w->captured && w->cap > 0 && w->per == per_now && (!w->pending || w->last_thread == me)) return true;
+    return false;
+}
+
+// scratch for up to `max_batch` transforms per launch, allocated now (a capture allocates nothing); a one-pass size forwards to
+// its multi-pass twin, which is what serves its small batches
+template <typename T> int Planner<T>::reserve_batch(size_t max_batch) {
+    if (max_batch == 0) return PHAST_ERR_INVALID_ARG;
+    if (passes.empty()) return twin ? twin->reserve_batch(std::min(max_batch, twin_max_batch())) : PHAST_OK;
+    PHAST_ON_DEVICE(device);
+    reserve = max_batch;
+    Lease L;
+    int rc = check_out(L, nullptr, 2);
+    if (rc) return rc;
+    L.stream = nullptr;  // check_out waited for the workspace: whatever is retired below is idle
+    size_t cap;
+    return ensure_scratch(L, max_batch, &cap);
+}
+
+// The workspaces captured graphs work in are kept until the planner goes -- the library cannot know when a graph dies.  A
+// long-lived planner that is captured again and again may hand them back: the caller promises that every graph captured on
+// this planner so far has been destroyed (or will never be launched again).  Returns the bytes released.
+template <typename T> size_t Planner<T>::release_graph_workspaces() {
+    DeviceGuard on(device);
+    std::vector<std::unique_ptr<Workspace>> gone;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (size_t i = 0; i < pool.size();)
+            if (!pool[i]->busy && pool[i]->captured) {
+                gone.push_back(std::move(pool[i]));
+                pool.erase(pool.begin() + (long)i);
+            } else {
+                ++i;
+            }
+    }
+    size_t bytes = 0;
+    for (auto &w : gone) {
+        bytes += w->device_bytes();
+        w->release();  // hipFree waits for the device
+    }
+    if (twin) bytes += twin->release_graph_workspaces();
+    return bytes;
 }
 
 }  // namespace phast

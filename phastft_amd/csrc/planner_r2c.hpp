@@ -10,6 +10,9 @@ namespace phast {
 // ------------------------------------------------------------------------------------------------
 template <typename T> struct PlannerR2c {
     using Lease = typename Planner<T>::Lease;
+    using value_type = T;
+    unsigned wisdom_log_n() const { return ilog2(n); }
+    int device_of() const { return dit.device; }
     size_t n = 0;
     Planner<T> dit;         // the inner N/2-point transform; its workspace pool serves the real transforms too
     void *d_tw3 = nullptr;  // W_N^e three-level table for the untangle / c2r-preprocess passes
@@ -21,10 +24,12 @@ template <typename T> struct PlannerR2c {
     std::unique_ptr<PlannerR2c<T>> twin;  // N/2 = 8192 only: the multi-pass form for ONE real transform (Planner::twin)
     int init(size_t n_, bool force_multi = false) {
         n = n_;
+        dit.is_inner_of_real = true;
         int rc = dit.init(n / 2, force_multi, false);
         if (rc) return rc;
         if (!dit.passes.empty()) {
             rc = dit.make_c2r_plans();
+            if (rc == PHAST_OK) rc = dit.apply_wisdom(ilog2(n));  // r2c / c2r wisdom is keyed by the real length
             if (rc) return rc;
         }
         tw_bits = tw3_bits_for(ilog2(n));
@@ -69,15 +74,11 @@ template <typename T> struct PlannerR2c {
         return PHAST_OK;
     }
 
-    bool fuses(size_t batch) const {
-        if (dit.passes.empty() || !dit.fuse_pays(batch)) return false;
-        const auto &ps = dit.plan_for_r2c(batch);
-        return !ps.empty() && ps.back().r2c_blocks > 0;
-    }
-    bool c2r_fuses(size_t batch) const {
-        if (dit.passes.empty() || !c2r_fuse_enabled()) return false;
-        const auto &ps = dit.plan_for_c2r(batch);
-        return !ps.empty() && ps.front().c2r_blocks > 0;
+    // PlannerMode::Tune for the real transforms (tune.hpp)
+    int tune(int kind, size_t batch, typename Planner<T>::TuneReport *rep);
+    // C2R: does the first pass of `ch` form z on load (c2r_fused.hpp), or does the preprocess run as a sweep of its own?
+    static bool c2r_fuses(const typename Planner<T>::Choice &ch) {
+        return c2r_fuse_enabled() && ch.passes && !ch.passes->empty() && ch.passes->front().c2r_blocks > 0;
     }
     // r2c.rs:535-593 / 607-662 on device pointers (a _dev call: checks a workspace out for the enqueue)
     int r2c(const T *d_in, T *d_ore, T *d_oim, size_t batch, size_t in_dist, size_t out_dist, hipStream_t s,
@@ -97,7 +98,7 @@ template <typename T> struct PlannerR2c {
         return r2c_in(L, d_in, d_ore, d_oim, batch, in_dist, out_dist, timer);
     }
     int r2c_in(const Lease &L, const T *d_in, T *d_ore, T *d_oim, size_t batch, size_t in_dist, size_t out_dist,
-               PassTimer *timer = nullptr) const {
+               PassTimer *timer = nullptr, const typename Planner<T>::Choice *forced = nullptr) const {
         const size_t half = n / 2;
         hipStream_t s = L.stream;
         if (dit.passes.empty())  // N/2 <= 8192: one kernel, the untangle is its epilogue
@@ -105,7 +106,7 @@ template <typename T> struct PlannerR2c {
         const R2cFuse fuse{d_tw3, tw_bits};
         bool fused = false;
         size_t np = 0;
-        int rc = dit.exec_in(L, d_in, nullptr, in_dist / 2, 1, d_ore, d_oim, out_dist, 0, batch, 1.0, timer, &fuse, &fused, &np);
+        int rc = dit.exec_in(L, d_in, nullptr, in_dist / 2, 1, d_ore, d_oim, out_dist, 0, batch, 1.0, timer, &fuse, &fused, &np, forced);
         if (rc) return rc;
         if (fused) return PHAST_OK;  // the last pass wrote X[k] and X[h - k] itself (r2c_fused.hpp)
         const int untangle_slot = (int)np;  // timer slot after the passes of the plan that ran
@@ -142,16 +143,21 @@ template <typename T> struct PlannerR2c {
         return c2r_in(L, d_ire, d_iim, d_out, batch, in_dist, out_dist, timer);
     }
     int c2r_in(const Lease &L, const T *d_ire, const T *d_iim, T *d_out, size_t batch, size_t in_dist, size_t out_dist,
-               PassTimer *timer = nullptr) const {
+               PassTimer *timer = nullptr, const typename Planner<T>::Choice *forced = nullptr) const {
         const size_t half = n / 2;
         hipStream_t s = L.stream;
         if (dit.passes.empty())  // N/2 <= 8192: one kernel, the preprocess is its prologue
             return dit.exec_small_real(2, d_ire, d_iim, in_dist, d_out, nullptr, out_dist / 2, batch, 1.0 / (double)half,
                                        d_tw3, tw_bits, s);
-        if (c2r_fuses(batch)) {  // the first pass forms z on load: no preprocess sweep, no workspace (c2r_fused.hpp)
+        const typename Planner<T>::Choice ch = forced ? *forced : dit.choose(kC2R, batch, batch);
+        if (c2r_fuses(ch)) {  // the first pass forms z on load: no preprocess sweep, no workspace (c2r_fused.hpp)
             const R2cFuse fuse{d_tw3, tw_bits};
-            return dit.exec_in(L, d_ire, d_iim, in_dist, 3, d_out, nullptr, out_dist / 2, 2, batch, 1.0 / (double)half, timer, &fuse);
+            return dit.exec_in(L, d_ire, d_iim, in_dist, 3, d_out, nullptr, out_dist / 2, 2, batch, 1.0 / (double)half, timer, &fuse,
+                               nullptr, nullptr, &ch);
         }
+        // no fused form of that plan's first pass: the preprocess sweep, then the inner transform -- on a measured C2R plan if
+        // there is one (it was measured running exactly this), else on the C2C choice for the chunk
+        const typename Planner<T>::Choice *inner = (forced || ch.tuned) ? &ch : nullptr;
         size_t cap = 0;
         int rc = ensure_z(L, batch, &cap);
         if (rc) return rc;
@@ -172,11 +178,12 @@ template <typename T> struct PlannerR2c {
             hipEvent_t e0 = nullptr, e1 = nullptr;
             // the sweep's timer slot sits after the inner passes: of the plan a chunk of nb transforms runs (exec_in
             // picks it from nb too)
-            if (timer) PHAST_HIP(timer->pair((int)dit.plan_for(nb).size(), &e0, &e1));
+            if (timer) PHAST_HIP(timer->pair((int)(inner ? inner->passes->size() : dit.choose(kC2CI, nb, nb).passes->size()), &e0, &e1));
             PHAST_HIP(launch_c2r_preprocess<T>(pa, s, e0, e1));
             // inverse by the swap trick (algorithms/dit.rs:297-300): forward FFT of (z_im, z_re), 1/half scale,
             // and the (positional re, positional im) = (caller im, caller re) pair is stored as (im, re)
-            rc = dit.exec_in(L, z_im, z_re, half, 0, d_out + b0 * out_dist, nullptr, out_dist / 2, 2, nb, 1.0 / (double)half, timer);
+            rc = dit.exec_in(L, z_im, z_re, half, 0, d_out + b0 * out_dist, nullptr, out_dist / 2, 2, nb, 1.0 / (double)half, timer,
+                             nullptr, nullptr, nullptr, inner);
             if (rc) return rc;
         }
         return PHAST_OK;

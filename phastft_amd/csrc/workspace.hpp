@@ -2,6 +2,8 @@
 // unfused C2R workspace; the pool of them lives in Planner (planner.hpp, planner_pool.hpp).
 #pragma once
 
+#include <thread>
+
 #include "host_util.hpp"
 
 namespace phast {
@@ -55,22 +57,28 @@ static size_t max_workspaces() {
 }
 
 struct Workspace {
+    // Who touches what: the thread that has the workspace checked out (`busy`, set and cleared under the planner's `mu`) owns
+    // every field; other threads look at a workspace only under `mu` and only after seeing `busy == false`.  The exceptions
+    // are the byte counts and `captured`, which device_bytes() and the pool's head count read at any time: atomics (ADVICE
+    // r04: they were plain fields read under `mu` while the holder wrote them outside it).
     void *d_scratch = nullptr;  // [cap][2][stride]: re plane then im plane per transform (typed by the planner)
-    size_t cap = 0;
+    std::atomic<size_t> cap{0};
     size_t guard = 0;           // bytes of guard band before and after the scratch (debug hook, normally 0)
-    size_t per = 0;             // bytes per transform the scratch was cut for (2 * stride * sizeof(T))
+    std::atomic<size_t> per{0}; // bytes per transform the scratch was cut for (2 * stride * sizeof(T))
     void *d_stage = nullptr;    // device staging of the host-slice entry points (grow-only)
-    size_t stage_bytes = 0;
+    std::atomic<size_t> stage_bytes{0};
     void *h_pin = nullptr;      // pinned host mirror of the staging buffer for SMALL host-slice calls
     size_t pin_bytes = 0;
     void *d_z = nullptr;        // unfused C2R: the preprocess workspace [z_cap][2][n/2] (PlannerR2c)
-    size_t z_cap = 0, z_bytes = 0;
+    size_t z_cap = 0;
+    std::atomic<size_t> z_bytes{0};
     hipStream_t stream = nullptr;  // the stream the last work of this workspace went to (valid while `pending`)
     bool pending = false;          // work may still be running on `stream`
     hipStream_t own = nullptr;     // the non-blocking stream of host-slice calls (created on first use)
     hipEvent_t idle = nullptr;     // recorded behind the last _dev call's work (Planner::check_in); owned by the workspace
     bool busy = false;             // checked out by a host thread
-    bool captured = false;         // used under stream capture: pinned to the captured graphs (see above)
+    std::atomic<bool> captured{false};         // used under stream capture: pinned to the captured graphs (see above)
+    std::thread::id last_thread;   // the host thread whose call used it last (who may capture over its own warm-up, check_out)
     // A buffer that has to grow is replaced, never freed inside the call that outgrew it: kernels already enqueued may
     // still use the old one.  The predecessor is RETIRED with an event recorded on the workspace's stream behind them; a
     // later call frees it once that event has completed (never under capture, never for a captured workspace).
@@ -81,7 +89,7 @@ struct Workspace {
         bool pinned;
     };
     std::vector<Retired> retired;
-    size_t retired_dev_bytes = 0;
+    std::atomic<size_t> retired_dev_bytes{0};
 
     void retire(void *p, size_t bytes, bool pinned, hipStream_t on) {
         if (!p) return;
@@ -136,7 +144,12 @@ struct Workspace {
         d_scratch = d_stage = d_z = h_pin = nullptr;
         own = nullptr;
         idle = nullptr;
-        cap = stage_bytes = z_cap = z_bytes = pin_bytes = retired_dev_bytes = 0;
+        cap = 0;
+        per = 0;
+        stage_bytes = 0;
+        z_bytes = 0;
+        retired_dev_bytes = 0;
+        z_cap = pin_bytes = 0;
     }
 };
 

@@ -12,7 +12,8 @@ pub enum Direction {
     Reverse = -1,
 }
 
-/// planner.rs:24-32 (`Tune` is accepted and ignored, as in the reference: planner.rs:65)
+/// planner.rs:24-32.  `Tune`: the library times the plans that exist for this length on the device at plan time and keeps
+/// the fastest (include/phastft_hip.h, "PlannerMode::Tune"); `Heuristic`: static rules, zero planning overhead.
 #[derive(Copy, Clone, Debug, Default)]
 pub enum PlannerMode {
     #[default]

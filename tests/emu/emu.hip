@@ -551,5 +551,27 @@ int phast_emu_check_plan_tables(int *n_entries) {
     *n_entries = 0;
     return check_tables<double>(n_entries) + check_tables<float>(n_entries);
 }
+// The candidate set of a tuning run (plan.hpp: enumerate_plans, tune_tile_range): every entry must be a plan (make_passes), must
+// survive the round trip through its text form (the wisdom format), and -- returned -- how many there are; *has_spec = whether
+// `spec` (e.g. the hand-ranked table entry of that length) is among them.
+int phast_emu_enumerate_plans(unsigned L, size_t elem_bytes, size_t batch, const char *spec, int *has_spec, int *bad) {
+    using namespace phast;
+    unsigned tl_lo, tl_hi;
+    tune_tile_range(batch << L, elem_bytes, tl_lo, tl_hi);
+    std::vector<PlanSpec> specs;
+    enumerate_plans(L, elem_bytes, batch, tl_lo, tl_hi, specs);
+    PlanSpec want;
+    const bool have_want = spec && spec_from_string(spec, want);
+    *has_spec = 0;
+    *bad = 0;
+    std::vector<PassGeom> geo;
+    for (const PlanSpec &s : specs) {
+        PlanSpec back;
+        if (!spec_from_string(spec_to_string(s).c_str(), back) || !(back == s)) ++*bad;
+        if (!make_passes(L, s.lrs(), s.tls(), geo, s.lp, elem_bytes)) ++*bad;
+        if (have_want && s == want) *has_spec = 1;
+    }
+    return (int)specs.size();
+}
 #endif
 }

@@ -111,3 +111,37 @@ def test_every_environment_variable_the_library_reads_is_documented():
     assert names, "no environment variables found: the pattern no longer matches the sources"
     missing = sorted(n for n in names if n not in doc)
     assert not missing, missing
+
+
+def test_wisdom_store_without_a_device():
+    """csrc/wisdom.hpp through the C ABI: import / export / forget need no GPU.  Later layers win, malformed lines are skipped,
+    a text without the header is refused, and what comes out parses back to the same set."""
+    import phastft_amd as P
+
+    P.wisdom_forget()
+    base = P.wisdom_export()
+    assert base.startswith("phastft-hip-wisdom 1 cus=")
+    text = ("phastft-hip-wisdom 1 cus=256\n"
+            "f64 c2c 20 0 6,8,6@10,12,10:p8w fuse=0 us=23.10 heur=24.02\n"
+            "f32 r2c 24 0 8,9,6@12,13,11:p16 fuse=1 us=88.00 heur=95.00\n"
+            "f64 c2r 21 3 heuristic fuse=0 us=40.00 heur=40.00\n"
+            "f64 c2c 99 0 6,8,6@10,12,10:p8w\n"          # length out of range: skipped
+            "f64 c2c 20 1 6,8,6@10,12:p8 fuse=0\n"        # rows and tiles disagree: skipped
+            "garbage line\n")
+    P.wisdom_import(text)
+    out = P.wisdom_export()
+    for line in text.splitlines()[1:4]:
+        assert line in out, line
+    assert "garbage" not in out and " 99 " not in out and "f64 c2c 20 1" not in out
+    # a later import of the same key replaces it
+    P.wisdom_import("phastft-hip-wisdom 1 cus=256\nf64 c2c 20 0 7,7,6@12,12,12:p8 fuse=0 us=22.00 heur=24.00\n")
+    out2 = P.wisdom_export()
+    assert "f64 c2c 20 0 7,7,6@12,12,12:p8" in out2 and "6,8,6@10,12,10:p8w" not in out2
+    # round trip
+    P.wisdom_forget()
+    P.wisdom_import(out2)
+    assert P.wisdom_export() == out2
+    with pytest.raises(P.PhastPanic):
+        P.wisdom_import("f64 c2c 20 0 heuristic\n")  # no header
+    P.wisdom_forget()
+    assert P.wisdom_export() == base

@@ -447,3 +447,24 @@ def test_every_plan_table_entry_is_a_plan_that_exists(emu):
     emu.phast_emu_check_plan_tables.restype = C.c_int
     assert emu.phast_emu_check_plan_tables(C.byref(n)) == 0
     assert n.value >= 70, n.value
+
+
+def test_tuning_candidates_are_plans_and_cover_the_hand_ranked_tables(emu):
+    """PlannerMode::Tune (csrc/tune.hpp) times the plans plan.hpp: enumerate_plans lists.  Every one of them must be a plan that
+    exists as kernels and must survive its text form (the wisdom format); and the set must CONTAIN what rounds 2-4 found by
+    hand-driven sweeps -- the single-transform table entries -- or the tuner could never rediscover them."""
+    emu.phast_emu_enumerate_plans.argtypes = [C.c_uint, C.c_size_t, C.c_size_t, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    emu.phast_emu_enumerate_plans.restype = C.c_int
+    has, bad = C.c_int(), C.c_int()
+    # (length, element bytes, batch, a plan that must be among the candidates: plan.hpp single_plan / real_plan entries)
+    cases = [(20, 8, 1, b"6,8,6@10,12,10:p8w"), (14, 8, 1, b"6,8@10,12:p16w"), (22, 8, 1, b"8,7,7@13,12,13:p16"),
+             (19, 4, 1, b"6,7,6@11,11,11:p8"), (25, 4, 1, b"8,9,8@14,13,14:p16"), (20, 8, 8, b"10,10@13,13:p16"),
+             (13, 8, 1, b"6,7@10,11:p8w"), (26, 8, 1, None), (28, 4, 1, None), (16, 4, 64, None)]
+    for L, eb, batch, spec in cases:
+        cnt = emu.phast_emu_enumerate_plans(L, eb, batch, spec, C.byref(has), C.byref(bad))
+        assert bad.value == 0, (L, eb, batch)
+        assert 8 <= cnt <= 4000, (L, eb, batch, cnt)
+        if spec:
+            assert has.value == 1, (L, eb, batch, spec)
+    # nothing to enumerate below the multi-pass lengths
+    assert emu.phast_emu_enumerate_plans(10, 8, 1, None, C.byref(has), C.byref(bad)) == 0

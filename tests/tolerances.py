@@ -1,0 +1,85 @@
+"""The parity gates of the -m gpu tests, tied to the MEASURED error of the HIP path (the old gates --
+f64 rel-L2 <= 1e-13, per-bin <= 1e-11 rms; f32 1e-5 / 2e-3 -- sat two to four orders of magnitude above what the kernels
+do; a pre-twiddle that drifted 100 x would have passed).
+
+What is measured (tests/golden/error_budget.json, written on the MI355X by tests/golden/make_error_budget.py; the worst value
+per type, length and entry point over several seeds, plans and batch positions):
+    f64, uniform [-1, 1) inputs:  rel-L2 2e-16 ... 6e-16 for N = 2^4 ... 2^26,  worst bin / rms bin <= 4e-15
+    f32 against float64 pocketfft: rel-L2 1.5e-7 ... 3.5e-7,                    worst bin / rms bin <= 3e-6
+The gates are formulas in log2 N with a factor of ~4 ... 8 over those worst cases (the error of a radix-2-equivalent FFT grows
+like eps * sqrt(log2 N) on average, eps * log2 N at worst):
+
+    f64  rel-L2 <= 8e-16 * log2 N          per-bin <= 64 * eps64 * log2 N * rms      (2^20: 1.6e-14 / 2.8e-13)
+    f32  against a float64 reference:  rel-L2 <= 1e-6,  per-bin <= 5e-5 * rms
+    f32  against the f32 ORACLE only:  rel-L2 <= 1e-5,  per-bin <= 2e-3 * rms  -- the oracle restates the reference's
+         3.5-ulp f32 planner twiddles (planner.rs:83-88), which the GPU's correctly rounded tables do not share: that gap is
+         the reference's, and the loose bound is used nowhere else.
+    R2C / C2R f64 against the ORACLE: 1e-9 -- its rotation-recurrence twiddles drift (planner.rs:128-138); against an
+         independent real FFT the f64 formula above holds.
+
+tests/test_gpu_parity_r5.py::test_gates_notice_a_perturbed_twiddle shows that a single table entry off by 1e-9 (f64) fails
+them.  With PHAST_RECORD_ERRORS=<path> every checked value is appended to that file (how the budget was taken).
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+
+import numpy as np
+
+EPS64 = 2.220446049250313e-16
+
+
+def _lg(n_or_log2: int, is_log: bool) -> float:
+    return float(max(1, n_or_log2 if is_log else int(math.log2(max(2, n_or_log2)))))
+
+
+def f64_rel(log2n: int) -> float:
+    return 8e-16 * max(4.0, float(log2n))
+
+
+def f64_bin(log2n: int) -> float:
+    return 64.0 * EPS64 * max(4.0, float(log2n))
+
+
+F32_REL_VS_F64 = 1e-6
+F32_BIN_VS_F64 = 5e-5
+F32_REL_VS_ORACLE = 1e-5
+F32_BIN_VS_ORACLE = 2e-3
+F64_REAL_VS_ORACLE = 1e-9
+
+
+def rel_l2(got_re, got_im, ref_re, ref_im) -> float:
+    num = np.sqrt(np.sum((np.asarray(got_re, np.float64) - ref_re) ** 2 + (np.asarray(got_im, np.float64) - ref_im) ** 2))
+    den = np.sqrt(np.sum(np.asarray(ref_re, np.float64) ** 2 + np.asarray(ref_im, np.float64) ** 2))
+    return float(num / den) if den else float(num)
+
+
+def max_bin_err(got_re, got_im, ref_re, ref_im) -> float:
+    """largest single-bin error relative to the rms bin magnitude: a few wrong bins move the rel-L2 by ~sqrt(bins/N) only"""
+    e = np.maximum(np.abs(np.asarray(got_re, np.float64) - ref_re), np.abs(np.asarray(got_im, np.float64) - ref_im))
+    rms = np.sqrt(np.mean(np.asarray(ref_re, np.float64) ** 2 + np.asarray(ref_im, np.float64) ** 2))
+    return float(e.max()) / float(rms) if rms else float(e.max())
+
+
+def record(tag: str, log2n: int, rel: float, worst: float, gate_rel: float, gate_bin: float) -> None:
+    path = os.environ.get("PHAST_RECORD_ERRORS")
+    if path:
+        with open(path, "a") as f:
+            f.write(json.dumps({"tag": tag, "log2n": log2n, "rel": rel, "bin": worst, "gate_rel": gate_rel, "gate_bin": gate_bin}) + "\n")
+
+
+def check(tag: str, dt: str, log2n: int, got_re, got_im, ref_re, ref_im, against: str = "f64ref"):
+    """Assert the gate that applies to `dt` ("f64" | "f32") compared `against` "f64ref" (an independent float64 / long double
+    FFT, or -- for f64 -- the oracle: both round like the GPU) or "oracle" (f32 only: absorbs the reference's f32 twiddles)."""
+    rel, worst = rel_l2(got_re, got_im, ref_re, ref_im), max_bin_err(got_re, got_im, ref_re, ref_im)
+    if dt == "f64":
+        g_rel, g_bin = f64_rel(log2n), f64_bin(log2n)
+    elif against == "oracle":
+        g_rel, g_bin = F32_REL_VS_ORACLE, F32_BIN_VS_ORACLE
+    else:
+        g_rel, g_bin = F32_REL_VS_F64, F32_BIN_VS_F64
+    record(tag, log2n, rel, worst, g_rel, g_bin)
+    assert rel <= g_rel and worst <= g_bin, (tag, dt, log2n, against, rel, g_rel, worst, g_bin)
+    return rel, worst
