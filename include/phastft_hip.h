@@ -104,6 +104,9 @@ size_t phast_planner_dit64_device_bytes(const phast_planner_dit64 *p);
 size_t phast_planner_dit32_device_bytes(const phast_planner_dit32 *p);
 int phast_planner_dit64_describe(const phast_planner_dit64 *p, char *buf, size_t buf_len);
 int phast_planner_dit32_describe(const phast_planner_dit32 *p, char *buf, size_t buf_len);
+/* the plan a call of `kind` (PHAST_TUNE_*) with `batch` transforms runs, as text: "<which> [rows x cols ...]..." */
+int phast_planner_dit64_describe_call(const phast_planner_dit64 *p, size_t batch, int kind, char *buf, size_t buf_len);
+int phast_planner_dit32_describe_call(const phast_planner_dit32 *p, size_t batch, int kind, char *buf, size_t buf_len);
 /* optional: size the scratch for `max_batch` transforms in flight (default 1); realloc on demand otherwise */
 int phast_planner_dit64_reserve_batch(phast_planner_dit64 *p, size_t max_batch);
 int phast_planner_dit32_reserve_batch(phast_planner_dit32 *p, size_t max_batch);
@@ -146,6 +149,7 @@ int phast_planner_dit32_tune(phast_planner_dit32 *p, size_t batch_hint, int kind
 int phast_wisdom_export(char *buf, size_t buf_len, size_t *needed /* bytes incl. NUL, or NULL */);
 int phast_wisdom_import(const char *text); /* PHAST_ERR_INVALID_ARG: not a wisdom text */
 void phast_wisdom_forget(void);            /* everything but the built-in layer */
+void phast_wisdom_builtin(int enable);     /* the built-in layer off / on again at run time (planners made afterwards) */
 
 /* ---- planner.rs:164-212 ---- */
 typedef struct phast_planner_r2c64 phast_planner_r2c64; /* PlannerR2c64 */
@@ -158,6 +162,8 @@ void phast_planner_r2c32_free(phast_planner_r2c32 *p);
  * of one transform per call; `_tune`: kind = PHAST_TUNE_R2C or PHAST_TUNE_C2R) */
 int phast_planner_r2c64_with_mode(size_t n, int mode, phast_planner_r2c64 **out);
 int phast_planner_r2c32_with_mode(size_t n, int mode, phast_planner_r2c32 **out);
+int phast_planner_r2c64_describe_call(const phast_planner_r2c64 *p, size_t batch, int kind, char *buf, size_t buf_len);
+int phast_planner_r2c32_describe_call(const phast_planner_r2c32 *p, size_t batch, int kind, char *buf, size_t buf_len);
 int phast_planner_r2c64_tune(phast_planner_r2c64 *p, size_t batch_hint, int kind, phast_tune_report *report);
 int phast_planner_r2c32_tune(phast_planner_r2c32 *p, size_t batch_hint, int kind, phast_tune_report *report);
 

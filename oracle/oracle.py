@@ -302,7 +302,8 @@ def _declare_timing(l: C.CDLL) -> C.CDLL:
                        ("pho_time_fft_32_dit", [C.c_size_t, C.c_int, C.c_ulonglong]),
                        ("pho_time_fft_64_dit_parallel", [C.c_size_t, C.c_int, C.c_ulonglong, C.c_int]),
                        ("pho_time_fft_64_roundtrip", [C.c_size_t, C.c_int, C.c_ulonglong]),
-                       ("pho_time_r2c_fft_f32", [C.c_size_t, C.c_int, C.c_ulonglong])):
+                       ("pho_time_r2c_fft_f32", [C.c_size_t, C.c_int, C.c_ulonglong]),
+                       ("pho_time_c2r_fft_f32", [C.c_size_t, C.c_int, C.c_ulonglong])):
         getattr(l, name).restype = C.c_double
         getattr(l, name).argtypes = args
     return l
@@ -352,3 +353,7 @@ def parallel_threads() -> int:
 
 def time_r2c_fft_f32(n: int, iters: int, seed: int = 0xCAFE) -> float:
     return timing_lib().pho_time_r2c_fft_f32(n, iters, seed)
+
+
+def time_c2r_fft_f32(n: int, iters: int, seed: int = 0xCAFE) -> float:
+    return timing_lib().pho_time_c2r_fft_f32(n, iters, seed)

@@ -256,3 +256,28 @@ double pho_time_r2c_fft_f32(size_t n, int iters, unsigned long long seed) {
     pho_planner_r2c32_free(planner);
     return total;
 }
+
+/* the inverse leg (bench.py configs.c2r_f32_2p24): c2r_fft_f32_with_planner_and_scratch (r2c.rs:836-895) on a half-spectrum regenerated
+ * before every timed call, planner outside the timer */
+double pho_time_c2r_fft_f32(size_t n, int iters, unsigned long long seed) {
+    pho_planner_r2c32 *planner;
+    if (pho_planner_r2c32_new(n, &planner)) return -1.0;
+    size_t half = n / 2;
+    float *out = malloc(n * sizeof(float));
+    float *ire = malloc((half + 1) * sizeof(float)), *iim = malloc((half + 1) * sizeof(float));
+    float *sre = malloc(half * sizeof(float)), *sim = malloc(half * sizeof(float)); /* the caller's scratch (r2c.rs:836) */
+    double total = 0.0;
+    for (int it = 0; it < iters && out && ire && iim && sre && sim; ++it) {
+        pho_fill_f32(ire, iim, half + 1, seed, (unsigned long long)it);
+        double t0 = pho_now();
+        pho_c2r_fft_f32_with_planner_and_scratch(ire, half + 1, iim, half + 1, out, n, planner, sre, half, sim, half);
+        total += pho_now() - t0;
+    }
+    free(sre);
+    free(sim);
+    free(out);
+    free(ire);
+    free(iim);
+    pho_planner_r2c32_free(planner);
+    return total;
+}

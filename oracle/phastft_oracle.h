@@ -149,6 +149,7 @@ double pho_time_fft_64_dit_parallel(size_t n, int iters, unsigned long long seed
 int pho_parallel_threads(void);
 double pho_time_fft_64_roundtrip(size_t n, int iters, unsigned long long seed); /* forward + inverse per iteration */
 double pho_time_r2c_fft_f32(size_t n, int iters, unsigned long long seed);
+double pho_time_c2r_fft_f32(size_t n, int iters, unsigned long long seed);
 
 /* counter-based synthetic input shared with the HIP fill kernel:
  * u = splitmix64(seed ^ (transform_id << 40) ^ (2*i + is_imag)); value = (u >> 11) * 2^-52 - 1 in [-1, 1) */

@@ -37,7 +37,7 @@ import numpy as np
 from . import _lib
 
 __all__ = [
-    "Direction", "PlannerMode", "TuneKind", "wisdom_export", "wisdom_import", "wisdom_forget", "Options", "PhastPanic", "PhastHipError",
+    "Direction", "PlannerMode", "TuneKind", "wisdom_export", "wisdom_import", "wisdom_forget", "wisdom_builtin", "Options", "PhastPanic", "PhastHipError",
     "PlannerDit64", "PlannerDit32", "PlannerR2c64", "PlannerR2c32",
     "fft_64_dit", "fft_32_dit", "fft_64_dit_with_planner", "fft_32_dit_with_planner",
     "fft_64_dit_with_planner_and_opts", "fft_32_dit_with_planner_and_opts",
@@ -98,6 +98,11 @@ def wisdom_import(text: str) -> None:
 
 def wisdom_forget() -> None:
     _lib.lib().phast_wisdom_forget()
+
+
+def wisdom_builtin(enable: bool) -> None:
+    """The wisdom compiled into the library (csrc/builtin_wisdom.inc) off / on for planners made afterwards."""
+    _lib.lib().phast_wisdom_builtin(1 if enable else 0)
 
 
 ERR_INVALID_ARG = 16  # PHAST_ERR_INVALID_ARG (include/phastft_hip.h): e.g. a shape the strided kernels do not cover
@@ -235,6 +240,12 @@ class _PlannerDit:
     def device_bytes(self) -> int:
         return int(getattr(_lib.lib(), f"phast_planner_dit{self._sfx}_device_bytes")(self._h))
 
+    def describe_call(self, batch: int = 1, kind: "TuneKind" = 0) -> str:
+        """The plan a call with ``batch`` transforms runs: ``"<which> [rows x cols ...]..."`` (the library's own answer)."""
+        buf = C.create_string_buffer(512)
+        _check(getattr(_lib.lib(), f"phast_planner_dit{self._sfx}_describe_call")(self._h, C.c_size_t(batch), C.c_int(int(kind)), buf, C.c_size_t(512)))
+        return buf.value.decode()
+
     def check_guards(self) -> int:
         """debug: bytes of the scratch's guard bands overwritten since allocation (see :func:`debug_set_guard_bytes`)"""
         bad = C.c_size_t(0)
@@ -304,6 +315,12 @@ class _PlannerR2c:
     def with_mode(cls, n: int, mode: PlannerMode):
         """(no reference counterpart: the PlannerDit*::with_mode switch for the real transforms)"""
         return cls(n, mode)
+
+    def describe_call(self, batch: int = 1, kind: "TuneKind" = 2) -> str:
+        """The plan of the inner transform an ``r2c_fft`` / ``c2r_fft`` call with ``batch`` transforms runs."""
+        buf = C.create_string_buffer(512)
+        _check(getattr(_lib.lib(), f"phast_planner_r2c{self._sfx}_describe_call")(self._h, C.c_size_t(batch), C.c_int(int(kind)), buf, C.c_size_t(512)))
+        return buf.value.decode()
 
     def tune(self, batch: int = 1, kind: TuneKind = TuneKind.R2C) -> dict:
         """PlannerMode::Tune for ``batch`` real transforms per call, ``TuneKind.R2C`` or ``TuneKind.C2R``."""

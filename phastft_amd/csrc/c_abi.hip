@@ -97,6 +97,7 @@ int phast_wisdom_import(const char *text) {
     return WisdomStore::instance().import_text(text, 2) == 0 ? PHAST_OK : PHAST_ERR_INVALID_ARG;
 }
 void phast_wisdom_forget(void) { WisdomStore::instance().forget(); }
+void phast_wisdom_builtin(int enable) { WisdomStore::instance().set_builtin(enable != 0); }
 
 const char *phast_strerror(int code) {
     switch (code) {
@@ -203,6 +204,19 @@ int phast_options_guess(size_t input_size, phast_options *out) {
     }                                                                                                              \
     int phast_planner_dit##SFX##_describe(const phast_planner_dit##SFX *p, char *buf, size_t len) {                \
         return describe_to<T>(p, buf, len);                                                                        \
+    }                                                                                                              \
+    int phast_planner_dit##SFX##_describe_call(const phast_planner_dit##SFX *p, size_t batch, int kind, char *buf, \
+                                               size_t len) {                                                       \
+        if (!p || !buf || !len || (kind != kC2C && kind != kC2CI)) return PHAST_ERR_INVALID_ARG;                   \
+        std::snprintf(buf, len, "%s", p->describe_call(kind, batch).c_str());                                      \
+        return PHAST_OK;                                                                                           \
+    }                                                                                                              \
+    int phast_planner_r2c##SFX##_describe_call(const phast_planner_r2c##SFX *p, size_t batch, int kind, char *buf, \
+                                               size_t len) {                                                       \
+        if (!p || !buf || !len || (kind != kR2C && kind != kC2R)) return PHAST_ERR_INVALID_ARG;                    \
+        const PlannerR2c<T> *q = (p->twin && batch <= Planner<T>::twin_max_batch()) ? p->twin.get() : p;           \
+        std::snprintf(buf, len, "%s", q->dit.passes.empty() ? "one-pass" : q->dit.describe_call(kind, batch).c_str()); \
+        return PHAST_OK;                                                                                           \
     }                                                                                                              \
     int phast_planner_dit##SFX##_reserve_batch(phast_planner_dit##SFX *p, size_t max_batch) {                      \
         if (!p || max_batch == 0) return PHAST_ERR_INVALID_ARG;                                                    \

@@ -338,6 +338,7 @@ template <typename T> struct Planner {
     int tune_core(int kind, size_t batch, unsigned wisdom_log_n, int ring, bool grows, Run &&run, Refill &&refill, TuneReport *rep);
     int tune(int kind, size_t batch, TuneReport *rep);
     std::string describe() const;
+    std::string describe_call(int kind, size_t batch) const;
     // live tables and scratch plus what is retired but not yet released
     size_t device_bytes() const {
         std::lock_guard<std::mutex> lk(mu);

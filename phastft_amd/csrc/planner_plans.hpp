@@ -383,6 +383,36 @@ template <typename T> int Planner<T>::prepare_passes(std::vector<PassDesc> &ps) 
     return PHAST_OK;
 }
 
+// "<which plan> [rows x cols ...][...]" of the call (kind, batch): what bench.py and the tools label their numbers with -- the
+// library's own answer (choose), not a copy of its rules
+template <typename T> std::string Planner<T>::describe_call(int kind, size_t batch) const {
+    if (passes.empty()) return (twin && batch <= twin_max_batch()) ? twin->describe_call(kind, batch) : std::string("one-pass");
+    std::shared_lock<std::shared_mutex> plans(plan_mu);
+    const Choice c = choose(kind, batch ? batch : 1, batch ? batch : 1);
+    const std::vector<PassDesc> *v = c.passes;
+    std::string s = c.tuned                  ? "tuned"
+                    : v == &passes           ? "throughput"
+                    : v == &passes_mid       ? "mid"
+                    : v == &passes_lat       ? "latency"
+                    : v == &passes_one       ? "single"
+                    : v == &passes_c2r_one   ? "c2r-single"
+                    : v == &passes_c2r_lat   ? "c2r-latency"
+                    : v == &passes_r2c       ? "r2c-single"
+                    : v == &passes_r2c_tp    ? "r2c-batch"
+                    : v == &passes_c2r_tp    ? "c2r-batch"
+                                             : "?";
+    s += " ";
+    char buf[96];
+    for (const PassDesc &p : *v) {
+        std::snprintf(buf, sizeof buf, "[%ux%u%s %s%u]", 1u << p.lr, 1u << p.lc, p.transpose ? "A" : "", p.wave ? "w" : p.quad ? "q" : "p",
+                      1u << p.lp);
+        s += buf;
+    }
+    if (kind == kR2C && c.r2c_fuse && !v->empty() && v->back().r2c_blocks > 0) s += " untangle-fused";
+    if (kind == kC2R && !v->empty() && v->front().c2r_blocks > 0 && c2r_fuse_enabled()) s += " preprocess-fused";
+    return s;
+}
+
 template <typename T> std::string Planner<T>::describe() const {
     char buf[512];
     std::string s = "n=2^" + std::to_string(log_n);

@@ -103,6 +103,13 @@ class WisdomStore {
         load_layers_locked();
         for (auto it = entries_.begin(); it != entries_.end();) it = it->second.layer > 0 ? entries_.erase(it) : std::next(it);
     }
+    // the built-in layer on or off at run time (tests that look at the static rules' plans; tools: A/B of the two)
+    void set_builtin(bool on) {
+        std::lock_guard<std::mutex> lk(mu_);
+        load_layers_locked();
+        for (auto it = entries_.begin(); it != entries_.end();) it = it->second.layer == 0 ? entries_.erase(it) : std::next(it);
+        if (on) (void)import_locked(builtin_text(), 0, nullptr);  // (an entry of a later layer for the same key stays)
+    }
     size_t size() {
         std::lock_guard<std::mutex> lk(mu_);
         load_layers_locked();

@@ -32,3 +32,15 @@ def gpu():
     info = P.device_info()
     assert "gfx950" in info["name"], info
     return P
+
+
+@pytest.fixture
+def static_rules():
+    """For tests that assert on the plans of plan.hpp's static rules (pass counts, kernel names in describe()): planners made
+    inside the test do not see the library's built-in wisdom (csrc/builtin_wisdom.inc), which replaces those plans wherever the
+    tuner measured a faster one."""
+    import phastft_amd as P
+
+    P.wisdom_builtin(False)
+    yield
+    P.wisdom_builtin(True)

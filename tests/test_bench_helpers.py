@@ -1,5 +1,5 @@
-"""bench.py's host-side helpers (no GPU): the parsing of planner.describe() that decides which plan a call runs, how the
-plan is named on the JSON line and which profiled kernels its passes map to (profiles/traffic_latest.json)."""
+"""bench.py's host-side helpers (no GPU): how the plan a call runs is named on the JSON line and which profiled kernels its
+passes map to (profiles/traffic_latest.json)."""
 import json
 import os
 import sys
@@ -9,39 +9,38 @@ sys.path.insert(0, ROOT)
 
 import bench  # noqa: E402
 
-PLAN_20 = ("n=2^20 throughput=2p[1024x16A p32 lds=136192 wg/cu=1][1024x16 p32 lds=142336 wg/cu=1] "
-           "mid=2p[1024x8A p16 lds=70656 wg/cu=2][1024x8 p16 lds=76800 wg/cu=2] "
-           "latency=3p[64x64A p8 lds=67584 wg/cu=2][256x16 p8 lds=76288 wg/cu=2][64x64 p8 lds=72704 wg/cu=2] "
-           "single=3p[64x16A w16 lds=67072 wg/cu=2][256x16 q16 lds=69120 wg/cu=2][64x16 w16 lds=6656 wg/cu=4]")
-PLAN_R2C = ("n=2^23 throughput=3p[256x32A p16 lds=66304 wg/cu=2][256x32 p16 lds=67584 wg/cu=2][128x64 p16 lds=72192 wg/cu=2] "
-            "latency=3p[256x16A p8 lds=37376 wg/cu=4][256x16 p8 lds=38912 wg/cu=4][128x32 p8 lds=39424 wg/cu=4] "
-            "single=3p[256x16A p16 lds=35328 wg/cu=4][256x16 p16 lds=36864 wg/cu=4][128x32 p16 lds=39936 wg/cu=4]")
+SINGLE_20 = "[64x16A w16][256x16 q16][64x16 w16]"          # what Planner::describe_call answers for one f64 2^20 transform
+THROUGHPUT_20 = "[1024x16A p32][1024x16 p32]"
+R2C_SINGLE_23 = "[256x16A p16][256x16 p16][128x32 p16]"
 
 
-def test_plan_kind_follows_the_library():
-    n = 1 << 20
-    assert bench.plan_kind(None, n, 1, PLAN_20) == "single"
-    assert bench.plan_kind(None, n, 2, PLAN_20) == "single"
-    assert bench.plan_kind(None, n, 3, PLAN_20) == "mid"
-    assert bench.plan_kind(None, n, 15, PLAN_20) == "mid"
-    assert bench.plan_kind(None, n, 1, PLAN_20.split(" single=")[0]) == "latency"
-    assert bench.plan_kind(None, n, 16, PLAN_20) == "throughput"      # 2^24 points in flight, 16384-point tiles
-    assert bench.plan_kind(None, n, 1024, PLAN_20) == "throughput"
-    assert bench.plan_kind(None, 1 << 23, 1, PLAN_R2C, "f32") == "single"
-    assert bench.plan_kind(None, 1 << 23, 3, PLAN_R2C, "f32") == "latency"   # f32: the crossover sits one octave higher
-    assert bench.plan_kind(None, 1 << 23, 4, PLAN_R2C, "f32") == "throughput"
-    assert bench.plan_kind(None, 1 << 10, 64, "n=2^10 one pass (whole transforms on chip)") == "one-pass"
+class _FakePlanner:
+    """stands in for phastft_amd.PlannerDit64: bench.py labels its numbers with the LIBRARY's answer (describe_call ->
+    Planner::choose), not with a copy of the plan rules (round 5)"""
+
+    def __init__(self, text):
+        self.text, self.asked = text, None
+
+    def describe_call(self, batch, kind):
+        self.asked = (batch, kind)
+        return self.text
+
+
+def test_plan_label_is_the_librarys_answer():
+    pl = _FakePlanner("single " + SINGLE_20)
+    assert bench.plan_used(pl, 1) == ("single", SINGLE_20) and pl.asked == (1, 0)
+    pl = _FakePlanner("tuned [128x32A p8][128x32 p8][64x64 p8] untangle-fused")
+    which, lst = bench.plan_used(pl, 16, 2)
+    assert which == "tuned" and lst.endswith("untangle-fused") and pl.asked == (16, 2)
+    assert bench.plan_used(_FakePlanner("one-pass"), 64) == ("one-pass", "")
 
 
 def test_plan_lists_and_kernel_names():
-    lat = bench.plan_of(PLAN_20, "single")
-    assert lat.startswith("[64x16A w16") and lat.count("[") == 3
-    assert bench.kernel_tags(lat) == ["wave_fft_kernel<double, false, true>", "quad_fft_kernel<double>",
-                                      "wave_fft_kernel<double, true, false>"]
-    thr = bench.plan_of(PLAN_20, "throughput")
-    assert bench.kernel_tags(thr) == ["tile_fft_kernel<double, 10, 4, 5, false, true,",
-                                      "tile_fft_kernel<double, 10, 4, 5, true, false,"]
-    assert bench.kernel_tags(bench.plan_of(PLAN_R2C, "single"), "float")[2] == "tile_fft_kernel<float, 7, 5, 4, true, false,"
+    assert bench.kernel_tags(SINGLE_20) == ["wave_fft_kernel<double, false, true>", "quad_fft_kernel<double>",
+                                            "wave_fft_kernel<double, true, false>"]
+    assert bench.kernel_tags(THROUGHPUT_20) == ["tile_fft_kernel<double, 10, 4, 5, false, true,",
+                                                "tile_fft_kernel<double, 10, 4, 5, true, false,"]
+    assert bench.kernel_tags(R2C_SINGLE_23, "float")[2] == "tile_fft_kernel<float, 7, 5, 4, true, false,"
 
 
 def test_committed_traffic_profile_matches_the_default_plans():
@@ -49,10 +48,10 @@ def test_committed_traffic_profile_matches_the_default_plans():
     t = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
     for key in ("single_2p20", "single_2p26", "r2c_f32_2p24", "batch_2p20"):
         assert key in t and t[key]["kernels"], key
-    tr = bench.load_profiled_traffic(1, 1, 3, bench.kernel_tags(bench.plan_of(PLAN_20, "single")))
+    tr = bench.load_profiled_traffic(1, 1, 3, bench.kernel_tags(SINGLE_20))
     assert tr is not None and "quad_fft_kernel" in tr["traffic_kernel"]
     assert 1.0 <= tr["traffic"] / 33554432 < 1.02       # HBM bytes ~ algorithmic bytes
-    tb = bench.load_profiled_traffic(8, 0, 2, bench.kernel_tags(bench.plan_of(PLAN_20, "throughput")))
+    tb = bench.load_profiled_traffic(8, 0, 2, bench.kernel_tags(THROUGHPUT_20))
     assert tb is not None and 1.0 <= tb["traffic"] / (1024 * 33554432) < 1.02  # profiled per 1024-transform launch (round 3)
 
 
@@ -60,7 +59,8 @@ def test_roofline_arithmetic():
     roof, dom = bench.roofline_of([0.008, 0.010, 0.008], 33554432, plan_used="x")
     assert dom == 1 and abs(roof["achieved"] - 33554432 / 0.010e-3 / 1e9) < 1e-6
     assert abs(roof["frac"] - roof["achieved"] / 8000.0) < 1e-12
-    assert abs(roof["transform_frac"] - 33554432 / 0.026e-3 / 1e9 / 8000.0) < 1e-9 and roof["passes"] == 3
+    assert roof["frac_dominant_pass"] == roof["frac"]
+    assert abs(roof["frac_transform"] - 33554432 / 0.026e-3 / 1e9 / 8000.0) < 1e-9 and roof["passes"] == 3
 
 
 # ---------------------------------------------------------------- round 4: `bench.py --gpus N` cannot mis-measure

@@ -363,7 +363,7 @@ def test_strided_batch_with_fused_input_twiddle(gpu, oracle, k, s, total_log, co
 
 
 @pytest.mark.parametrize("k", [15, 16, 20, 21, 22])
-def test_real_transforms_f64_through_wave_and_quad_plans(gpu, oracle, k):
+def test_real_transforms_f64_through_wave_and_quad_plans(gpu, oracle, k, static_rules):
     """One f64 real transform whose inner N/2-point complex transform runs a wave-/quad-tile plan (2^14, 2^15, 2^19 … 2^21;
     round 4 moved 2^22 and 2^23 to generic tiles, plan.hpp: single_plan):
     the first pass reads the real signal as (even, odd) pairs (wave tiles or generic), the last pass of C2R stores (im, re)

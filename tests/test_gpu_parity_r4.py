@@ -78,7 +78,7 @@ def _c2r_model_f64(x_re, x_im, n):
 
 @pytest.mark.parametrize("k,batch,dt", [(24, 1, "f32"), (24, 1, "f64"), (26, 1, "f32"), (25, 1, "f64"), (23, 2, "f32"),
                                         (20, 32, "f32"), (19, 32, "f64"), (16, 512, "f32"), (21, 1, "f64")])
-def test_c2r_fused_first_pass_non_hermitian_vs_oracle(gpu, oracle, k, batch, dt):
+def test_c2r_fused_first_pass_non_hermitian_vs_oracle(gpu, oracle, k, batch, dt, static_rules):
     """Half-spectra with random imaginary parts EVERYWHERE, incl. X[0] and X[h] (round 3 fed the fused kernel spectra of
     real signals only): every output of the first and last transform against the oracle's c2r (which accepts any input) and
     an independent float64 model, rel-L2 and the worst single sample."""
@@ -230,7 +230,7 @@ def test_bench_dist_fft_mode_times_every_stage(gpu, argv, world):
 
 
 # ---------------------------------------------------------------- the fused real-transform passes beyond 2^26
-def test_r2c_f32_2p27_fused_every_output(gpu, oracle):
+def test_r2c_f32_2p27_fused_every_output(gpu, oracle, static_rules):
     """Real transforms of 2^27 / 2^28 points ran the untangle as a sweep of its own until round 4 (the throughput plan's 32-point
     last pass has no fused form); `plan.hpp: real_plan` now gives them inner plans whose last pass fuses.  f32 2^27: three
     kernels, every one of the 2^26 + 1 bins against the oracle's r2c and an independent float64 real FFT, the worst single
@@ -266,7 +266,7 @@ def test_r2c_f32_2p27_fused_every_output(gpu, oracle):
 
 @pytest.mark.parametrize("k,dt", [(20, "f64"), (21, "f64"), (22, "f64"), (23, "f64"), (24, "f64"), (25, "f64"), (26, "f64"),
                                   (20, "f32"), (21, "f32"), (22, "f32"), (23, "f32"), (25, "f32"), (26, "f32")])
-def test_real_transform_plans_every_output(gpu, k, dt):
+def test_real_transform_plans_every_output(gpu, k, dt, static_rules):
     """One R2C / C2R transform runs the plan ranked for the real transform itself where `plan.hpp: real_plan` has one (round 4;
     `r2c-single=` / `c2r-single=` in describe()).  Every bin of r2c_fft against an independent float64 real FFT (rel-L2 and
     the worst single bin), exact zeros in Im X[0] and Im X[h], and c2r_fft gives the signal back -- at every size that has
@@ -328,7 +328,7 @@ def test_planner_pool_stress_eight_threads_three_planners(gpu, tmp_path):
 
 
 @pytest.mark.parametrize("k", [27, 28])
-def test_r2c_f64_large_fused_vs_c2c_route(gpu, k):
+def test_r2c_f64_large_fused_vs_c2c_route(gpu, k, static_rules):
     """`r2c_fft_f64` of 2^27 / 2^28 real points runs a ranked plan with the untangle in the last pass (`real_plan`, round 4).
     Every bin against the library's own C2C transform of the same signal with a zero imaginary part (another plan, other
     kernels, no untangle): X[j] = C[j] for j <= N/2 -- rel-L2 and the worst single bin; then C2R gives the signal back."""
@@ -360,7 +360,7 @@ def test_r2c_f64_large_fused_vs_c2c_route(gpu, k):
 
 # ---------------------------------------------------------------- ONE transform of 8192 points: the multi-pass twin
 @pytest.mark.parametrize("dt", ["f64", "f32"])
-def test_one_transform_of_8192_points_runs_the_multi_pass_twin(gpu, oracle, dt):
+def test_one_transform_of_8192_points_runs_the_multi_pass_twin(gpu, oracle, dt, static_rules):
     """N = 2^13 is the largest size of the one-pass kernel (one workgroup per transform): right for batches, 16 us for ONE
     transform.  A planner of that size keeps a multi-pass twin (`planner.hpp: Planner::twin`) that serves up to 128 transforms --
     through every entry point, so that the same transform gives the same bits from host slices, device pointers and a captured
@@ -459,7 +459,7 @@ def test_small_twin_switch_restores_the_one_pass_kernel(gpu):
 
 # ---------------------------------------------------------------- batches of real transforms on their own plans
 @pytest.mark.parametrize("k,dt", [(14, "f32"), (14, "f64"), (15, "f32"), (15, "f64"), (17, "f32"), (18, "f64"), (20, "f32"), (20, "f64")])
-def test_batched_real_transforms_run_the_plans_ranked_for_batches(gpu, k, dt):
+def test_batched_real_transforms_run_the_plans_ranked_for_batches(gpu, k, dt, static_rules):
     """`plan.hpp: real_batch_plan` (round 4): in the throughput regime a batch of R2C / C2R transforms runs a plan whose last /
     first pass has the fused untangle / preprocess form (`r2c-batch=` / `c2r-batch=` in describe()) instead of the C2C
     throughput plan + a sweep.  2^26 real samples in flight; rows at both ends and in the middle of the batch against an

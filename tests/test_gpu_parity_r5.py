@@ -3,8 +3,8 @@
 * PlannerMode::Tune is real (planner.rs:18-32): a tuning run is never slower than the static rules (within 3 %) at eight
   (length, batch, kind) points, its plan's results stay within the parity gates, N = 2^20 tunes in under a second, and what it
   finds travels as wisdom text to planners made later.
-* The parity gates (tests/tolerances.py) are tight enough to notice ONE twiddle-table entry that is off by 1e-12 (f64) /
-  2e-5 (f32) -- the round-4 gates (1e-13 / 1e-5) would have passed both.
+* The parity gates (tests/tolerances.py) are tight enough to notice ONE twiddle-table entry that is off by 5e-13 (f64) /
+  5e-5 (f32) -- the round-4 gates (1e-13 / 1e-5) would have passed both.
 * Non-finite and subnormal inputs go through the HIP path as through the oracle (C2C, R2C, C2R at 2^10 and 2^20).
 * Stream capture: a capture never takes a workspace another thread's stream is working in; 8192-point
   planners capture without a warm-up call again; graph workspaces can be handed back; replaced plans leave
@@ -149,7 +149,7 @@ def _time_alternating(calls, ring, rounds=7):
 
 
 @pytest.mark.parametrize("dt,L,batch,kind", TUNE_POINTS)
-def test_tune_is_not_slower_and_stays_within_tolerance(gpu, dt, L, batch, kind):
+def test_tune_is_not_slower_and_stays_within_tolerance(gpu, static_rules, dt, L, batch, kind):
     """Heuristic planner against a planner that tuned for exactly this call: interleaved timing over a cold ring, Tune >=
     Heuristic - 3 %; the tuned plan's results within the gates of a float64 reference, first and last transform of the batch."""
     P = gpu
@@ -174,7 +174,7 @@ def test_tune_is_not_slower_and_stays_within_tolerance(gpu, dt, L, batch, kind):
         assert "tuned:" in tuned.describe() and "tuned:" not in heur.describe()
 
 
-def test_tune_2p20_takes_under_a_second(gpu):
+def test_tune_2p20_takes_under_a_second(gpu, static_rules):
     """'Adds planning overhead proportional to FFT size' (planner.rs:30-31): N = 2^20, one transform -- every plan that exists
     (several hundred) screened and the finalists confirmed in under a second; with_mode(Tune) is that plus the planner."""
     import time
@@ -202,7 +202,7 @@ def test_tune_2p20_takes_under_a_second(gpu):
         pl.tune(0)
 
 
-def test_wisdom_travels_to_planners_made_later(gpu, oracle):
+def test_wisdom_travels_to_planners_made_later(gpu, oracle, static_rules):
     """Import a plan as wisdom text -> the next planner of that type and length runs it for the bucket it names (and only for
     that bucket and kind), bit-identical to a planner forced onto the same plan; forget -> planners are static again."""
     import torch
@@ -267,13 +267,13 @@ d_re, d_im = torch.from_numpy(h_re.copy()).cuda(), torch.from_numpy(h_im.copy())
 z = np.fft.fft(h_re.astype(np.float64) + 1j * h_im.astype(np.float64))
 g_re, g_im = d_re.cpu().numpy(), d_im.cpu().numpy()
 rel, worst = tol.rel_l2(g_re, g_im, z.real, z.imag), tol.max_bin_err(g_re, g_im, z.real, z.imag)
-new_ok = (rel <= tol.f64_rel(L) and worst <= tol.f64_bin(L)) if dt == "f64" else (rel <= tol.F32_REL_VS_F64 and worst <= tol.F32_BIN_VS_F64)
+new_ok = (rel <= tol.f64_rel(L) and worst <= tol.f64_bin(L)) if dt == "f64" else (rel <= tol.f32_rel(L) and worst <= tol.f32_bin(L))
 old_ok = (rel <= 1e-13 and worst <= 1e-11) if dt == "f64" else (rel <= 1e-5 and worst <= 2e-3)
 print("RESULT", int(new_ok), int(old_ok), rel, worst)
 """
 
 
-@pytest.mark.parametrize("dt,L,perturb", [("f64", 20, "1e-12"), ("f32", 20, "2e-5"), ("f64", 24, "1e-9")])
+@pytest.mark.parametrize("dt,L,perturb", [("f64", 20, "5e-13"), ("f32", 20, "5e-5"), ("f64", 24, "1e-9")])
 def test_gates_notice_a_perturbed_twiddle(gpu, dt, L, perturb, tmp_path):
     """PHAST_TEST_PERTURB_TW3 (a test hook of Planner::table) puts a relative error on ONE entry of every three-level twiddle
     table.  The same script runs clean and perturbed: clean passes the gates of tests/tolerances.py; perturbed fails them --
@@ -331,8 +331,8 @@ def _run_kind(P, oracle, kind, dt, n, h_a, h_b):
 @pytest.mark.parametrize("kind", ["c2c", "r2c", "c2r"])
 def test_nonfinite_and_subnormal_inputs_like_the_oracle(gpu, oracle, kind, L, dt):
     """Every output of an FFT depends on every input: one NaN (or one +Inf: Inf * w and Inf - Inf) in the input leaves NO finite
-    output -- on the HIP path as in the oracle (which elements are NaN and which Inf depends on where an algorithm multiplies
-    by an exact 0 or 1, so only finiteness is compared).  Subnormal inputs are NOT flushed: the outputs agree with the oracle's
+    output bin -- on the HIP path as in the oracle (which components are NaN, which Inf and which survive depends on where an
+    algorithm multiplies by an exact 0 or 1, so only the finiteness of whole bins is compared).  Subnormal inputs are NOT flushed: the outputs agree with the oracle's
     to a few quanta of the subnormal range and are far from zero."""
     n = 1 << L
     ndt = np.float64 if dt == "f64" else np.float32
@@ -341,9 +341,14 @@ def test_nonfinite_and_subnormal_inputs_like_the_oracle(gpu, oracle, kind, L, dt
         a, b = rng.uniform(-1, 1, n).astype(ndt), rng.uniform(-1, 1, n).astype(ndt)
         a[n // 3] = bad
         got, want = _run_kind(gpu, oracle, kind, dt, n, a, b)
+        # per BIN (c2r: per sample): a complex bin may keep ONE finite component where an algorithm skips the multiplication by a
+        # trivial twiddle (W = +-1, +-i: the GPU's radix butterflies do, the oracle's table-driven stages multiply NaN by 0)
+        bad_g = np.zeros(len(got[0]), bool)
+        bad_w = np.zeros(len(want[0]), bool)
         for g, w in zip(got, want):
-            frac_g, frac_w = float(np.mean(~np.isfinite(g))), float(np.mean(~np.isfinite(w)))
-            assert frac_g == 1.0 and frac_w == 1.0, (kind, dt, L, bad, frac_g, frac_w)
+            bad_g |= ~np.isfinite(g)
+            bad_w |= ~np.isfinite(w)
+        assert bad_g.all() and bad_w.all(), (kind, dt, L, bad, float(bad_g.mean()), float(bad_w.mean()))
     # subnormal inputs: |x| < 2^-1040 (f64: subnormal below 2^-1022, quantum 2^-1074) / 2^-133 (f32: 2^-126, 2^-149).  Every
     # rounding on the way is at least half a quantum ABSOLUTE; through log2 N stages those errors random-walk like the signal,
     # ~ quantum * sqrt(N) (c2r: times its 1/(N/2) scale, plus the final rounding).
@@ -433,7 +438,9 @@ def test_capture_never_takes_another_threads_busy_workspace(gpu, oracle):
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.stream(s2):
-            with torch.cuda.graph(g, stream=s2):
+            # (thread-local capture mode: in the default global mode ANY thread's event query or allocation -- thread B's,
+            # here -- invalidates a capture in progress, whatever library made the call)
+            with torch.cuda.graph(g, stream=s2, capture_error_mode="thread_local"):
                 P.fft_64_dit_with_planner(g_re, g_im, P.Direction.Forward, pl)
         src_re, src_im = dev(h_re.copy()), dev(h_im.copy())
         for _ in range(40):
@@ -457,7 +464,7 @@ def test_capture_never_takes_another_threads_busy_workspace(gpu, oracle):
     assert float((a_re.cpu() - torch.from_numpy(h_re)).abs().max()) < 1e-12
 
 
-def test_replaced_plans_leave_no_tables_behind(gpu):
+def test_replaced_plans_leave_no_tables_behind(gpu, static_rules):
     """every set_plan used to park the replaced plan's tables until the planner died and count them twice.
     Tables are shared per planner now: forty plan changes between three plans add three plans' worth of tables, once."""
     P = gpu
@@ -472,3 +479,99 @@ def test_replaced_plans_leave_no_tables_behind(gpu):
     assert pl.device_bytes() == settled, (settled, pl.device_bytes())
     pl.set_plan(())
     assert pl.device_bytes() <= settled + (1 << 20)
+
+
+# ---------------------------------------------------------------- a torch-free sharded host over the C ABI + RCCL
+def test_torch_free_sharded_host_with_rccl_gather(gpu, oracle, tmp_path):
+    """tests/cpp/shard_host.cpp: BASELINE configs[4]'s path without Python or torch -- one C++ thread per visible device, a
+    planner per device, on-device fill -> phast_fft_64_dit_dev -> phast_digest_f64_dev, ncclCommInitAll + ONE ncclAllGather of
+    the 32-byte digests through librccl.so.  Compiled and run here on the visible device(s) (an RCCL communicator of that
+    size); every gathered digest is checked: Parseval for all transforms, sampled ones against digests of the CPU oracle's
+    output of the same seeded inputs (the oracle is the checker).  Its throughput is that of the Python host's path."""
+    import json
+
+    import torch
+
+    from phastft_amd import build
+
+    lib = build.build()
+    exe = tmp_path / "shard_host"
+    r = subprocess.run([build.hipcc(), "-O2", "-std=c++17", "--offload-arch=gfx950", os.path.join(ROOT, "tests", "cpp", "shard_host.cpp"),
+                        "-I", os.path.join(ROOT, "include"), "-L", os.path.dirname(lib), "-lphastft_hip", "-L", "/opt/rocm/lib", "-lrccl",
+                        "-pthread", "-Wl,-rpath," + os.path.dirname(lib), "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    gpus = torch.cuda.device_count()
+    shard, n = 256, 1 << 20
+    dig = tmp_path / "digests.bin"
+    env = {k: v for k, v in os.environ.items() if not k.startswith(("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_"))}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    r = subprocess.run([str(exe), "--shard", str(shard), "--steps", "5", "--warmup", "2", "--digests-out", str(dig)],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1, r.stdout
+    out = json.loads(line[0])
+    total = shard * gpus
+    assert out["n_gpus"] == gpus and out["scaling"] == "weak" and out["config"]["digests_finite"] is True
+    assert "ncclAllGather" in out["config"]["digest_gather"]
+    d = np.fromfile(dig, dtype=np.float64).reshape(total, 4)
+    # Parseval on every transform: sum |X|^2 = N sum |x|^2, inputs regenerated with the same counter-based generator
+    ids = sorted({0, 1, shard // 2, shard - 1, total - 1})
+    for tid in ids:
+        h_re, h_im = oracle.fill(n, np.float64, seed=0xCAFE, transform_id=tid)
+        e_in = float(np.sum(h_re ** 2 + h_im ** 2))
+        assert abs(d[tid, 2] / (n * e_in) - 1.0) < 1e-12, tid
+        oracle.fft_64_dit(h_re, h_im, oracle.FORWARD)
+        scale = np.sqrt(n * e_in)
+        assert abs(d[tid, 0] - h_re.sum()) <= 1e-10 * scale * np.sqrt(n) and abs(d[tid, 1] - h_im.sum()) <= 1e-10 * scale * np.sqrt(n), tid
+        assert abs(d[tid, 2] / float(np.sum(h_re ** 2 + h_im ** 2)) - 1.0) <= 1e-12 and abs(d[tid, 3] - h_re[1]) <= 1e-12 * scale, tid
+    assert np.all(np.isfinite(d)) and np.all(d[:, 2] > 0)
+    # the same shard through the Python host on this device: the torch-free host is not slower (3 % + noise)
+    P = gpu
+    pl = P.PlannerDit64(n)
+    re = torch.empty(shard * n, dtype=torch.float64, device="cuda"); im = torch.empty_like(re)
+    P.fill_uniform(re, im, n, seed=0xCAFE, first_id=0)
+    for _ in range(2):
+        P.fft_dit_batched(re, im, n, P.Direction.Forward, pl)
+    P.fill_uniform(re, im, n, seed=0xCAFE, first_id=0)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        P.fft_dit_batched(re, im, n, P.Direction.Forward, pl)
+    e1.record()
+    torch.cuda.synchronize()
+    py_value = shard * n * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    print(f"\nshard_host {out['value']:.1f} GSamples/s over {gpus} device(s) (per device {out['value'] / gpus:.1f}); Python host {py_value:.1f} on one")
+    assert out["value"] / gpus >= 0.9 * py_value, (out["value"], gpus, py_value)
+
+
+# ---------------------------------------------------------------- the committed error budget still holds
+def test_error_budget_holds(gpu):
+    """tests/golden/error_budget.json (tests/golden/make_error_budget.py on the MI355X) is what the gates of tests/tolerances.py
+    are derived from: every committed value sits at least 2.5 x below its gate, and a sample re-measured here with the
+    generator's own code (whatever plans wisdom has put in force since) still sits 2 x below."""
+    import importlib.util
+    import json
+
+    budget = json.load(open(os.path.join(ROOT, "tests", "golden", "error_budget.json")))["budget"]
+    for key, per_len in budget.items():
+        dt = "f64" if "f64" in key else "f32"
+        for L, e in per_len.items():
+            if "roundtrip" in key or "vs_oracle" in key:
+                continue  # (two transforms / the reference's f32 twiddles: their own criteria)
+            g_rel, g_bin = (tol.f64_rel(int(L)), tol.f64_bin(int(L))) if dt == "f64" else (tol.f32_rel(int(L)), tol.f32_bin(int(L)))
+            assert e["rel"] * 2.5 <= g_rel and e["bin"] * 2.5 <= g_bin, (key, L, e, g_rel, g_bin)
+    spec = importlib.util.spec_from_file_location("make_error_budget", os.path.join(ROOT, "tests", "golden", "make_error_budget.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for lo, hi in ((10, 10), (16, 16), (20, 20)):
+        now = mod.measure(lo, hi, seeds=(1,))
+        for key, per_len in now.items():
+            dt = "f64" if "f64" in key else "f32"
+            for L, e in per_len.items():
+                if "roundtrip" in key or "vs_oracle" in key:
+                    continue
+                g_rel, g_bin = (tol.f64_rel(int(L)), tol.f64_bin(int(L))) if dt == "f64" else (tol.f32_rel(int(L)), tol.f32_bin(int(L)))
+                assert e["rel"] * 2.0 <= g_rel and e["bin"] * 2.0 <= g_bin, (key, L, e, budget[key][L], g_rel, g_bin)

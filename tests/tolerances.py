@@ -2,37 +2,36 @@
 f64 rel-L2 <= 1e-13, per-bin <= 1e-11 rms; f32 1e-5 / 2e-3 -- sat two to four orders of magnitude above what the kernels
 do; a pre-twiddle that drifted 100 x would have passed).
 
-What is measured (tests/golden/error_budget.json, written on the MI355X by tests/golden/make_error_budget.py; the worst value
-per type, length and entry point over several seeds, plans and batch positions):
-    f64, uniform [-1, 1) inputs:  rel-L2 2e-16 ... 6e-16 for N = 2^4 ... 2^26,  worst bin / rms bin <= 4e-15
-    f32 against float64 pocketfft: rel-L2 1.5e-7 ... 3.5e-7,                    worst bin / rms bin <= 3e-6
-The gates are formulas in log2 N with a factor of ~4 ... 8 over those worst cases (the error of a radix-2-equivalent FFT grows
-like eps * sqrt(log2 N) on average, eps * log2 N at worst):
+What is measured (tests/golden/error_budget.json, written on the MI355X by tests/golden/make_error_budget.py: the worst value
+per type, length and entry point over the seeds, single transforms and the last transform of a batch):
+
+    f64, uniform [-1, 1) inputs, against a long-double FFT:  rel-L2 1.4e-16 (N = 2^4) ... 1.4e-15 (the 32-point-per-thread
+         throughput plans at 2^18 .. 2^21; 2^26: 1.3e-15);  worst bin / rms bin 3e-16 ... 1.6e-14
+    f32 against float64 pocketfft:  rel-L2 7e-8 (2^4) ... 9.5e-7 (2^24 batch, 2^26);  worst bin / rms bin 1.5e-7 ... 1.1e-5
+         -- it grows with log2 N, so a flat 1e-6 (VERDICT r04's proposal) would sit ON the measured value at 2^24 and beyond
+
+The gates are formulas in log2 N with a factor >= 3.7 over those worst cases (f64: >= 10) (the error of a radix-2-equivalent FFT grows like
+eps * sqrt(log2 N) on average, eps * log2 N at worst):
 
     f64  rel-L2 <= 8e-16 * log2 N          per-bin <= 64 * eps64 * log2 N * rms      (2^20: 1.6e-14 / 2.8e-13)
-    f32  against a float64 reference:  rel-L2 <= 1e-6,  per-bin <= 5e-5 * rms
+    f32  against a float64 reference:  rel-L2 <= 1.5e-7 * log2 N,  per-bin <= 2e-6 * log2 N * rms   (2^20: 3e-6 / 4e-5)
     f32  against the f32 ORACLE only:  rel-L2 <= 1e-5,  per-bin <= 2e-3 * rms  -- the oracle restates the reference's
          3.5-ulp f32 planner twiddles (planner.rs:83-88), which the GPU's correctly rounded tables do not share: that gap is
          the reference's, and the loose bound is used nowhere else.
     R2C / C2R f64 against the ORACLE: 1e-9 -- its rotation-recurrence twiddles drift (planner.rs:128-138); against an
-         independent real FFT the f64 formula above holds.
+         independent real FFT the f64 formula above holds (measured 1.3e-16 ... 8e-16).
 
-tests/test_gpu_parity_r5.py::test_gates_notice_a_perturbed_twiddle shows that a single table entry off by 1e-9 (f64) fails
-them.  With PHAST_RECORD_ERRORS=<path> every checked value is appended to that file (how the budget was taken).
+tests/test_gpu_parity_r5.py::test_gates_notice_a_perturbed_twiddle shows that ONE table entry off by 5e-13 (f64) / 5e-5 (f32)
+fails them where the round-4 gates passed.  With PHAST_RECORD_ERRORS=<path> every checked value is appended to that file.
 """
 from __future__ import annotations
 
 import json
-import math
 import os
 
 import numpy as np
 
 EPS64 = 2.220446049250313e-16
-
-
-def _lg(n_or_log2: int, is_log: bool) -> float:
-    return float(max(1, n_or_log2 if is_log else int(math.log2(max(2, n_or_log2)))))
 
 
 def f64_rel(log2n: int) -> float:
@@ -43,8 +42,14 @@ def f64_bin(log2n: int) -> float:
     return 64.0 * EPS64 * max(4.0, float(log2n))
 
 
-F32_REL_VS_F64 = 1e-6
-F32_BIN_VS_F64 = 5e-5
+def f32_rel(log2n: int) -> float:
+    return 1.5e-7 * max(4.0, float(log2n))
+
+
+def f32_bin(log2n: int) -> float:
+    return 2e-6 * max(4.0, float(log2n))
+
+
 F32_REL_VS_ORACLE = 1e-5
 F32_BIN_VS_ORACLE = 2e-3
 F64_REAL_VS_ORACLE = 1e-9
@@ -79,7 +84,7 @@ def check(tag: str, dt: str, log2n: int, got_re, got_im, ref_re, ref_im, against
     elif against == "oracle":
         g_rel, g_bin = F32_REL_VS_ORACLE, F32_BIN_VS_ORACLE
     else:
-        g_rel, g_bin = F32_REL_VS_F64, F32_BIN_VS_F64
+        g_rel, g_bin = f32_rel(log2n), f32_bin(log2n)
     record(tag, log2n, rel, worst, g_rel, g_bin)
     assert rel <= g_rel and worst <= g_bin, (tag, dt, log2n, against, rel, g_rel, worst, g_bin)
     return rel, worst
