@@ -408,7 +408,8 @@ template <> hipError_t launch_bitrev<float>(float *data, unsigned log_n, size_t 
     auto *p = reinterpret_cast<unsigned *>(data);
     if (log_n < 12) return launch_bitrev_u<unsigned, 6, 512>(p, log_n, batch, dist, s);
     const bool even = (dist & 3) == 0 && (reinterpret_cast<size_t>(data) & 15) == 0;
-    if (even && (((size_t)batch << log_n) >= ((size_t)1 << PHAST_BITREV_F32_P2_MIN_LOG)))
+    // (the default of 99 means "never": the comparison is guarded -- a 64-bit shift by 99 is undefined)
+    if (even && PHAST_BITREV_F32_P2_MIN_LOG < 64 && (((size_t)batch << log_n) >= ((size_t)1 << (PHAST_BITREV_F32_P2_MIN_LOG & 63))))
         return launch_bitrev_persistent2<unsigned, 6, 256, true>(p, log_n, batch, dist, s, 4);
     return launch_bitrev_persistent<unsigned, 6, 512>(p, log_n, batch, dist, s, 4);
 }

@@ -26,6 +26,7 @@ struct SmallArgs {
     const void *rtw3;
 };
 constexpr unsigned kSmallMaxLog = 13;
+constexpr unsigned kTwinMinLog = 12;  // the shortest length that also exists as a multi-pass plan (64 x 64: Planner::twin)
 template <typename T>
 hipError_t launch_small_fft(const SmallArgs &a, hipStream_t stream, hipEvent_t ev_start = nullptr,
                             hipEvent_t ev_stop = nullptr);

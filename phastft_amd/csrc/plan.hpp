@@ -181,7 +181,7 @@ inline void heuristic_plan(unsigned L, bool latency, std::vector<unsigned> &lrs,
     lrs.clear();
     tls.assign(1, 12);
     lp = 4;
-    if (L < kSmallMaxLog) return;  // (L = kSmallMaxLog: the multi-pass twin of the one-pass kernel's largest size, planner.hpp)
+    if (L < kTwinMinLog) return;  // (L = 12, 13: the multi-pass twins of the one-pass kernel's largest sizes, planner.hpp)
     auto split = [&](unsigned np) {
         lrs.clear();
         for (unsigned i = 0; i < np; ++i) lrs.push_back(L / np + (i < L % np ? 1 : 0));  // balanced, larger first
@@ -247,12 +247,13 @@ inline bool single_plan(unsigned L, std::vector<unsigned> &lrs, std::vector<unsi
         unsigned L, a, b, c, ta, tb, tc, lp;  // c = 0: two passes
     };
     constexpr unsigned W = kWaveTiles;  // 64 x 16 wave tiles (wave_fft.hpp) and the four-wave 256 x 16 pass (quad_fft.hpp)
-    static const E f64[] = {{13, 6, 7, 0, 10, 11, 0, 3 | W},  // (8192 points: Planner::twin, planner.hpp)
+    static const E f64[] = {{12, 6, 6, 0, 10, 10, 0, 3},      // (4096 / 8192 points: Planner::twin, planner.hpp)
+                            {13, 6, 7, 0, 10, 11, 0, 3 | W},
                             {14, 6, 8, 0, 10, 12, 0, 4 | W},  {15, 7, 8, 0, 10, 12, 0, 3 | W},  {16, 8, 8, 0, 11, 11, 0, 3},      {17, 8, 9, 0, 11, 12, 0, 3},
                             {19, 6, 7, 6, 10, 11, 10, 3 | W}, {20, 6, 8, 6, 10, 12, 10, 3 | W},
                             {21, 6, 8, 7, 10, 12, 12, 3 | W}, {22, 8, 7, 7, 13, 12, 13, 4},     {23, 7, 9, 7, 13, 12, 13, 4},     {24, 8, 9, 7, 13, 12, 13, 4},
                             {25, 8, 9, 8, 12, 12, 14, 4},     {27, 8, 10, 9, 13, 14, 14, 5},    {28, 9, 9, 10, 14, 14, 14, 5}};
-    static const E f32[] = {{14, 7, 7, 0, 11, 11, 0, 3},  {15, 8, 7, 0, 12, 11, 0, 3},  {19, 6, 7, 6, 11, 11, 11, 3}, {22, 7, 8, 7, 13, 13, 13, 4}, {23, 8, 8, 7, 12, 12, 12, 4}, {25, 8, 9, 8, 14, 13, 14, 4}};
+    static const E f32[] = {{12, 6, 6, 0, 10, 10, 0, 3},  {14, 7, 7, 0, 11, 11, 0, 3},  {15, 8, 7, 0, 12, 11, 0, 3},  {19, 6, 7, 6, 11, 11, 11, 3}, {22, 7, 8, 7, 13, 13, 13, 4}, {23, 8, 8, 7, 12, 12, 12, 4}, {25, 8, 9, 8, 14, 13, 14, 4}};
     const E *tab = sizeof(T) == 8 ? f64 : f32;
     const size_t cnt = (sizeof(T) == 8 ? sizeof f64 : sizeof f32) / sizeof(E);
     for (size_t i = 0; i < cnt; ++i)
@@ -599,7 +600,7 @@ inline double plan_model_us(const std::vector<PassGeom> &ps, unsigned L, size_t 
 // -- what tools/sweep_single_cold.py and tools/sweep_real*.py enumerated by hand until round 5.  Sorted by plan_model_us.
 inline void enumerate_plans(unsigned L, size_t elem_bytes, size_t batch, unsigned tl_lo, unsigned tl_hi, std::vector<PlanSpec> &out) {
     out.clear();
-    if (L <= kSmallMaxLog - 1 || L > 31) return;
+    if (L < kTwinMinLog || L > 31) return;
     const unsigned lps64[] = {3, 4, 5, 3 | kWaveTiles, 4 | kWaveTiles}, lps32[] = {3, 4, 5};
     const unsigned *lps = elem_bytes == 8 ? lps64 : lps32;
     const unsigned n_lps = elem_bytes == 8 ? 5 : 3;

@@ -308,6 +308,16 @@ template <typename T> struct Planner {
     }
     // ... and a batch of them is one workgroup EACH: below half the chip's CUs the twin still wins (2^13 x 128 f64: 17.8 us
     // against 21.8, x 32: 11.3 against 17.3; profiles/r04_small_twin_batch.log).  PHAST_SMALL_TWIN_MAX_BATCH: tools.
+    // Round 5: 4096 points as well (one transform: 8.6 us in one workgroup, profiles/r04_size_ladder.log) -- behind
+    // PHAST_SMALL_TWIN_MIN_LOG (default 13: 8192 points only) until a same-box A/B says otherwise.
+    static unsigned twin_min_log() {
+        static const unsigned v = [] {
+            const char *e = std::getenv("PHAST_SMALL_TWIN_MIN_LOG");
+            const unsigned m = (e && *e) ? (unsigned)std::atoi(e) : kSmallMaxLog;
+            return m < kTwinMinLog ? kTwinMinLog : m;
+        }();
+        return v;
+    }
     static size_t twin_max_batch() {
         static const size_t v = [] {
             const char *e = std::getenv("PHAST_SMALL_TWIN_MAX_BATCH");

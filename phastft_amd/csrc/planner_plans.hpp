@@ -240,11 +240,11 @@ template <typename T> int Planner<T>::init(size_t num_points, bool force_multi, 
     log_n = ilog2(n);
     int rc = ensure_device(&device);
     if (rc) return rc;
-    if (log_n <= kSmallMaxLog && !(force_multi && log_n == kSmallMaxLog)) {
+    if (log_n <= kSmallMaxLog && !(force_multi && log_n >= kTwinMinLog)) {
         std::vector<cx_t<T>> h = host_twr<T>((unsigned)n);  // W_N^j two-level table of the one-pass kernel
         rc = upload<T>(h, &d_small_tw);
         if (rc == PHAST_OK) table_bytes += h.size() * sizeof(cx_t<T>);
-        if (rc == PHAST_OK && with_twin && log_n == kSmallMaxLog && twin_enabled()) {
+        if (rc == PHAST_OK && with_twin && log_n >= twin_min_log() && twin_enabled()) {
             twin.reset(new (std::nothrow) Planner<T>());
             if (twin && twin->init(n, true) != PHAST_OK) twin.reset();  // an optimisation: without it the one-pass kernel serves
         }

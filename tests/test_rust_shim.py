@@ -61,7 +61,7 @@ def _rust_class(ty: str) -> str:
         stars += 1
     prim = {"c_int": "i32", "c_uint": "u32", "usize": "usize", "f64": "f64", "f32": "f32"}
     if stars:
-        base = {"f64": "double", "f32": "float", "c_char": "char", "c_void": "void", "c_uint": "unsigned"}.get(ty)
+        base = {"f64": "double", "f32": "float", "c_char": "char", "c_void": "void", "c_uint": "unsigned", "usize": "size_t"}.get(ty)
         return f"ptr{stars}:{base}" if base else f"ptr{stars}:opaque"
     return prim[ty]
 
