@@ -214,7 +214,7 @@ int phast_options_guess(size_t input_size, phast_options *out) {
     int phast_planner_r2c##SFX##_describe_call(const phast_planner_r2c##SFX *p, size_t batch, int kind, char *buf, \
                                                size_t len) {                                                       \
         if (!p || !buf || !len || (kind != kR2C && kind != kC2R)) return PHAST_ERR_INVALID_ARG;                    \
-        const PlannerR2c<T> *q = (p->twin && batch <= Planner<T>::twin_max_batch()) ? p->twin.get() : p;           \
+        const PlannerR2c<T> *q = p->route_small(kind == kC2R, batch);                                              \
         std::snprintf(buf, len, "%s", q->dit.passes.empty() ? "one-pass" : q->dit.describe_call(kind, batch).c_str()); \
         return PHAST_OK;                                                                                           \
     }                                                                                                              \
@@ -279,7 +279,9 @@ int phast_options_guess(size_t input_size, phast_options *out) {
     int phast_planner_r2c##SFX##_describe(const phast_planner_r2c##SFX *p, char *buf, size_t len) {                \
         if (!p || !buf || !len) return PHAST_ERR_INVALID_ARG;                                                      \
         std::string s = p->dit.describe();                                                                         \
-        if (p->twin) s += " | one transform: " + p->twin->dit.describe();                                          \
+        if (p->twin)                                                                                               \
+            s += std::string(p->route_small(false) != p ? " | one transform: " : " | one c2r transform: ") +       \
+                 p->twin->dit.describe();                                                                          \
         std::snprintf(buf, len, "%s", s.c_str());                                                                  \
         return PHAST_OK;                                                                                           \
     }

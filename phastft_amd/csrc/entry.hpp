@@ -64,7 +64,7 @@ static int fft_dev_many(T *const *d_re, T *const *d_im, size_t count, size_t n, 
     for (size_t i = 0; i < count; ++i)
         if (!d_re[i] || !d_im[i]) return PHAST_ERR_INVALID_ARG;
     if (count == 0) return PHAST_OK;
-    if (pl->twin) pl = pl->twin.get();  // 8192 points: the plan of a single-transform call (Planner::twin)
+    pl = pl->route_small();  // 4096 / 8192 points: the plan of a single-transform call (Planner::twin)
     PHAST_ON_DEVICE(pl->device);
     typename Planner<T>::Lease L;  // one workspace for the whole list: the transforms follow each other on the stream
     if (!pl->passes.empty()) {

@@ -123,7 +123,7 @@ int Planner<T>::exec(const void *in_re, const void *in_im, size_t in_dist, unsig
     // one 8192-point transform: two passes over the whole chip instead of one workgroup -- unless the call is being captured
     // and the twin has no scratch yet: the one-pass kernel needs none, so a capture without a warm-up call keeps working as
     // it did before the twin existed
-    if (twin && batch <= twin_max_batch() && !(capturing(stream) && !twin->capture_ready()))
+    if (route_small(batch) != this && !(capturing(stream) && !twin->capture_ready(stream)))
         return twin->exec(in_re, in_im, in_dist, in_mode, out_re, out_im, out_dist, out_mode, batch, scale, stream, timer);
     PHAST_ON_DEVICE(device);
     Lease L;

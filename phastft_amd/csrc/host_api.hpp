@@ -86,7 +86,7 @@ static int fft_host(T *re, size_t re_len, T *im, size_t im_len, int direction, c
     if (!is_pow2(re_len)) return PHAST_ERR_NOT_POW2;          // dit.rs:285
     if (ilog2(re_len) != pl->log_n) return PHAST_ERR_PLANNER_SIZE;  // dit.rs:289
     const size_t n = re_len, bytes = n * sizeof(T), total = 2 * bytes;
-    if (pl->twin) pl = pl->twin.get();  // ONE transform of 8192 points: the plan (and the bits) of the _dev call
+    pl = pl->route_small();  // ONE transform of 8192 points: the plan (and the bits) of the _dev call
     PHAST_ON_DEVICE(pl->device);
     typename Planner<T>::Lease L;
     int rc = pl->check_out(L, nullptr, 1);
@@ -130,7 +130,7 @@ template <typename T> static int fft_interleaved_host(T *signal, size_t n, int d
     if (direction != PHAST_FORWARD && direction != PHAST_REVERSE) return PHAST_ERR_INVALID_ARG;
     if (!is_pow2(n)) return PHAST_ERR_NOT_POW2;
     if (ilog2(n) != pl->log_n) return PHAST_ERR_PLANNER_SIZE;
-    if (pl->twin) pl = pl->twin.get();
+    pl = pl->route_small();
     PHAST_ON_DEVICE(pl->device);
     typename Planner<T>::Lease L;
     int rc = pl->check_out(L, nullptr, 1);
@@ -249,7 +249,7 @@ static int r2c_host(const T *in, size_t in_len, T *ore, size_t ore_len, T *oim, 
     if (in_len != n) return PHAST_ERR_R2C_INPUT_LEN;
     if (ore_len != half + 1) return PHAST_ERR_R2C_OUT_RE_LEN;
     if (oim_len != half + 1) return PHAST_ERR_R2C_OUT_IM_LEN;
-    if (pl->twin) pl = pl->twin.get();
+    pl = pl->route_small(false);
     PHAST_ON_DEVICE(pl->dit.device);
     typename Planner<T>::Lease L;
     int rc = pl->dit.check_out(L, nullptr, 1);
@@ -291,7 +291,7 @@ static int c2r_host(const T *ire, size_t ire_len, const T *iim, size_t iim_len, 
     if (iim_len != half + 1) return PHAST_ERR_C2R_IN_IM_LEN;
     if (check_scratch && sre_len != half) return PHAST_ERR_C2R_SCRATCH_RE;
     if (check_scratch && sim_len != half) return PHAST_ERR_C2R_SCRATCH_IM;
-    if (pl->twin) pl = pl->twin.get();
+    pl = pl->route_small(true);
     PHAST_ON_DEVICE(pl->dit.device);
     typename Planner<T>::Lease L;
     int rc = pl->dit.check_out(L, nullptr, 1);

@@ -212,7 +212,7 @@ template <typename T> struct Planner {
     void check_in(Workspace *ws, hipStream_t stream, bool host_synchronised) const;
     int ensure_scratch(const Lease &L, size_t batch, size_t *cap_out, bool exact = false) const;
     int check_guards(size_t *bad_out) const;
-    bool capture_ready() const;
+    bool capture_ready(hipStream_t stream) const;
     int reserve_batch(size_t max_batch);
     size_t release_graph_workspaces();
 
@@ -308,15 +308,22 @@ template <typename T> struct Planner {
     }
     // ... and a batch of them is one workgroup EACH: below half the chip's CUs the twin still wins (2^13 x 128 f64: 17.8 us
     // against 21.8, x 32: 11.3 against 17.3; profiles/r04_small_twin_batch.log).  PHAST_SMALL_TWIN_MAX_BATCH: tools.
-    // Round 5: 4096 points as well (one transform: 8.6 us in one workgroup, profiles/r04_size_ladder.log) -- behind
-    // PHAST_SMALL_TWIN_MIN_LOG (default 13: 8192 points only) until a same-box A/B says otherwise.
-    static unsigned twin_min_log() {
+    // Round 5: 4096 points as well.  Measured per call kind (profiles/r05_small_twin_4096.log, one transform, graph over a cold
+    // ring): C2R of 8192 real points 12.5 -> 8.7 us in f64, 11.1 -> 6.7 in f32 (two passes with the preprocess fused into the
+    // first against one workgroup's chain) -- adopted; R2C 9.8 -> 10.4 / 8.1 -> 8.8 (the untangle becomes a third kernel) -- not;
+    // C2C: PHAST_SMALL_TWIN_MIN_LOG (the C2C threshold; see twin_min_log_c2c's default for what the A/B said).
+    static unsigned twin_min_log_c2c() {
         static const unsigned v = [] {
             const char *e = std::getenv("PHAST_SMALL_TWIN_MIN_LOG");
             const unsigned m = (e && *e) ? (unsigned)std::atoi(e) : kSmallMaxLog;
             return m < kTwinMinLog ? kTwinMinLog : m;
         }();
         return v;
+    }
+    static constexpr unsigned kTwinMinLogR2c = kSmallMaxLog, kTwinMinLogC2r = kTwinMinLog;  // log2 of the INNER length
+    // the planner a call of ONE (or a few) C2C transforms runs on: the multi-pass twin where this length has one in use
+    const Planner<T> *route_small(size_t batch = 1) const {
+        return (twin && log_n >= twin_min_log_c2c() && batch <= twin_max_batch()) ? twin.get() : this;
     }
     static size_t twin_max_batch() {
         static const size_t v = [] {

@@ -244,7 +244,7 @@ template <typename T> int Planner<T>::init(size_t num_points, bool force_multi, 
         std::vector<cx_t<T>> h = host_twr<T>((unsigned)n);  // W_N^j two-level table of the one-pass kernel
         rc = upload<T>(h, &d_small_tw);
         if (rc == PHAST_OK) table_bytes += h.size() * sizeof(cx_t<T>);
-        if (rc == PHAST_OK && with_twin && log_n >= twin_min_log() && twin_enabled()) {
+        if (rc == PHAST_OK && with_twin && log_n >= kTwinMinLog && twin_enabled()) {
             twin.reset(new (std::nothrow) Planner<T>());
             if (twin && twin->init(n, true) != PHAST_OK) twin.reset();  // an optimisation: without it the one-pass kernel serves
         }
@@ -386,7 +386,7 @@ template <typename T> int Planner<T>::prepare_passes(std::vector<PassDesc> &ps) 
 // "<which plan> [rows x cols ...][...]" of the call (kind, batch): what bench.py and the tools label their numbers with -- the
 // library's own answer (choose), not a copy of its rules
 template <typename T> std::string Planner<T>::describe_call(int kind, size_t batch) const {
-    if (passes.empty()) return (twin && batch <= twin_max_batch()) ? twin->describe_call(kind, batch) : std::string("one-pass");
+    if (passes.empty()) return route_small(batch) != this ? twin->describe_call(kind, batch) : std::string("one-pass");
     std::shared_lock<std::shared_mutex> plans(plan_mu);
     const Choice c = choose(kind, batch ? batch : 1, batch ? batch : 1);
     const std::vector<PassDesc> *v = c.passes;
@@ -426,7 +426,7 @@ template <typename T> std::string Planner<T>::describe() const {
     };
     if (passes.empty()) {
         s += " one pass (whole transforms on chip)";
-        if (twin) add("single", twin->plan_for(1));
+        if (route_small() != this) add("single", twin->plan_for(1));
         return s;
     }
     add("throughput", passes);

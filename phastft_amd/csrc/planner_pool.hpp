@@ -248,15 +248,19 @@ template <typename T> int Planner<T>::check_guards(size_t *bad_out) const {
     return PHAST_OK;
 }
 
-// Can a call on this planner be CAPTURED right now without allocating -- is there a scratch, cut for the present plans, that a
-// capture may take?  (Planner::exec: the 8192-point twin under capture.)
-template <typename T> bool Planner<T>::capture_ready() const {
+// Can a call on `stream` be CAPTURED on this planner right now without allocating -- is there a scratch, cut for the present
+// plans, that check_out would hand a capture on that stream (the same rule: nothing in flight, or this stream's own -- incl. the
+// one an earlier call of the same capture already took --, or this thread's warm-up)?  (Planner::exec: the twin under capture.)
+template <typename T> bool Planner<T>::capture_ready(hipStream_t stream) const {
     std::shared_lock<std::shared_mutex> plans(plan_mu);
     const size_t per_now = 2 * sstride() * sizeof(T);
     const std::thread::id me = std::this_thread::get_id();
     std::lock_guard<std::mutex> lk(mu);
-    for (auto &w : pool)
-        if (!w->busy && !w->captured && w->cap > 0 && w->per == per_now && (!w->pending || w->last_thread == me)) return true;
+    for (auto &w : pool) {
+        if (w->busy || w->cap == 0 || w->per != per_now) continue;
+        const bool own_ws = w->pending && w->stream == stream;
+        if ((!w->pending || own_ws || w->last_thread == me) && (!w->captured || own_ws)) return true;
+    }
     return false;
 }
 

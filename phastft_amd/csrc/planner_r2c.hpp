@@ -34,7 +34,7 @@ template <typename T> struct PlannerR2c {
         }
         tw_bits = tw3_bits_for(ilog2(n));
         rc = upload<T>(host_tw3<T>(ilog2(n), tw_bits), &d_tw3);
-        if (rc == PHAST_OK && !force_multi && dit.passes.empty() && dit.log_n >= Planner<T>::twin_min_log() && Planner<T>::twin_enabled()) {
+        if (rc == PHAST_OK && !force_multi && dit.passes.empty() && dit.log_n >= kTwinMinLog && Planner<T>::twin_enabled()) {
             twin.reset(new (std::nothrow) PlannerR2c<T>());
             if (twin && twin->init(n, true) != PHAST_OK) twin.reset();
         }
@@ -74,6 +74,11 @@ template <typename T> struct PlannerR2c {
         return PHAST_OK;
     }
 
+    // the planner a call of ONE (or a few) real transforms runs on (see Planner::kTwinMinLogR2c / kTwinMinLogC2r)
+    const PlannerR2c<T> *route_small(bool c2r, size_t batch = 1) const {
+        const unsigned min_log = c2r ? Planner<T>::kTwinMinLogC2r : Planner<T>::kTwinMinLogR2c;
+        return (twin && dit.log_n >= min_log && batch <= Planner<T>::twin_max_batch()) ? twin.get() : this;
+    }
     // PlannerMode::Tune for the real transforms (tune.hpp)
     int tune(int kind, size_t batch, typename Planner<T>::TuneReport *rep);
     // C2R: does the first pass of `ch` form z on load (c2r_fused.hpp), or does the preprocess run as a sweep of its own?
@@ -85,7 +90,7 @@ template <typename T> struct PlannerR2c {
             PassTimer *timer = nullptr) const {
         if (in_dist & 1) return PHAST_ERR_INVALID_ARG;  // the input is read as (even, odd) pairs
         // (... and large batches too where the twin has a plan ranked for them: f32, plan.hpp: real_batch_plan)
-        if (twin && (batch <= Planner<T>::twin_max_batch() || (batch * (n / 2) >= ((size_t)1 << 24) && !twin->dit.passes_r2c_tp.empty())))
+        if (route_small(false, batch) != this || (twin && batch * (n / 2) >= ((size_t)1 << 24) && !twin->dit.passes_r2c_tp.empty()))
             return twin->r2c(d_in, d_ore, d_oim, batch, in_dist, out_dist, s, timer);
         PHAST_ON_DEVICE(dit.device);
         Lease L;
@@ -130,7 +135,7 @@ template <typename T> struct PlannerR2c {
     int c2r(const T *d_ire, const T *d_iim, T *d_out, size_t batch, size_t in_dist, size_t out_dist,
             hipStream_t s, PassTimer *timer = nullptr) const {
         if (out_dist & 1) return PHAST_ERR_INVALID_ARG;
-        if (twin && (batch <= Planner<T>::twin_max_batch() || (batch * (n / 2) >= ((size_t)1 << 24) && !twin->dit.passes_c2r_tp.empty())))
+        if (route_small(true, batch) != this || (twin && batch * (n / 2) >= ((size_t)1 << 24) && !twin->dit.passes_c2r_tp.empty()))
             return twin->c2r(d_ire, d_iim, d_out, batch, in_dist, out_dist, s, timer);
         PHAST_ON_DEVICE(dit.device);
         Lease L;

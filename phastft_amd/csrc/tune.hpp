@@ -263,7 +263,7 @@ template <typename T> int Planner<T>::tune(int kind, size_t batch, TuneReport *r
     if ((kind != kC2C && kind != kC2CI) || batch == 0) return PHAST_ERR_INVALID_ARG;
     if (rep) *rep = TuneReport();
     if (passes.empty()) {  // whole transforms on chip: one kernel, nothing to choose -- except in the 8192-point twin
-        if (twin && batch <= twin_max_batch()) return twin->tune(kind, batch, rep);
+        if (route_small(batch) != this) return twin->tune(kind, batch, rep);
         if (rep) rep->plan = "one pass";
         return PHAST_OK;
     }
@@ -291,7 +291,7 @@ template <typename T> int PlannerR2c<T>::tune(int kind, size_t batch, typename P
     if ((kind != kR2C && kind != kC2R) || batch == 0) return PHAST_ERR_INVALID_ARG;
     if (rep) *rep = typename Planner<T>::TuneReport();
     if (dit.passes.empty()) {
-        if (twin && batch <= Planner<T>::twin_max_batch()) return twin->tune(kind, batch, rep);
+        if (route_small(kind == kC2R, batch) != this) return twin->tune(kind, batch, rep);
         if (rep) rep->plan = "one pass";
         return PHAST_OK;
     }

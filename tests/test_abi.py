@@ -118,9 +118,11 @@ def test_wisdom_store_without_a_device():
     a text without the header is refused, and what comes out parses back to the same set."""
     import phastft_amd as P
 
+    assert "f64 c2c" in P.wisdom_export()  # the built-in layer (csrc/builtin_wisdom.inc) is there without a device, too
+    P.wisdom_builtin(False)                # ... and out of the way for the rest of this test
     P.wisdom_forget()
     base = P.wisdom_export()
-    assert base.startswith("phastft-hip-wisdom 1 cus=")
+    assert base == "phastft-hip-wisdom 1 cus=0\n"
     text = ("phastft-hip-wisdom 1 cus=256\n"
             "f64 c2c 20 0 6,8,6@10,12,10:p8w fuse=0 us=23.10 heur=24.02\n"
             "f32 r2c 24 0 8,9,6@12,13,11:p16 fuse=1 us=88.00 heur=95.00\n"
@@ -145,3 +147,5 @@ def test_wisdom_store_without_a_device():
         P.wisdom_import("f64 c2c 20 0 heuristic\n")  # no header
     P.wisdom_forget()
     assert P.wisdom_export() == base
+    P.wisdom_builtin(True)
+    assert "f64 c2c" in P.wisdom_export()
