@@ -311,11 +311,12 @@ template <typename T> struct Planner {
     // Round 5: 4096 points as well.  Measured per call kind (profiles/r05_small_twin_4096.log, one transform, graph over a cold
     // ring): C2R of 8192 real points 12.5 -> 8.7 us in f64, 11.1 -> 6.7 in f32 (two passes with the preprocess fused into the
     // first against one workgroup's chain) -- adopted; R2C 9.8 -> 10.4 / 8.1 -> 8.8 (the untangle becomes a third kernel) -- not;
-    // C2C: PHAST_SMALL_TWIN_MIN_LOG (the C2C threshold; see twin_min_log_c2c's default for what the A/B said).
+    // C2C: 8.48 -> 7.67 us (f64), 6.72 -> 6.50 (f32) once the capture fix let the twin run (call 4's A/B) -- adopted; 2^11 stays
+    // in one workgroup (7.5 us).  PHAST_SMALL_TWIN_MIN_LOG=13 restores round 4's threshold for C2C (tools: A/B).
     static unsigned twin_min_log_c2c() {
         static const unsigned v = [] {
             const char *e = std::getenv("PHAST_SMALL_TWIN_MIN_LOG");
-            const unsigned m = (e && *e) ? (unsigned)std::atoi(e) : kSmallMaxLog;
+            const unsigned m = (e && *e) ? (unsigned)std::atoi(e) : kTwinMinLog;
             return m < kTwinMinLog ? kTwinMinLog : m;
         }();
         return v;

