@@ -287,6 +287,14 @@ hipError_t launch_row_inst(const RowArgs &a, hipStream_t stream, hipEvent_t ev_s
     X(1, 8, 1) X(2, 8, 2) X(3, 8, 3) X(4, 8, 4) X(5, 7, 5) X(6, 6, 3) X(7, 5, 3) X(8, 4, 4) X(9, 3, 4) X(10, 2, 4) \
     X(11, 1, 4) X(12, 0, 4) X(13, 0, PHAST_ROW13_LP)
 
+// Real transforms of 64 points (the 32-point core with the untangle as epilogue / the preprocess as prologue) run 16 points per
+// thread on 256 threads -- radix 16 x 2, one more LDS exchange -- instead of one radix-32 butterfly per thread on 128: the
+// epilogue / prologue is per-point work, and 128 threads per 4096-point tile left one wave per SIMD to hide it.  Same-box A/B
+// (profiles/r05_real64_lp4_ab.log, 2^27 / 2^22 real points in flight): c2r_fft_f64 132 -> 199 / 117 -> 167 GSamples/s,
+// c2r_fft_f32 264 -> 392 / 136 -> 201, r2c_fft_f32 397 -> 389 (noise) / 213 -> 263, r2c_fft_f64 225 -> 234 / 163 -> 175.
+// Plain C2C of 32 points keeps the single butterfly (no epilogue to hide).
+constexpr int kRealRow5LP = 4;
+
 inline unsigned row_tile_cols_log(unsigned log_n) {
 #define PHAST_ROW_LC(LR_, LC_, LP_) \
     if (log_n == LR_) return LC_;

@@ -64,12 +64,8 @@ hipError_t launch_small_fft(const SmallArgs &a, hipStream_t stream, hipEvent_t e
     r.rtw3 = a.rtw3;
     const unsigned lc = row_tile_cols_log(a.log_n);
     r.tiles_total = (unsigned)((a.batch + ((1ull << lc) - 1)) >> lc);
-#ifdef PHAST_ROW5_REAL_LP4
-    // experiment (round 5): real transforms of 64 points -- the 32-point core with 16 points per thread on 256 threads
-    // (radix 16 x 2, one more LDS exchange) instead of one radix-32 butterfly per thread on 128: the untangle / preprocess
-    // epilogue gets twice the threads
-    if (a.log_n == 5 && a.real_mode) return launch_row_inst<T, 5, 7, 4, true>(r, stream, ev_start, ev_stop);
-#endif
+    if (a.log_n == 5 && a.real_mode)  // 64-point real transforms: 16 points per thread (row_fft.hpp: kRealRow5LP)
+        return launch_row_inst<T, 5, 7, kRealRow5LP, true>(r, stream, ev_start, ev_stop);
 #define PHAST_ROW_CASE(LR_, LC_, LP_)                                                                       \
     if (a.log_n == LR_)                                                                                     \
         return a.real_mode ? launch_row_inst<T, LR_, LC_, LP_, true>(r, stream, ev_start, ev_stop)          \

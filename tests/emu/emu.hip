@@ -430,6 +430,11 @@ static int emu_small(int is_f64, const void *in_re, const void *in_im, unsigned 
     const std::vector<phast::cx_t<double>> t64 = phast::host_twr<double>(1u << log_n);
     const std::vector<phast::cx_t<float>> t32 = phast::host_twr<float>(1u << log_n);
     r.twr = is_f64 ? (const void *)t64.data() : (const void *)t32.data();
+    if (log_n == 5 && real_mode) {  // as launch_small_fft: the 64-point real transforms' core runs 16 points per thread
+        if (is_f64) phast::emulate_row_fft<double, 5, 7, phast::kRealRow5LP>(r);
+        else phast::emulate_row_fft<float, 5, 7, phast::kRealRow5LP>(r);
+        return 0;
+    }
 #define PHAST_ROW_EMU(LR_, LC_, LP_)                                      \
     if (log_n == LR_) {                                                   \
         if (is_f64) phast::emulate_row_fft<double, LR_, LC_, LP_>(r);     \

@@ -149,3 +149,19 @@ def test_wisdom_store_without_a_device():
     assert P.wisdom_export() == base
     P.wisdom_builtin(True)
     assert "f64 c2c" in P.wisdom_export()
+
+
+def test_wisdom_file_is_loaded_at_first_use(tmp_path):
+    """PHAST_WISDOM=<path>: read when the store is first used (no device needed); PHAST_BUILTIN_WISDOM=0 leaves the built-in
+    layer out.  (The rewrite after a tuning run needs a GPU: tests/test_gpu_parity_r5.py.)"""
+    import subprocess
+    import sys
+
+    path = tmp_path / "wisdom.txt"
+    path.write_text("phastft-hip-wisdom 1 cus=256\nf32 c2r 24 1 7,9,7@12,13,13:p16 fuse=0 us=185.13 heur=202.99\n")
+    code = "import sys; sys.path.insert(0, %r)\nimport phastft_amd as P\nprint(P.wisdom_export())" % ROOT
+    env = dict(os.environ, PHAST_WISDOM=str(path), PHAST_BUILTIN_WISDOM="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln and not ln.startswith("phastft-hip-wisdom")]
+    assert lines == ["f32 c2r 24 1 7,9,7@12,13,13:p16 fuse=0 us=185.13 heur=202.99"], r.stdout

@@ -663,3 +663,26 @@ def test_4096_points_run_the_twin_where_it_was_measured_faster(gpu, oracle, dt, 
     t_out = torch.zeros(m, dtype=tdt, device="cuda")
     c2r(dev(ore), dev(oim), t_out, rp)                                            # device pointers: the same bits
     assert np.array_equal(t_out.cpu().numpy(), back)
+
+
+def test_wisdom_file_carries_a_tuning_run_to_the_next_process(gpu, tmp_path):
+    """PHAST_WISDOM=<path>: process 1 tunes f64 2^18 x 16 (the static rule loses by ~30 % there) -- the library rewrites the file;
+    process 2, same variable, makes a planner of that length and starts with the measured plan without measuring anything."""
+    path = tmp_path / "wisdom.txt"
+    env = dict(os.environ, PHAST_WISDOM=str(path), PHAST_BUILTIN_WISDOM="0")
+    code1 = ("import sys; sys.path.insert(0, %r)\nimport phastft_amd as P\npl = P.PlannerDit64(1 << 18)\n"
+             "rep = pl.tune(16)\nprint('ADOPTED', int(rep['adopted']), rep['plan'])\nprint('CALL', pl.describe_call(16))" % ROOT)
+    r1 = subprocess.run([sys.executable, "-c", code1], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    adopted = "ADOPTED 1" in r1.stdout
+    text = path.read_text()
+    assert text.startswith("phastft-hip-wisdom 1 cus=") and "f64 c2c 18 4 " in text, text
+    assert ("f64 c2c 18 4 heuristic" in text) == (not adopted)
+    code2 = ("import sys; sys.path.insert(0, %r)\nimport phastft_amd as P\npl = P.PlannerDit64(1 << 18)\n"
+             "print('CALL', pl.describe_call(16))\nprint('OTHER', pl.describe_call(1))" % ROOT)
+    r2 = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    call1 = [ln for ln in r1.stdout.splitlines() if ln.startswith("CALL")][0]
+    call2 = [ln for ln in r2.stdout.splitlines() if ln.startswith("CALL")][0]
+    assert call1 == call2 and call2.startswith("CALL tuned ") == adopted, (call1, call2)
+    assert "tuned" not in [ln for ln in r2.stdout.splitlines() if ln.startswith("OTHER")][0]   # another bucket: the static rules
