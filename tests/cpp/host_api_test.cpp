@@ -211,6 +211,44 @@ int main(int argc, char **argv) {
         for (size_t i = 0; i < n; ++i) worst = std::max(worst, std::fabs(fback[i] - xf[i]));
         EXPECT(worst < 1e-4f);
     }
+    // ---- PlannerMode::Tune beyond one transform per call, the real planners, wisdom (round 5; planner.rs:18-32) ----
+    {
+        const size_t n = size_t(1) << 15;
+        std::vector<double> x(n), ore(n / 2 + 1), oim(n / 2 + 1), back(n);
+        for (size_t i = 0; i < n; ++i) x[i] = std::sin(0.001 * double(i)) + 0.25 * double(i % 11);
+        PlannerR2c64 tuned(n, PlannerMode::Tune);            // r2c and c2r of one transform measured at plan time
+        PlannerR2c64 plain(n);
+        r2c_fft_f64_with_planner(x, ore, oim, tuned);
+        std::vector<double> pre(n / 2 + 1), pim(n / 2 + 1);
+        r2c_fft_f64_with_planner(x, pre, pim, plain);
+        double worst = 0, peak = 0;
+        for (size_t k = 0; k <= n / 2; ++k) {
+            worst = std::max(worst, std::max(std::fabs(ore[k] - pre[k]), std::fabs(oim[k] - pim[k])));
+            peak = std::max(peak, std::fabs(pre[k]));
+        }
+        EXPECT(worst <= 1e-12 * peak);                       // another plan: other last bits, the same transform
+        c2r_fft_f64_with_planner(ore, oim, back, tuned);
+        for (size_t i = 0; i < n; ++i) EXPECT(std::fabs(back[i] - x[i]) < 1e-9);
+        const phast_tune_report rep = tuned.tune(8, PHAST_TUNE_C2R);   // a batch bucket, the other call kind
+        EXPECT(rep.candidates >= 8 && rep.us_best <= rep.us_heuristic * 1.0001f && rep.seconds < 5.0);
+        PlannerDit32 c32(size_t(1) << 16);
+        const phast_tune_report r32 = c32.tune(4, PHAST_TUNE_C2C_INTERLEAVED);
+        EXPECT(r32.candidates >= 8 && r32.plan[0] != '\0');
+        EXPECT(panic_message([&] { (void)c32.tune(4, PHAST_TUNE_R2C); }) == "invalid argument");
+        // what was measured travels as text
+        size_t need = 0;
+        EXPECT(phast_wisdom_export(nullptr, 0, &need) == PHAST_OK && need > 32);
+        std::string text(need, '\0');
+        EXPECT(phast_wisdom_export(&text[0], need, nullptr) == PHAST_OK);
+        EXPECT(text.find("f64 c2r 15 3 ") != std::string::npos && text.find("f32 c2ci 16 2 ") != std::string::npos);
+        phast_wisdom_forget();
+        EXPECT(phast_wisdom_import(text.c_str()) == PHAST_OK);
+        EXPECT(phast_wisdom_import("not wisdom") == PHAST_ERR_INVALID_ARG);
+        PlannerR2c64 again(n);                               // starts with the imported plans
+        c2r_fft_f64_with_planner(ore, oim, back, again);
+        for (size_t i = 0; i < n; ++i) EXPECT(std::fabs(back[i] - x[i]) < 1e-9);
+        phast_wisdom_forget();
+    }
     // ---- bit reversal exact (bravo.rs:373-407) ----
     for (unsigned nb = 2; nb <= 18; ++nb) {
         const size_t n = size_t(1) << nb;
