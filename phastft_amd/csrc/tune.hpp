@@ -297,11 +297,15 @@ template <typename T> int PlannerR2c<T>::tune(int kind, size_t batch, typename P
     }
     PHAST_ON_DEVICE(dit.device);
     const size_t half = n / 2, hp = half + 1;
+    // the three arrays of a set start on 256-byte boundaries, as a caller's separately allocated slices do (the half-spectrum
+    // has an odd length: packed back to back its imaginary plane would start 4 or 8 bytes off a 16-byte boundary)
+    auto pad = [](size_t elems) { return (elems + 63) & ~(size_t)63; };
+    const size_t x_elems = pad(batch * n), s_elems = pad(batch * hp);
     TuneRing ring;
-    int rc = ring.alloc((batch * n + 2 * batch * hp) * sizeof(T));
+    int rc = ring.alloc((x_elems + 2 * s_elems) * sizeof(T));
     if (rc) return rc;
     auto run = [&](const Lease &L, const typename Planner<T>::Choice &c, int set) {
-        T *x = reinterpret_cast<T *>(ring.set(set)), *sr = x + batch * n, *si = sr + batch * hp;
+        T *x = reinterpret_cast<T *>(ring.set(set)), *sr = x + x_elems, *si = sr + s_elems;
         return kind == kR2C ? r2c_in(L, x, sr, si, batch, n, hp, nullptr, &c) : c2r_in(L, sr, si, x, batch, hp, n, nullptr, &c);
     };
     auto refill = [&](hipStream_t st) {
