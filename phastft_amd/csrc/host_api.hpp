@@ -5,16 +5,6 @@
 
 namespace phast {
 
-struct DevBuf {
-    void *p = nullptr;
-    ~DevBuf() {
-        if (p) hipFree(p);
-    }
-    int alloc(size_t bytes) {
-        PHAST_HIP(hipMalloc(&p, bytes ? bytes : 1));
-        return PHAST_OK;
-    }
-};
 
 // Host slices <-> the leased workspace's device staging buffer, on the workspace's own stream.  `parts` are (host pointer,
 // byte offset in the staging buffer, bytes); small totals travel through the pinned mirror (Planner::pinned_max_bytes).

@@ -126,4 +126,16 @@ template <typename T> static int upload(const std::vector<cx_t<T>> &h, void **d_
     return PHAST_OK;
 }
 
+// a device allocation that goes with its scope
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() {
+        if (p) hipFree(p);
+    }
+    int alloc(size_t bytes) {
+        PHAST_HIP(hipMalloc(&p, bytes ? bytes : 1));
+        return PHAST_OK;
+    }
+};
+
 }  // namespace phast

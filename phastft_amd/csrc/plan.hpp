@@ -646,6 +646,24 @@ inline void enumerate_plans(unsigned L, size_t elem_bytes, size_t batch, unsigne
     for (auto &e : scored) out.push_back(e.second);
 }
 
+// Do two runs' per-transform digests {sum re, sum im, energy, one probed value} (fill.hip: digest_kernel) describe the same
+// results?  What a tuning run asks before it adopts a plan (tune.hpp): far coarser than the parity gates -- two correct plans
+// differ by rounding, 1e-15 / 1e-6 relative -- and enough to stop a plan whose geometry is wrong.
+inline bool digests_agree(const double *a, const double *c, size_t batch, size_t n, size_t elem_bytes) {
+    const double tol = elem_bytes == 8 ? 1e-9 : 1e-4;
+    for (size_t b = 0; b < batch; ++b, a += 4, c += 4) {
+        const double e = a[2], rms = std::sqrt(e > 0 ? e : 0), sum_tol = tol * rms * std::sqrt((double)n) + 1e-300;
+        for (int i = 0; i < 4; ++i)
+            if (!std::isfinite(a[i]) || !std::isfinite(c[i])) return false;
+        // (the probed value against the rms BIN: a permutation of the outputs keeps the energy and both sums)
+        const double bin_tol = (elem_bytes == 8 ? 1e-9 : 1e-3) * rms / std::sqrt((double)n) + 1e-300;
+        if (std::fabs(c[2] - e) > tol * e || std::fabs(c[0] - a[0]) > sum_tol || std::fabs(c[1] - a[1]) > sum_tol ||
+            std::fabs(c[3] - a[3]) > bin_tol)
+            return false;
+    }
+    return true;
+}
+
 // the tile sizes worth trying for `points` in flight (batch * n): a latency-bound call wants many small tiles, a full chip
 // the widest rows (section 5; the ranges the round-4 sweeps were run with)
 inline void tune_tile_range(size_t points, size_t elem_bytes, unsigned &tl_lo, unsigned &tl_hi) {

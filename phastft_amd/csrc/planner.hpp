@@ -345,6 +345,7 @@ template <typename T> struct Planner {
     int install_tuned(int kind, unsigned bucket, const PlanSpec &spec, bool fuse, float us, float us_heur);
     struct TuneReport {
         int adopted = 0;  // a measured plan replaced the static rule's
+        int rejected = 0; // the fastest plan computed something else than the static rule's (never adopted; a bug to report)
         unsigned candidates = 0;
         float us_heuristic = 0, us_best = 0;
         double seconds = 0;
@@ -352,8 +353,9 @@ template <typename T> struct Planner {
     };
     int install_built(int kind, unsigned bucket, const PlanSpec &spec, bool fuse, std::vector<PassDesc> &&ps, float us, float us_heur);
     void remove_tuned(int kind, unsigned bucket);
-    template <typename Run, typename Refill>
-    int tune_core(int kind, size_t batch, unsigned wisdom_log_n, int ring, bool grows, Run &&run, Refill &&refill, TuneReport *rep);
+    template <typename Run, typename Refill, typename Digest>
+    int tune_core(int kind, size_t batch, unsigned wisdom_log_n, int ring, bool grows, Run &&run, Refill &&refill, Digest &&digest,
+                  TuneReport *rep);
     int tune(int kind, size_t batch, TuneReport *rep);
     std::string describe() const;
     std::string describe_call(int kind, size_t batch) const;

@@ -9,6 +9,8 @@
 //   * screening: every candidate once, over a slice of the ring that moves on with every candidate, after one untimed call;
 //   * finals: the best few and the static rule's plan INTERLEAVED (A B C A B C ...) over the whole ring, median of the rounds --
 //     boxes drift by a few per cent within seconds, so only alternating measurements compare;
+//   * the winner's RESULT is compared with the static rule's plan's before anything is adopted (digests of one set of inputs,
+//     plan.hpp: digests_agree): the candidates are compositions no parity test enumerates;
 //   * a measured plan is adopted only if it beats the static rule's by more than 3 % (PHAST_TUNE_MIN_GAIN): below that the
 //     ranking is noise (where a buffer landed is worth +-5 % at 2^25 points and beyond, profiles/r04_placement_probe.log).
 // Eager launches on a private stream, never graphs: a workspace that was captured belongs to its graph for good.
@@ -17,6 +19,7 @@
 #pragma once
 
 #include <chrono>
+#include <cmath>
 
 #include "planner_r2c.hpp"
 
@@ -60,10 +63,12 @@ struct TuneRing {
 };
 
 // run(L, choice, set) enqueues one call of the kind being tuned on L.stream; refill(stream) rewrites the ring with inputs (in
-// place transforms grow their data by ~sqrt(N) per call: `grows`).
+// place transforms grow their data by ~sqrt(N) per call: `grows`); digest(set, probe, d_out, stream) enqueues the per-transform digests
+// {sum re, sum im, energy, one probed value} of the call's OUTPUT in `set` (4 doubles per transform).
 template <typename T>
-template <typename Run, typename Refill>
-int Planner<T>::tune_core(int kind, size_t batch, unsigned wisdom_log_n, int ring, bool grows, Run &&run, Refill &&refill, TuneReport *rep) {
+template <typename Run, typename Refill, typename Digest>
+int Planner<T>::tune_core(int kind, size_t batch, unsigned wisdom_log_n, int ring, bool grows, Run &&run, Refill &&refill, Digest &&digest,
+                          TuneReport *rep) {
     using clock = std::chrono::steady_clock;
     const auto t_start = clock::now();
     auto elapsed_s = [&] { return std::chrono::duration<double>(clock::now() - t_start).count(); };
@@ -227,6 +232,33 @@ int Planner<T>::tune_core(int kind, size_t batch, unsigned wisdom_log_n, int rin
             }
         }
         if (rep) rep->candidates = (unsigned)screened;
+        // ---- 4b. the winner must compute what the static rule's plan computes.  Every candidate is built from kernels that are
+        // parity-tested on their own, but the tuner composes them in combinations no test enumerates: before a plan is adopted
+        // its output for one set of inputs is compared with the static rule's, transform by transform, through the digests
+        // (energy, sums, a probed bin) -- far coarser than the parity gates, and enough to stop a plan whose geometry is wrong.
+        if (best >= 0 && med_best < (float)(1.0 - TuneKnobs::min_gain()) * med_heur) {
+            DevBuf d_dig;  // [static rule | winner] x [two probed bins] x batch x 4
+            rc = d_dig.alloc(4 * batch * 4 * sizeof(double));
+            if (rc) return rc;
+            double *d_all = reinterpret_cast<double *>(d_dig.p);
+            const Choice w_choice = choice_of(cands[(size_t)best]);
+            const size_t probes[2] = {1, n / 2 + 1};
+            for (int pass = 0; pass < 2; ++pass) {
+                rc = refill(st);
+                if (rc == PHAST_OK) rc = run(L, pass == 0 ? h_choice : w_choice, 0);
+                for (int k = 0; k < 2 && rc == PHAST_OK; ++k) rc = digest(0, probes[k], d_all + (size_t)(2 * pass + k) * batch * 4, st);
+                if (rc) return rc;
+            }
+            std::vector<double> h(4 * batch * 4);
+            PHAST_HIP(hipMemcpyAsync(h.data(), d_all, h.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+            PHAST_HIP(hipStreamSynchronize(st));
+            const bool same = digests_agree(&h[0], &h[8 * batch], batch, n, sizeof(T)) &&
+                              digests_agree(&h[4 * batch], &h[12 * batch], batch, n, sizeof(T));
+            if (!same) {
+                best = -1;  // not adopted, and said so: this is a bug in plan.hpp's geometry, not a slow plan
+                if (rep) rep->rejected = 1;
+            }
+        }
         PHAST_HIP(hipStreamSynchronize(st));
     }  // the lease goes: the plans may change now
 
@@ -252,7 +284,7 @@ int Planner<T>::tune_core(int kind, size_t batch, unsigned wisdom_log_n, int rin
         rep->adopted = adopted ? 1 : 0;
         rep->us_heuristic = med_heur;
         rep->us_best = adopted ? med_best : med_heur;
-        rep->plan = adopted ? spec_to_string(we.spec) + (we.fuse ? " fused" : "") : std::string("heuristic");
+        rep->plan = adopted ? spec_to_string(we.spec) + (we.fuse ? " fused" : "") : std::string(rep->rejected ? "heuristic (the fastest plan FAILED the result check)" : "heuristic");
         rep->seconds = elapsed_s();
     }
     return PHAST_OK;
@@ -282,7 +314,13 @@ template <typename T> int Planner<T>::tune(int kind, size_t batch, TuneReport *r
         PHAST_HIP(launch_fill<T>(reinterpret_cast<T *>(ring.base), nullptr, total, 1, total, 0xCAFEull, 0, st));
         return (int)PHAST_OK;
     };
-    return tune_core(kind, batch, log_n, ring.ring, true, run, refill, rep);
+    auto digest = [&](int set, size_t probe, double *d_out, hipStream_t st) {
+        T *re = reinterpret_cast<T *>(ring.set(set)), *im = re + plane;
+        if (kind == kC2C) PHAST_HIP(launch_digest<T>(re, im, n, batch, n, probe, d_out, st));
+        else PHAST_HIP(launch_digest<T>(re, re + 1, 2 * n - 1, batch, 2 * n, 2 * probe, d_out, st));  // pairs: the pair array as two shifted planes
+        return (int)PHAST_OK;
+    };
+    return tune_core(kind, batch, log_n, ring.ring, true, run, refill, digest, rep);
 }
 
 // PlannerR2c*: r2c_fft (kR2C) or c2r_fft (kC2R), `batch` real transforms of n points per call.  The plans are the inner
@@ -313,7 +351,13 @@ template <typename T> int PlannerR2c<T>::tune(int kind, size_t batch, typename P
         PHAST_HIP(launch_fill<T>(reinterpret_cast<T *>(ring.base), nullptr, total, 1, total, 0xCAFEull, 0, st));
         return (int)PHAST_OK;
     };
-    return dit.tune_core(kind, batch, ilog2(n), ring.ring, false, run, refill, rep);
+    auto digest = [&](int set, size_t probe, double *d_out, hipStream_t st) {
+        T *x = reinterpret_cast<T *>(ring.set(set)), *sr = x + x_elems, *si = sr + s_elems;
+        if (kind == kR2C) PHAST_HIP(launch_digest<T>(sr, si, hp, batch, hp, probe, d_out, st));
+        else PHAST_HIP(launch_digest<T>(x, x, n, batch, n, 2 * probe + 1, d_out, st));
+        return (int)PHAST_OK;
+    };
+    return dit.tune_core(kind, batch, ilog2(n), ring.ring, false, run, refill, digest, rep);
 }
 
 }  // namespace phast

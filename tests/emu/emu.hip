@@ -556,6 +556,10 @@ int phast_emu_check_plan_tables(int *n_entries) {
     *n_entries = 0;
     return check_tables<double>(n_entries) + check_tables<float>(n_entries);
 }
+// plan.hpp: digests_agree -- the result check of a tuning run
+int phast_emu_digests_agree(const double *a, const double *c, size_t batch, size_t n, size_t elem_bytes) {
+    return phast::digests_agree(a, c, batch, n, elem_bytes) ? 1 : 0;
+}
 // The candidate set of a tuning run (plan.hpp: enumerate_plans, tune_tile_range): every entry must be a plan (make_passes), must
 // survive the round trip through its text form (the wisdom format), and -- returned -- how many there are; *has_spec = whether
 // `spec` (e.g. the hand-ranked table entry of that length) is among them.

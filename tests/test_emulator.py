@@ -468,3 +468,35 @@ def test_tuning_candidates_are_plans_and_cover_the_hand_ranked_tables(emu):
             assert has.value == 1, (L, eb, batch, spec)
     # nothing to enumerate below the multi-pass lengths
     assert emu.phast_emu_enumerate_plans(10, 8, 1, None, C.byref(has), C.byref(bad)) == 0
+
+
+def test_tuning_result_check_stops_a_wrong_plan(emu):
+    """Before a tuning run adopts a plan it compares the plan's output with the static rule's through per-transform digests
+    (plan.hpp: digests_agree).  Two correct plans differ by rounding; a plan with a wrong geometry does not survive."""
+    emu.phast_emu_digests_agree.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_size_t, C.c_size_t, C.c_size_t]
+    emu.phast_emu_digests_agree.restype = C.c_int
+    rng = np.random.default_rng(5)
+    n, batch = 1 << 12, 3
+    digs = []
+    for b in range(batch):
+        x = np.fft.fft(rng.uniform(-1, 1, n) + 1j * rng.uniform(-1, 1, n))
+        digs.append([x.real.sum(), x.imag.sum(), float(np.sum(np.abs(x) ** 2)), x.real[1]])
+    a = np.array(digs, np.float64)
+
+    def agree(c, eb):
+        return emu.phast_emu_digests_agree(a.ctypes.data_as(C.POINTER(C.c_double)), np.ascontiguousarray(c).ctypes.data_as(C.POINTER(C.c_double)),
+                                           batch, n, eb)
+
+    assert agree(a.copy(), 8) == 1 and agree(a.copy(), 4) == 1
+    r = a * (1 + 1e-12 * rng.standard_normal(a.shape))      # rounding-level differences: another plan, the same transform
+    assert agree(r, 8) == 1
+    r32 = a * (1 + 1e-6 * rng.standard_normal(a.shape))
+    assert agree(r32, 4) == 1 and agree(r32, 8) == 0         # (f64 results that differ by 1e-6 are not the same transform)
+    bad = a.copy(); bad[1, 2] *= 1.01                        # one transform's energy off by 1 %
+    assert agree(bad, 8) == 0 and agree(bad, 4) == 0
+    bad = a.copy(); bad[2, 3] += 0.5 * np.sqrt(a[2, 2] / n)  # one probed bin off by half an rms bin
+    assert agree(bad, 4) == 0
+    bad = a.copy(); bad[0, 0] = np.nan
+    assert agree(bad, 8) == 0
+    swapped = a[::-1].copy()                                 # the right transforms in the wrong places
+    assert agree(swapped, 4) == 0
