@@ -16,6 +16,11 @@ complex samples transformed per second over the whole job, inputs resident in HB
     buffer of a pre-filled ring (values never overflow; the ring, > 512 MiB, defeats the 256 MiB Infinity Cache);
     the K steps are captured once into a HIP graph and replayed inside the timed region so that the host launch
     path (Python + ctypes) is not what is measured.
+    After the timed region four buffers of that ring are compared, every bin, with the CPU oracle's fft_64_dit of the
+    same seeded inputs (`config.result_check`; the oracle is the checker, never the thing measured).
+    `config.results` (round 5: the driver's record keeps the top-level keys and `config`) holds the WHOLE metric in
+    compact form -- {value, ms_per_step, frac, frac_transform, cpu_value, traffic_over_algorithmic} for N = 2^20, N = 2^26,
+    the round trip, R2C / C2R f32 2^24, f32 C2C 2^20 / 2^26 and the 1024-transform shard.
     The same line carries, under "configs", the other single-GPU BASELINE configurations measured in the same run,
     each with its own value / ms_per_step / roofline / cpu_baseline:
       n2p26_forward   (the second half of BASELINE's metric: N=2^26, 1 GiB per transform, three 2 GiB-traffic passes)
@@ -32,7 +37,9 @@ complex samples transformed per second over the whole job, inputs resident in HB
     Parseval on every transform of the shard and >= 8 sampled transforms against digests computed from the CPU
     oracle's output (the oracle is the checker here, never the thing measured).
 
-"roofline": HIP-event duration of the dominant pass kernel vs the 8 TB/s HBM peak, and -- N = 1 --
+"roofline": HIP-event duration of the dominant pass kernel vs the 8 TB/s HBM peak = `frac` =
+`frac_dominant_pass`; `frac_transform` = the transform's compulsory bytes / the sum of its kernels' durations / peak (SURVEY.md
+8d's figure, <= 1/passes); `traffic` = HBM bytes per launch from the committed PMC profile of the plan that ran; and -- N = 1 --
 `stream_probe` = {read, write, copy} GB/s of the library's own hand-written streaming kernels on 1 GiB in the same run
 (csrc/probe.hip) with `frac_of_copy` / `pass_frac_of_copy` for every config: the ceiling of THIS box on the line;
 "cpu_baseline": the -O3 build of the oracle (a C restatement of the reference's CPU algorithm, bit-identical to the
