@@ -233,8 +233,8 @@ class _PlannerDit:
 
     # ---- MI355X-side extras (no reference counterpart) ----
     def describe(self) -> str:
-        buf = C.create_string_buffer(1024)
-        _check(getattr(_lib.lib(), f"phast_planner_dit{self._sfx}_describe")(self._h, buf, C.c_size_t(1024)))
+        buf = C.create_string_buffer(16384)   # (a planner may carry a dozen wisdom plans besides its static ones)
+        _check(getattr(_lib.lib(), f"phast_planner_dit{self._sfx}_describe")(self._h, buf, C.c_size_t(16384)))
         return buf.value.decode()
 
     def device_bytes(self) -> int:
@@ -337,8 +337,8 @@ class _PlannerR2c:
 
     def describe(self) -> str:
         """Plan of the inner N/2-point complex transform."""
-        buf = C.create_string_buffer(1024)
-        _check(getattr(_lib.lib(), f"phast_planner_r2c{self._sfx}_describe")(self._h, buf, C.c_size_t(1024)))
+        buf = C.create_string_buffer(16384)
+        _check(getattr(_lib.lib(), f"phast_planner_r2c{self._sfx}_describe")(self._h, buf, C.c_size_t(16384)))
         return buf.value.decode()
 
     def set_plan(self, log_rows=(), tile_log=12, points_log=4) -> None:
