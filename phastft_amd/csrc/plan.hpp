@@ -601,9 +601,15 @@ inline double plan_model_us(const std::vector<PassGeom> &ps, unsigned L, size_t 
 inline void enumerate_plans(unsigned L, size_t elem_bytes, size_t batch, unsigned tl_lo, unsigned tl_hi, std::vector<PlanSpec> &out) {
     out.clear();
     if (L < kTwinMinLog || L > 31) return;
-    const unsigned lps64[] = {3, 4, 5, 3 | kWaveTiles, 4 | kWaveTiles}, lps32[] = {3, 4, 5};
-    const unsigned *lps = elem_bytes == 8 ? lps64 : lps32;
+    const unsigned lps64[] = {3, 4, 5, 3 | kWaveTiles, 4 | kWaveTiles};
+#ifdef PHAST_EXPERIMENTAL_WAVE_F32  // (build.py --experimental: the f32 wave tiles are candidates too)
+    const unsigned lps32[] = {3, 4, 5, 3 | kWaveTiles, 4 | kWaveTiles};
+    const unsigned n_lps = 5;
+#else
+    const unsigned lps32[] = {3, 4, 5};
     const unsigned n_lps = elem_bytes == 8 ? 5 : 3;
+#endif
+    const unsigned *lps = elem_bytes == 8 ? lps64 : lps32;
     std::vector<std::pair<double, PlanSpec>> scored;
     std::vector<PassGeom> geo;
     for (unsigned np = 2; np <= 3; ++np) {
