@@ -37,7 +37,7 @@ import numpy as np
 from . import _lib
 
 __all__ = [
-    "Direction", "PlannerMode", "TuneKind", "wisdom_export", "wisdom_import", "wisdom_forget", "wisdom_builtin", "Options", "PhastPanic", "PhastHipError",
+    "Direction", "PlannerMode", "TuneKind", "wisdom_export", "wisdom_import", "wisdom_forget", "wisdom_builtin", "wisdom_count", "Options", "PhastPanic", "PhastHipError",
     "PlannerDit64", "PlannerDit32", "PlannerR2c64", "PlannerR2c32",
     "fft_64_dit", "fft_32_dit", "fft_64_dit_with_planner", "fft_32_dit_with_planner",
     "fft_64_dit_with_planner_and_opts", "fft_32_dit_with_planner_and_opts",
@@ -82,8 +82,13 @@ def _tune(fn, handle, batch: int, kind: "TuneKind") -> dict:
             "us_best": float(rep.us_best), "seconds": float(rep.seconds), "plan": rep.plan.decode()}
 
 
+def wisdom_count(layer: int = -1) -> int:
+    """Entries of a wisdom layer: 0 built-in, 1 PHAST_WISDOM file, 2 imported, 3 measured by this process; -1 all."""
+    return int(_lib.lib().phast_wisdom_count(C.c_int(layer)))
+
+
 def wisdom_export() -> str:
-    """Everything tuning runs (and imports, and the built-in layer) know, as text (csrc/wisdom.hpp)."""
+    """What this process measured, imported or read from PHAST_WISDOM, as text (csrc/wisdom.hpp) -- without the built-in layer."""
     need = C.c_size_t(0)
     _check(_lib.lib().phast_wisdom_export(None, C.c_size_t(0), C.byref(need)))
     buf = C.create_string_buffer(need.value)

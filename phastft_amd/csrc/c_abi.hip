@@ -98,6 +98,7 @@ int phast_wisdom_import(const char *text) {
 }
 void phast_wisdom_forget(void) { WisdomStore::instance().forget(); }
 void phast_wisdom_builtin(int enable) { WisdomStore::instance().set_builtin(enable != 0); }
+size_t phast_wisdom_count(int layer) { return WisdomStore::instance().count(layer); }
 
 const char *phast_strerror(int code) {
     switch (code) {

@@ -93,10 +93,19 @@ class WisdomStore {
         load_layers_locked();
         return import_locked(text, layer, skipped);
     }
+    // what this process measured, imported or read from PHAST_WISDOM -- NOT the built-in layer: a text that carried it would pin
+    // this library version's built-in plans in every file and process it travels to
     std::string export_text() {
         std::lock_guard<std::mutex> lk(mu_);
         load_layers_locked();
-        return export_locked();
+        return export_locked(1);
+    }
+    size_t count(int layer) {  // entries of one layer (0 built-in .. 3 measured here), -1: all
+        std::lock_guard<std::mutex> lk(mu_);
+        load_layers_locked();
+        size_t c = 0;
+        for (const auto &kv : entries_) c += layer < 0 || kv.second.layer == layer;
+        return c;
     }
     void forget() {  // everything but the built-in layer
         std::lock_guard<std::mutex> lk(mu_);
@@ -109,11 +118,6 @@ class WisdomStore {
         load_layers_locked();
         for (auto it = entries_.begin(); it != entries_.end();) it = it->second.layer == 0 ? entries_.erase(it) : std::next(it);
         if (on) (void)import_locked(builtin_text(), 0, nullptr);  // (an entry of a later layer for the same key stays)
-    }
-    size_t size() {
-        std::lock_guard<std::mutex> lk(mu_);
-        load_layers_locked();
-        return entries_.size();
     }
 
   private:
@@ -195,11 +199,12 @@ class WisdomStore {
         }
         return header ? 0 : -1;
     }
-    std::string export_locked() const {
+    std::string export_locked(int min_layer) const {
         // grouped by the CU count the entries were measured with (one header per group)
         std::map<int, std::string> groups;
         for (const auto &kv : entries_) {
             const WisdomEntry &e = kv.second;
+            if (e.layer < min_layer) continue;
             char tail[96];
             std::snprintf(tail, sizeof tail, " fuse=%d us=%.2f heur=%.2f\n", e.fuse ? 1 : 0, (double)e.us, (double)e.us_heur);
             groups[e.cus] += kv.first + " " + (e.heuristic ? std::string("heuristic") : spec_to_string(e.spec)) + tail;
@@ -213,7 +218,7 @@ class WisdomStore {
         std::string text;
         {
             std::lock_guard<std::mutex> lk(mu_);
-            text = export_locked();
+            text = export_locked(1);
         }
         const std::string tmp = path + ".tmp";
         if (FILE *f = std::fopen(tmp.c_str(), "wb")) {
