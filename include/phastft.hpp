@@ -6,7 +6,7 @@
 //   planner::Direction {Forward = 1, Reverse = -1}  planner.rs:10    enum class Direction
 //   planner::PlannerMode {Heuristic, Tune}          planner.rs:24    enum class PlannerMode
 //   options::Options, Options::guess_options        options.rs:10    struct Options, Options::guess_options
-//   PlannerDit64/32::{new, with_mode}               planner.rs:55    class PlannerDit64/32 (ctor, with_mode)
+//   PlannerDit64/32::{new, with_mode}               planner.rs:55    class PlannerDit64/32 (ctor, with_mode; + tune, wisdom_*)
 //   PlannerR2c64/32::new                            planner.rs:194   class PlannerR2c64/32
 //   fft_64_dit, fft_32_dit                          lib.rs:180,223   fft_64_dit, fft_32_dit
 //   fft_*_dit_with_planner[_and_opts]               lib.rs:143,186; dit.rs:263,338
@@ -133,6 +133,18 @@ PHASTFT_PLANNER(PlannerR2c32, phast_planner_r2c32,
                 },
                 phast_planner_r2c32_free)
 #undef PHASTFT_PLANNER
+
+// ---- wisdom: what PlannerMode::Tune measured, as text (csrc/wisdom.hpp; no reference counterpart) ----
+inline std::string wisdom_export() {
+    std::size_t need = 0;
+    check(phast_wisdom_export(nullptr, 0, &need));
+    std::string text(need, '\0');
+    check(phast_wisdom_export(&text[0], need, nullptr));
+    text.resize(need ? need - 1 : 0);
+    return text;
+}
+inline void wisdom_import(const std::string &text) { check(phast_wisdom_import(text.c_str())); }
+inline void wisdom_forget() { phast_wisdom_forget(); }
 
 // ---- C2C, planar (lib.rs:143-226, algorithms/dit.rs:263,338) ----
 inline void fft_64_dit_with_planner_and_opts(Slice<double> reals, Slice<double> imags, Direction direction,

@@ -236,18 +236,16 @@ int main(int argc, char **argv) {
         EXPECT(r32.candidates >= 8 && r32.plan[0] != '\0');
         EXPECT(panic_message([&] { (void)c32.tune(4, PHAST_TUNE_R2C); }) == "invalid argument");
         // what was measured travels as text
-        size_t need = 0;
-        EXPECT(phast_wisdom_export(nullptr, 0, &need) == PHAST_OK && need > 32);
-        std::string text(need, '\0');
-        EXPECT(phast_wisdom_export(&text[0], need, nullptr) == PHAST_OK);
+        const std::string text = wisdom_export();
         EXPECT(text.find("f64 c2r 15 3 ") != std::string::npos && text.find("f32 c2ci 16 2 ") != std::string::npos);
-        phast_wisdom_forget();
-        EXPECT(phast_wisdom_import(text.c_str()) == PHAST_OK);
-        EXPECT(phast_wisdom_import("not wisdom") == PHAST_ERR_INVALID_ARG);
+        wisdom_forget();
+        wisdom_import(text);
+        EXPECT(wisdom_export() == text);
+        EXPECT(panic_message([] { wisdom_import("not wisdom"); }) == "invalid argument");
         PlannerR2c64 again(n);                               // starts with the imported plans
         c2r_fft_f64_with_planner(ore, oim, back, again);
         for (size_t i = 0; i < n; ++i) EXPECT(std::fabs(back[i] - x[i]) < 1e-9);
-        phast_wisdom_forget();
+        wisdom_forget();
     }
     // ---- bit reversal exact (bravo.rs:373-407) ----
     for (unsigned nb = 2; nb <= 18; ++nb) {
