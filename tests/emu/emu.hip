@@ -17,6 +17,19 @@
 
 namespace phast {
 
+// A plan named as the wisdom names it ("9,9@13,13:p32", plan.hpp: PlanSpec) -- tile logs PER PASS and the wave flag, which
+// the (lrs, tile_log | points << 8) arguments of the entry points below cannot carry.  While one is set
+// (phast_emu_set_plan) it replaces those arguments in emu_exec / emu_r2c_fused / emu_c2r_fused.
+inline PlanSpec g_plan;
+inline bool g_have_plan = false;
+static bool forced_plan(std::vector<unsigned> &lrs, std::vector<unsigned> &tls, unsigned &lp) {
+    if (!g_have_plan) return false;
+    lrs = g_plan.lrs();
+    tls = g_plan.tls();
+    lp = g_plan.lp;
+    return true;
+}
+
 template <typename T> static bool emu_pass(const PassGeom &p, const TileArgs &a) {
     if (p.quad) {
         emulate_quad_pass<T>(a);
@@ -52,7 +65,8 @@ static int emu_exec(const void *in_re, const void *in_im, unsigned in_mode, void
     const unsigned tile_log = tile_log_and_lp & 0xff;
     unsigned lp = (tile_log_and_lp >> 8) ? (tile_log_and_lp >> 8) : 4;
     std::vector<unsigned> lrs(lrs_in, lrs_in + np_in), tls(1, tile_log);
-    if (lrs.empty()) {  // the library's own plans: tile_log 0 = latency plan, 1 = the plan for one transform, else throughput
+    if (forced_plan(lrs, tls, lp)) {
+    } else if (lrs.empty()) {  // the library's own plans: tile_log 0 = latency plan, 1 = the plan for one transform, else throughput
         if (tile_log != 1 || !single_plan<T>(log_n, lrs, tls, lp)) heuristic_plan<T>(log_n, tile_log <= 1, lrs, tls, lp);
     }
     std::vector<PassGeom> ps;
@@ -104,7 +118,8 @@ static int emu_r2c_fused(const T *in, unsigned log_n, T *ore, T *oim, const unsi
     const unsigned tile_log = tile_log_and_lp & 0xff;
     unsigned lp = (tile_log_and_lp >> 8) ? (tile_log_and_lp >> 8) : 4;
     std::vector<unsigned> lrs(lrs_in, lrs_in + np_in), tls(1, tile_log);
-    if (lrs.empty()) {  // 0 = latency plan, 1 = the plan for one transform, 2 / 3 = the R2C tables (real_plan / real_batch_plan)
+    if (forced_plan(lrs, tls, lp)) {
+    } else if (lrs.empty()) {  // 0 = latency plan, 1 = the plan for one transform, 2 / 3 = the R2C tables (real_plan / real_batch_plan)
         if (tile_log == 2 || tile_log == 3) {
             if (!(tile_log == 2 ? real_plan<T>(L, false, lrs, tls, lp) : real_batch_plan<T>(L, false, lrs, tls, lp))) return 3;
             lp &= ~kFuseBelow;
@@ -181,7 +196,8 @@ static int emu_c2r_fused(const T *ire, const T *iim, unsigned log_n, T *out, siz
     const unsigned tile_log = tile_log_and_lp & 0xff;
     unsigned lp = (tile_log_and_lp >> 8) ? (tile_log_and_lp >> 8) : 4;
     std::vector<unsigned> lrs(lrs_in, lrs_in + np_in), tls(1, tile_log);
-    if (lrs.empty()) {  // 0 = latency plan, 1 = the plan for one transform, 2 / 3 = the C2R tables (real_plan / real_batch_plan)
+    if (forced_plan(lrs, tls, lp)) {
+    } else if (lrs.empty()) {  // 0 = latency plan, 1 = the plan for one transform, 2 / 3 = the C2R tables (real_plan / real_batch_plan)
         if (tile_log == 2 || tile_log == 3) {
             if (!(tile_log == 2 ? real_plan<T>(L, true, lrs, tls, lp) : real_batch_plan<T>(L, true, lrs, tls, lp))) return 3;
             lp &= ~kFuseBelow;
@@ -367,6 +383,14 @@ extern "C" int phast_emu_audit_lds(int is_f64, unsigned lr, unsigned lc, unsigne
 extern "C" {
 // planar in-place forward / inverse (swap trick + 1/N as algorithms/dit.rs:297-300,325-331)
 #if !defined(EMU_PART) || EMU_PART == 1
+// every transform that follows runs the plan `spec` names (nullptr: back to the arguments' plan); 1 = not a plan text
+int phast_emu_set_plan(const char *spec) {
+    phast::g_have_plan = false;
+    if (!spec) return 0;
+    if (!phast::spec_from_string(spec, phast::g_plan)) return 1;
+    phast::g_have_plan = true;
+    return 0;
+}
 int phast_emu_fft_f64(double *re, double *im, unsigned log_n, size_t batch, int direction, const unsigned *lrs,
                       size_t np, unsigned tile_log) {
     const size_t n = (size_t)1 << log_n;

@@ -500,3 +500,94 @@ def test_tuning_result_check_stops_a_wrong_plan(emu):
     assert agree(bad, 8) == 0
     swapped = a[::-1].copy()                                 # the right transforms in the wrong places
     assert agree(swapped, 4) == 0
+
+
+def _builtin_wisdom_plans(max_log=21, stride_above=3, cap_log=24):
+    """(type, kind, caller's log2 length, plan text, fuse) of csrc/builtin_wisdom.inc -- every distinct plan up to 2^max_log,
+    every stride_above-th of the longer ones up to 2^cap_log (emulating a thread at a time, a 2^20-point plan takes 0.2 s)."""
+    import os
+    import re
+    path = os.path.join(os.path.dirname(__file__), "..", "phastft_amd", "csrc", "builtin_wisdom.inc")
+    seen, out, long_ones = set(), [], 0
+    for m in re.finditer(r'^"(f64|f32) (c2c|c2ci|r2c|c2r) (\d+) \d+ (\S+) fuse=([01])', open(path).read(), re.M):
+        ty, kind, L, plan, fuse = m.group(1), m.group(2), int(m.group(3)), m.group(4), int(m.group(5))
+        key = (ty, kind, L, plan, fuse)
+        if plan == "heuristic" or key in seen or L > cap_log:
+            continue
+        seen.add(key)
+        if L > max_log:
+            long_ones += 1
+            if long_ones % stride_above:
+                continue
+        out.append(key)
+    return out
+
+
+def test_builtin_wisdom_plans_thread_by_thread_vs_numpy(emu):
+    """round 5: the tuner composes passes the hand-ranked tables never did (a tile log per pass: "8,8@12,13:p16"), and what it
+    adopted on the GPU ships as built-in wisdom.  On the GPU a plan is adopted only after its output agreed with the static
+    rule's (digests at two bins); here every distinct built-in plan up to 2^21 points and a third of those up to 2^24 runs
+    through the kernels' own phase functions thread by thread, against numpy in float64: C2C plans in place, R2C plans
+    through the fused last pass where the entry says so (else the inner transform from interleaved pairs), C2R plans through
+    the fused first pass where that pass has one (else the inner transform)."""
+    emu.phast_emu_set_plan.argtypes = [C.c_char_p]
+    plans = _builtin_wisdom_plans()
+    assert len(plans) >= 200, len(plans)
+    ran = {"c2c": 0, "c2ci": 0, "r2c": 0, "c2r": 0, "r2c_fused": 0, "c2r_fused": 0}
+    try:
+        for ty, kind, L, plan, fuse in plans:
+            dtype = np.float64 if ty == "f64" else np.float32
+            tol = 1e-13 if ty == "f64" else 1e-5
+            rng = np.random.default_rng(L * 131 + len(plan))
+            assert emu.phast_emu_set_plan(plan.encode()) == 0, plan
+            n = 1 << L
+
+            def inner_c2c(m, interleaved_in):  # the plan as the complex transform of 2^m points it is inside a real one
+                z = rng.uniform(-1, 1, 1 << m) + 1j * rng.uniform(-1, 1, 1 << m)
+                a, b = z.real.astype(dtype), z.imag.astype(dtype)
+                ref = np.fft.fft(a.astype(np.float64) + 1j * b.astype(np.float64))
+                if interleaved_in and dtype == np.float32:
+                    pairs = np.empty(2 << m, dtype)
+                    pairs[0::2], pairs[1::2] = a, b
+                    ore, oim = np.zeros(1 << m, dtype), np.zeros(1 << m, dtype)
+                    p = lambda v: v.ctypes.data_as(C.c_void_p)
+                    rc = emu.phast_emu_fft_f32_modes(p(pairs), None, 1, p(ore), p(oim), 0, m, 1.0, None, 0, 0)
+                    a, b = ore, oim
+                else:
+                    rc = run(emu, a, b, 1)
+                assert rc == 0, (ty, kind, L, plan, rc)
+                got = a.astype(np.float64) + 1j * b.astype(np.float64)
+                assert np.linalg.norm(got - ref) / np.linalg.norm(ref) <= tol, (ty, kind, L, plan)
+
+            if kind in ("c2c", "c2ci"):
+                inner_c2c(L, kind == "c2ci")
+                ran[kind] += 1
+            elif kind == "r2c":
+                x = rng.uniform(-1, 1, n).astype(dtype)
+                if fuse:
+                    rc, ore, oim = _emu_r2c(emu, x)
+                    assert rc == 0, (ty, kind, L, plan, rc)  # an entry that says fuse=1 names a plan whose last pass has the form
+                    ref = np.fft.rfft(x.astype(np.float64))
+                    got = ore.astype(np.float64) + 1j * oim.astype(np.float64)
+                    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) <= tol, (ty, kind, L, plan)
+                    assert oim[0] == 0 and oim[-1] == 0
+                    ran["r2c_fused"] += 1
+                else:
+                    inner_c2c(L - 1, True)
+                ran[kind] += 1
+            else:
+                spec = np.fft.rfft(rng.uniform(-1, 1, n))
+                spec.imag[0] = spec.imag[-1] = 0.0
+                ire, iim = spec.real.astype(dtype), spec.imag.astype(dtype)
+                rc, out = _emu_c2r(emu, ire, iim, n)
+                assert rc in (0, 3), (ty, kind, L, plan, rc)
+                if rc == 0:
+                    ref = np.fft.irfft(ire.astype(np.float64) + 1j * iim.astype(np.float64), n)
+                    assert np.linalg.norm(out - ref) / np.linalg.norm(ref) <= tol, (ty, kind, L, plan)
+                    ran["c2r_fused"] += 1
+                else:  # no fused form of its first pass: the library runs the preprocess sweep, then this plan
+                    inner_c2c(L - 1, False)
+                ran[kind] += 1
+    finally:
+        emu.phast_emu_set_plan(None)
+    assert min(ran["c2c"], ran["r2c"], ran["c2r"]) >= 10 and ran["r2c_fused"] >= 3 and ran["c2r_fused"] >= 3, ran
