@@ -566,7 +566,9 @@ def test_torch_free_sharded_host_with_rccl_gather(gpu, oracle, tmp_path):
     torch.cuda.synchronize()
     py_value = shard * n * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
     print(f"\nshard_host {out['value']:.1f} GSamples/s over {gpus} device(s) (per device {out['value'] / gpus:.1f}); Python host {py_value:.1f} on one")
-    assert out["value"] / gpus >= 0.9 * py_value, (out["value"], gpus, py_value)
+    # (one device is what this pool has measured; with several, the threads of one process share a host and the step ends with
+    # the slowest device: the bar there is that nothing serialises them)
+    assert out["value"] / gpus >= (0.9 if gpus == 1 else 0.6) * py_value, (out["value"], gpus, py_value)
 
 
 # ---------------------------------------------------------------- the committed error budget still holds
