@@ -23,6 +23,8 @@
 #include <mutex>
 #include <sstream>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "plan.hpp"
 
@@ -150,6 +152,7 @@ class WisdomStore {
             }
         }
     }
+    // all or nothing: a text that is refused (no header, another format version -- also half way down) leaves the store as it was
     int import_locked(const char *text, int layer, size_t *skipped) {
         if (skipped) *skipped = 0;
         if (!text) return -1;
@@ -157,6 +160,7 @@ class WisdomStore {
         std::string line;
         int cus = 0;
         bool header = false;
+        std::vector<std::pair<std::string, WisdomEntry>> parsed;
         while (std::getline(in, line)) {
             if (line.empty() || line[0] == '#') continue;
             std::istringstream ls(line);
@@ -193,11 +197,14 @@ class WisdomStore {
                 if (skipped) ++*skipped;
                 continue;
             }
-            const std::string ky = key(a == "f64" ? 8 : 4, k, log_n, bucket);
-            auto it = entries_.find(ky);
-            if (it == entries_.end() || it->second.layer <= layer) entries_[ky] = e;
+            parsed.emplace_back(key(a == "f64" ? 8 : 4, k, log_n, bucket), e);
         }
-        return header ? 0 : -1;
+        if (!header) return -1;
+        for (auto &kv : parsed) {
+            auto it = entries_.find(kv.first);
+            if (it == entries_.end() || it->second.layer <= layer) entries_[kv.first] = kv.second;
+        }
+        return 0;
     }
     std::string export_locked(int min_layer) const {
         // grouped by the CU count the entries were measured with (one header per group)

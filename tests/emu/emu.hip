@@ -56,7 +56,7 @@ template <typename T> static bool emu_pass(const PassGeom &p, const TileArgs &a)
     return false;
 }
 
-// in -> out through the same pass sequence as Planner<T>::exec (api.hip)
+// in -> out through the same pass sequence as Planner<T>::exec_in (csrc/exec.hpp)
 template <typename T>
 static int emu_exec(const void *in_re, const void *in_im, unsigned in_mode, void *out_re, void *out_im,
                     unsigned out_mode, unsigned log_n, size_t batch, size_t in_dist, size_t out_dist, double scale,

@@ -146,6 +146,9 @@ def test_wisdom_store_without_a_device():
     assert P.wisdom_export() == out2
     with pytest.raises(P.PhastPanic):
         P.wisdom_import("f64 c2c 20 0 heuristic\n")  # no header
+    with pytest.raises(P.PhastPanic):                 # another format version half way down: all or nothing
+        P.wisdom_import("phastft-hip-wisdom 1 cus=256\nf64 c2c 22 0 heuristic fuse=0 us=1.00 heur=1.00\nphastft-hip-wisdom 2 cus=256\n")
+    assert "f64 c2c 22 0" not in P.wisdom_export()
     P.wisdom_forget()
     assert P.wisdom_export() == base
     P.wisdom_builtin(True)
@@ -166,3 +169,45 @@ def test_wisdom_file_is_loaded_at_first_use(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln and not ln.startswith("phastft-hip-wisdom")]
     assert lines == ["f32 c2r 24 1 7,9,7@12,13,13:p16 fuse=0 us=185.13 heur=202.99"], r.stdout
+
+
+def test_wisdom_import_survives_arbitrary_text():
+    """A wisdom file is input from outside (PHAST_WISDOM, phast_wisdom_import): whatever the text, the import either refuses it
+    (no header / wrong version) or keeps exactly the lines that parse -- and what it kept comes out as text that imports back
+    to the same set.  Lines are built from the tokens of the format, mutated: digits where names belong, lists too long, values
+    out of range, stray separators."""
+    import phastft_amd as P
+    from hypothesis import HealthCheck, given, settings
+    from hypothesis import strategies as st
+
+    tok = st.one_of(st.sampled_from(["f64", "f32", "c2c", "c2ci", "r2c", "c2r", "heuristic", "fuse=1", "fuse=0", "us=1.5", "heur=2",
+                                     "6,6@10,11:p8", "9,9@13,13:p32", "6,8,6@10,12,10:p8w", "6,6,6,6@1,1,1,1:p8", "99,6@10,10:p8",
+                                     "6,6@10,10:p7", "6,6@10:p8", ",@:p", "6,,6@10,10:p16", "phastft-hip-wisdom", "1", "2", "cus=256",
+                                     "cus=", "#", "4294967296", "-1", "20", "0", "41"]),
+                    st.text(alphabet="0123456789,@:pw=. -#\tfcru", max_size=12))
+    line = st.lists(tok, max_size=9).map(" ".join)
+    body = st.lists(line, max_size=12).map("\n".join)
+    text = st.tuples(st.sampled_from(["phastft-hip-wisdom 1 cus=256\n", "phastft-hip-wisdom 1\n", "phastft-hip-wisdom 2 cus=1\n", ""]), body).map("".join)
+
+    P.wisdom_builtin(False)
+    try:
+        @settings(max_examples=300, deadline=None, suppress_health_check=list(HealthCheck))
+        @given(text)
+        def check(t):
+            P.wisdom_forget()
+            try:
+                P.wisdom_import(t)
+            except P.PhastPanic:
+                assert P.wisdom_count(-1) == 0, t   # a refused text leaves nothing behind ...
+                return
+            out = P.wisdom_export()
+            n = P.wisdom_count(-1)
+            assert n == len([ln for ln in out.splitlines() if ln and not ln.startswith("phastft-hip-wisdom")]), (t, out)
+            P.wisdom_forget()
+            P.wisdom_import(out)                    # ... and an accepted one is kept in the form it is written in
+            assert P.wisdom_export() == out and P.wisdom_count(-1) == n, (t, out)
+
+        check()
+    finally:
+        P.wisdom_forget()
+        P.wisdom_builtin(True)
