@@ -147,7 +147,7 @@ int phast_planner_dit32_tune(phast_planner_dit32 *p, size_t batch_hint, int kind
  * PHAST_WISDOM=<path>: read at first use, rewritten after every tuning run.  The library also carries built-in wisdom measured
  * on an MI355X (PHAST_BUILTIN_WISDOM=0 turns it off).  No device needed for these three calls. */
 int phast_wisdom_export(char *buf, size_t buf_len, size_t *needed /* bytes incl. NUL, or NULL */); /* without the built-in layer */
-int phast_wisdom_import(const char *text); /* PHAST_ERR_INVALID_ARG: not a wisdom text */
+int phast_wisdom_import(const char *text); /* PHAST_ERR_INVALID_ARG: not a wisdom text (nothing of it is kept); lines that do not parse are skipped */
 void phast_wisdom_forget(void);            /* everything but the built-in layer */
 void phast_wisdom_builtin(int enable);     /* the built-in layer off / on again at run time (planners made afterwards) */
 size_t phast_wisdom_count(int layer);      /* entries of a layer: 0 built-in, 1 PHAST_WISDOM file, 2 imported, 3 measured here; -1 all */
