@@ -688,3 +688,116 @@ def test_wisdom_file_carries_a_tuning_run_to_the_next_process(gpu, tmp_path):
     call2 = [ln for ln in r2.stdout.splitlines() if ln.startswith("CALL")][0]
     assert call1 == call2 and call2.startswith("CALL tuned ") == adopted, (call1, call2)
     assert "tuned" not in [ln for ln in r2.stdout.splitlines() if ln.startswith("OTHER")][0]   # another bucket: the static rules
+
+
+# ---------------------------------------------------------------- every plan the library ships as built-in wisdom
+def _builtin_entries():
+    import re
+
+    path = os.path.join(ROOT, "phastft_amd", "csrc", "builtin_wisdom.inc")
+    out = {}
+    for m in re.finditer(r'^"(f64|f32) (c2c|c2ci|r2c|c2r) (\d+) (\d+) (\S+) fuse=([01])', open(path).read(), re.M):
+        if m.group(5) != "heuristic":
+            out.setdefault((m.group(1), "real" if m.group(2) in ("r2c", "c2r") else "cplx", int(m.group(3))), []).append(
+                (m.group(2), int(m.group(4)), m.group(5), int(m.group(6))))
+    return out
+
+
+def test_every_builtin_wisdom_plan_runs_its_call_within_the_gates(gpu):
+    """csrc/builtin_wisdom.inc holds ~ 425 (type, call kind, length, batch bucket) -> plan lines that a tuning run on an MI355X
+    adopted after a coarse result check (digests at two bins).  Here EVERY line is held to the parity gates at the call it
+    was measured for: a planner made with the wisdom in force must say it runs that plan for a batch in the bucket (the line
+    names a plan this build can make), and its output -- all transforms of the batch, every bin, compared on the device --
+    must agree with the static rule's plan of a planner made without the wisdom (parity-tested against the oracle throughout
+    tests/test_gpu_parity*.py) within the sum of the two gates; up to 2^20 points the first and the last transform also
+    against numpy in float64.  C2R inputs are half-spectra of real signals (made by r2c), so the round trip must return them."""
+    import re
+
+    import torch
+
+    P = gpu
+    entries = _builtin_entries()
+    assert sum(len(v) for v in entries.values()) >= 300
+    rng = np.random.default_rng(2025)
+    kinds = {"c2c": P.TuneKind.C2C, "c2ci": P.TuneKind.C2CInterleaved, "r2c": P.TuneKind.R2C, "c2r": P.TuneKind.C2R}
+    checked = 0
+
+    def gates(dt, L):
+        return (tol.f64_rel(L), tol.f64_bin(L)) if dt == "f64" else (tol.f32_rel(L), tol.f32_bin(L))
+
+    def close(tag, dt, L, got, want, n_per, factor=2.0):
+        """device tensors [batch * n_per] (real views of whatever the call wrote): rel-L2 over the batch, worst element against
+        the rms element, both within `factor` x the gate (two plans, each inside its own gate of the exact transform)"""
+        g, w = got.to(torch.float64), want.to(torch.float64)
+        den = float(torch.linalg.vector_norm(w))
+        rel = float(torch.linalg.vector_norm(g - w)) / den
+        worst = float((g - w).abs().max()) / (den / np.sqrt(w.numel()))
+        g_rel, g_bin = gates(dt, L)
+        # (per-bin gate: rms over re and im together is 1/sqrt(2) of the rms bin magnitude the gate is written for)
+        assert rel <= factor * g_rel and worst <= factor * g_bin * np.sqrt(2.0), (tag, rel, factor * g_rel, worst, factor * g_bin)
+
+    for (dt, cls, L), lines in sorted(entries.items()):
+        n = 1 << L
+        tdt = torch.float64 if dt == "f64" else torch.float32
+        Pl = (P.PlannerR2c64 if dt == "f64" else P.PlannerR2c32) if cls == "real" else (P.PlannerDit64 if dt == "f64" else P.PlannerDit32)
+        P.wisdom_builtin(False)
+        try:
+            static = Pl(n)
+        finally:
+            P.wisdom_builtin(True)
+        tuned = Pl(n)
+        for kind, bucket, plan, fuse in lines:
+            batch = 1 << bucket
+            tag = f"{dt} {kind} 2^{L} x {batch} {plan}"
+            said = tuned.describe_call(batch, kinds[kind])
+            assert said.startswith("tuned "), (tag, said)
+            assert not static.describe_call(batch, kinds[kind]).startswith("tuned "), tag
+            lrs, tls = (list(map(int, part.split(","))) for part in plan.split(":")[0].split("@"))
+            shapes = [(int(r), int(c)) for r, c in re.findall(r"\[(\d+)x(\d+)A? ", said)]
+            assert shapes == [(1 << lr, 1 << (tl - lr)) for lr, tl in zip(lrs, tls)], (tag, said)
+            if kind == "r2c":
+                assert ("untangle-fused" in said) == bool(fuse), (tag, said)
+            if kind in ("c2c", "c2ci"):
+                re0 = torch.empty(batch * n, dtype=tdt, device="cuda").uniform_(-1, 1)
+                im0 = torch.empty_like(re0).uniform_(-1, 1)
+                outs = []
+                for pl in (static, tuned):
+                    if kind == "c2c":
+                        a, b = re0.clone(), im0.clone()
+                        P.fft_dit_batched(a, b, n, P.Direction.Forward, pl)
+                        outs.append(torch.stack((a, b)))
+                    else:
+                        assert batch == 1
+                        z = torch.complex(re0, im0)
+                        (P.fft_64_interleaved_with_planner if dt == "f64" else P.fft_32_interleaved_with_planner)(z, P.Direction.Forward, pl)
+                        outs.append(torch.stack((z.real, z.imag)))
+                close(tag, dt, L, outs[1].flatten(), outs[0].flatten(), n)
+                if L <= 20:
+                    for b in sorted({0, batch - 1}):
+                        sl = slice(b * n, (b + 1) * n)
+                        tol.check("builtin:" + kind, dt, L, outs[1][0][sl].cpu().numpy(), outs[1][1][sl].cpu().numpy(),
+                                  *_ref_c2c(re0[sl].cpu().numpy(), im0[sl].cpu().numpy()))
+            else:
+                h = n // 2 + 1
+                x = torch.empty(batch * n, dtype=tdt, device="cuda").uniform_(-1, 1)
+                sr, si = (torch.empty(batch * h, dtype=tdt, device="cuda") for _ in range(2))
+                P.r2c_fft_batched(x, sr, si, static, batch)
+                if kind == "r2c":
+                    tr, ti = torch.empty_like(sr), torch.empty_like(si)
+                    P.r2c_fft_batched(x, tr, ti, tuned, batch)
+                    close(tag, dt, L, torch.stack((tr, ti)).flatten(), torch.stack((sr, si)).flatten(), h)
+                    if L <= 20:
+                        for b in sorted({0, batch - 1}):
+                            ref = np.fft.rfft(x[b * n:(b + 1) * n].cpu().numpy().astype(np.float64))
+                            tol.check("builtin:r2c", dt, L, tr[b * h:(b + 1) * h].cpu().numpy(), ti[b * h:(b + 1) * h].cpu().numpy(), ref.real, ref.imag)
+                else:
+                    ys, yt = torch.empty_like(x), torch.empty_like(x)
+                    P.c2r_fft_batched(sr.clone(), si.clone(), ys, static, batch)
+                    P.c2r_fft_batched(sr, si, yt, tuned, batch)
+                    close(tag, dt, L, yt, ys, n)
+                    close(tag + " round trip", dt, L, yt, x, n, factor=3.0)  # r2c (static) + c2r (tuned)
+            checked += 1
+        del static, tuned
+        torch.cuda.empty_cache()
+    print(f"\n{checked} built-in wisdom lines checked at their own call")
+    assert checked >= 300
