@@ -690,6 +690,80 @@ def test_wisdom_file_carries_a_tuning_run_to_the_next_process(gpu, tmp_path):
     assert "tuned" not in [ln for ln in r2.stdout.splitlines() if ln.startswith("OTHER")][0]   # another bucket: the static rules
 
 
+# ---------------------------------------------------------------- a tuning run beside callers of the same planner
+def test_tuning_while_other_threads_transform_with_the_planner(gpu, static_rules):
+    """The planners are shared values (planner.rs:38-39: Send + Sync) and a tuning run CHANGES one: it holds the plans shared
+    while it measures and exclusively for the moment it installs the winner (planner_plans.hpp: install_built).  Three threads
+    keep 16 x 2^18 f64 transforms going through one planner, each on its own stream and buffers, while the main thread tunes
+    that very call (f64 2^18 x 16: the static rule's plan loses by 25 % there, so a plan IS swapped under them) and once more
+    for another bucket: every result before, during and after the swap is inside the gates of a float64 reference, nothing
+    deadlocks, and the threads' later calls run the tuned plan."""
+    import torch
+
+    P = gpu
+    L, batch = 18, 16
+    n = 1 << L
+    pl = P.PlannerDit64(n)
+    rng = np.random.default_rng(77)
+    h_re, h_im = rng.uniform(-1, 1, batch * n), rng.uniform(-1, 1, batch * n)
+    z = np.fft.fft((h_re + 1j * h_im).reshape(batch, n), axis=1).reshape(-1)
+    src = torch.stack((dev(h_re), dev(h_im)))
+    want = torch.stack((dev(z.real.copy()), dev(z.imag.copy())))
+    den = float(torch.linalg.vector_norm(want))
+    rms = den / np.sqrt(2 * batch * n)
+    stop = threading.Event()
+    errors, counts = [], [0, 0, 0]
+
+    def caller(k):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                buf = torch.empty_like(src)
+                while not stop.is_set():
+                    buf.copy_(src)
+                    P.fft_dit_batched(buf[0], buf[1], n, P.Direction.Forward, pl)
+                    d = buf - want
+                    rel = float(torch.linalg.vector_norm(d)) / den
+                    worst = float(d.abs().max()) / rms
+                    if not (rel <= tol.f64_rel(L) and worst <= tol.f64_bin(L) * np.sqrt(2.0)):
+                        errors.append((k, counts[k], rel, worst))
+                        return
+                    counts[k] += 1
+        except Exception as e:  # noqa: BLE001 -- reported by the main thread
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=caller, args=(k,)) for k in range(3)]
+    for t in threads:
+        t.start()
+    try:
+        import time
+
+        t0 = time.time()
+        while min(counts) < 5 and not errors and time.time() - t0 < 60:
+            time.sleep(0.01)
+        before = list(counts)
+        rep = pl.tune(batch)
+        rep2 = pl.tune(2)
+        mid = list(counts)
+        t0 = time.time()
+        while min(c - m for c, m in zip(counts, mid)) < 20 and not errors and time.time() - t0 < 60:
+            time.sleep(0.01)
+    finally:
+        stop.set()
+        for t in threads:
+            t.join(120)
+    torch.cuda.synchronize()
+    assert not errors, errors
+    assert all(not t.is_alive() for t in threads)
+    assert min(before) >= 5 and min(c - m for c, m in zip(counts, mid)) >= 20, (before, mid, counts)
+    assert rep["candidates"] >= 8 and rep2["candidates"] >= 8, (rep, rep2)
+    print(f"\ntuned beside 3 callers: {rep['plan']} ({rep['us_heuristic']:.1f} -> {rep['us_best']:.1f} us, adopted={rep['adopted']}), "
+          f"x2: {rep2['plan']}; calls per thread before / during / after: {before} / {[m - b for m, b in zip(mid, before)]} / {[c - m for c, m in zip(counts, mid)]}")
+    if rep["adopted"]:
+        assert pl.describe_call(batch).startswith("tuned "), pl.describe_call(batch)
+    P.wisdom_forget()
+
+
 # ---------------------------------------------------------------- every plan the library ships as built-in wisdom
 def _builtin_entries():
     import re
