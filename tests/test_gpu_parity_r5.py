@@ -764,6 +764,67 @@ def test_tuning_while_other_threads_transform_with_the_planner(gpu, static_rules
     P.wisdom_forget()
 
 
+def test_a_graph_captured_before_a_tuning_run_keeps_replaying_its_plan(gpu, static_rules):
+    """A captured call holds its kernels' arguments by value -- table pointers (the planner's table cache: released with the
+    planner, never with a plan) and the scratch of the workspace that went to the graph.  A tuning run afterwards widens the
+    scratch pitch, installs another plan for the very call and drops the candidates' descriptors: the graph's replays must not
+    notice (bit-identical to the replay before), eager calls run the tuned plan (inside the gates, not bit-identical), and a
+    new capture after one eager call records the tuned plan."""
+    import torch
+
+    P = gpu
+    L, batch = 18, 16
+    n = 1 << L
+    pl = P.PlannerDit64(n)
+    rng = np.random.default_rng(78)
+    h_re, h_im = rng.uniform(-1, 1, batch * n), rng.uniform(-1, 1, batch * n)
+    z = np.fft.fft((h_re + 1j * h_im).reshape(batch, n), axis=1).reshape(-1)
+    src_re, src_im = dev(h_re), dev(h_im)
+    s = torch.cuda.Stream()
+
+    def captured():
+        g_re, g_im = src_re.clone(), src_im.clone()
+        with torch.cuda.stream(s):
+            P.fft_dit_batched(g_re, g_im, n, P.Direction.Forward, pl)   # eager once: the workspace a capture may take
+        s.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(s):
+            with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
+                P.fft_dit_batched(g_re, g_im, n, P.Direction.Forward, pl)
+        return g, g_re, g_im
+
+    def replay(g, g_re, g_im):
+        with torch.cuda.stream(s):
+            g_re.copy_(src_re); g_im.copy_(src_im)
+            g.replay()
+        s.synchronize()
+        return g_re.clone(), g_im.clone()
+
+    g1 = captured()
+    a_re, a_im = replay(*g1)
+    tol.check("graph before tune", "f64", L, a_re.cpu().numpy(), a_im.cpu().numpy(), z.real, z.imag)
+    plan_before = pl.describe_call(batch)
+    rep = pl.tune(batch)
+    assert rep["adopted"], rep   # (f64 2^18 x 16: the static rule's plan loses by 20 .. 25 % on every box so far)
+    assert pl.describe_call(batch).startswith("tuned ") and pl.describe_call(batch) != plan_before
+    for _ in range(3):
+        b_re, b_im = replay(*g1)
+        assert torch.equal(a_re, b_re) and torch.equal(a_im, b_im)      # the graph still runs the plan it captured
+    e_re, e_im = src_re.clone(), src_im.clone()
+    P.fft_dit_batched(e_re, e_im, n, P.Direction.Forward, pl)
+    torch.cuda.synchronize()
+    tol.check("eager after tune", "f64", L, e_re.cpu().numpy(), e_im.cpu().numpy(), z.real, z.imag)
+    assert not (torch.equal(e_re, a_re) and torch.equal(e_im, a_im))    # another plan: the last bits differ
+    g2 = captured()
+    c_re, c_im = replay(*g2)
+    assert torch.equal(c_re, e_re) and torch.equal(c_im, e_im)          # the new capture recorded the tuned plan
+    b_re, b_im = replay(*g1)
+    assert torch.equal(a_re, b_re) and torch.equal(a_im, b_im)
+    del g1, g2
+    pl.release_graph_workspaces()
+    P.wisdom_forget()
+
+
 # ---------------------------------------------------------------- every plan the library ships as built-in wisdom
 def _builtin_entries():
     import re
