@@ -845,7 +845,8 @@ def test_every_builtin_wisdom_plan_runs_its_call_within_the_gates(gpu):
     names a plan this build can make), and its output -- all transforms of the batch, every bin, compared on the device --
     must agree with the static rule's plan of a planner made without the wisdom (parity-tested against the oracle throughout
     tests/test_gpu_parity*.py) within the sum of the two gates; up to 2^20 points the first and the last transform also
-    against numpy in float64.  C2R inputs are half-spectra of real signals (made by r2c), so the round trip must return them."""
+    against numpy in float64.  C2C calls also run in reverse through the tuned plan (the round trip returns the input); C2R inputs are
+    half-spectra of real signals (made by r2c), so the round trip must return them."""
     import re
 
     import torch
@@ -907,6 +908,16 @@ def test_every_builtin_wisdom_plan_runs_its_call_within_the_gates(gpu):
                         (P.fft_64_interleaved_with_planner if dt == "f64" else P.fft_32_interleaved_with_planner)(z, P.Direction.Forward, pl)
                         outs.append(torch.stack((z.real, z.imag)))
                 close(tag, dt, L, outs[1].flatten(), outs[0].flatten(), n)
+                # ... and back through the same plan (swap trick, 1/N in the last pass's store -- whatever tile that is)
+                if kind == "c2c":
+                    a, b = outs[1][0].clone(), outs[1][1].clone()
+                    P.fft_dit_batched(a, b, n, P.Direction.Reverse, tuned)
+                    back = torch.stack((a, b))
+                else:
+                    z = torch.complex(outs[1][0], outs[1][1])
+                    (P.fft_64_interleaved_with_planner if dt == "f64" else P.fft_32_interleaved_with_planner)(z, P.Direction.Reverse, tuned)
+                    back = torch.stack((z.real, z.imag))
+                close(tag + " round trip", dt, L, back.flatten(), torch.stack((re0, im0)).flatten(), n, factor=3.0)
                 if L <= 20:
                     for b in sorted({0, batch - 1}):
                         sl = slice(b * n, (b + 1) * n)
