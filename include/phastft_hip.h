@@ -67,7 +67,7 @@ extern "C" {
 #define PHAST_ERR_C2R_IN_IM_LEN 10  /* algorithms/r2c.rs:756-760,852-856 */
 #define PHAST_ERR_C2R_SCRATCH_RE 11 /* algorithms/r2c.rs:761,857 */
 #define PHAST_ERR_C2R_SCRATCH_IM 12 /* algorithms/r2c.rs:762,858 */
-#define PHAST_ERR_ALLOC 13          /* host allocation failed */
+#define PHAST_ERR_ALLOC 13          /* host allocation failed (incl. std::bad_alloc inside the library) */
 #define PHAST_ERR_HIP 14            /* a HIP runtime call failed; see phast_last_hip_error() */
 #define PHAST_ERR_NO_DEVICE 15      /* no gfx950 device visible: the library never falls back to CPU */
 #define PHAST_ERR_INVALID_ARG 16    /* null pointer / bad direction / bit-reversal length != 2^n (bravo.rs:228) */
@@ -351,6 +351,11 @@ void phast_debug_set_wg_per_cu(int wg_per_cu);
 void phast_debug_set_guard_bytes(size_t bytes);
 int phast_planner_dit64_debug_check_guards(const phast_planner_dit64 *p, size_t *bad_bytes);
 int phast_planner_dit32_debug_check_guards(const phast_planner_dit32 *p, size_t *bad_bytes);
+
+/* No C++ exception leaves the library (every entry point is a function-try-block, csrc/c_abi.hip): host memory exhaustion
+ * comes back as PHAST_ERR_ALLOC, any other exception as PHAST_ERR_HIP with its text in phast_last_hip_error().  Test hook:
+ * throws std::bad_alloc (1), std::runtime_error (2) or an int (3) INSIDE the library and returns what the caller would see. */
+int phast_debug_throw(int what);
 
 /* debug hook: device buffer of [3 passes][4096 workgroups][16] s_memtime stamps written by the tile kernels while
  * set (NULL = off; adds drains, so never leave it on while measuring).  tools/trace_tile.py decodes it. */

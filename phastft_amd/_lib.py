@@ -42,7 +42,7 @@ phast_twiddle_grid64_apply_dev phast_twiddle_grid32_apply_dev
 phast_planner_dit64_release_graph_workspaces phast_planner_dit32_release_graph_workspaces
 phast_planner_dit64_tune phast_planner_dit32_tune phast_planner_r2c64_tune phast_planner_r2c32_tune
 phast_planner_r2c64_with_mode phast_planner_r2c32_with_mode
-phast_wisdom_export phast_wisdom_import phast_wisdom_forget phast_wisdom_builtin phast_wisdom_count
+phast_wisdom_export phast_wisdom_import phast_wisdom_forget phast_wisdom_builtin phast_wisdom_count phast_debug_throw
 phast_planner_dit64_describe_call phast_planner_dit32_describe_call phast_planner_r2c64_describe_call phast_planner_r2c32_describe_call
 """.split()
 

@@ -16,6 +16,7 @@
 #include <mutex>
 #include <shared_mutex>
 #include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 

@@ -211,3 +211,26 @@ def test_wisdom_import_survives_arbitrary_text():
     finally:
         P.wisdom_forget()
         P.wisdom_builtin(True)
+
+
+def test_no_cxx_exception_crosses_the_c_abi():
+    """Callers are C, Rust (unwinding across `extern "C"` is undefined there) and ctypes: every entry point of csrc/c_abi.hip is a
+    function-try-block.  The debug hook throws inside the library: std::bad_alloc comes back as PHAST_ERR_ALLOC (13), any
+    other exception as PHAST_ERR_HIP (14) with its text in phast_last_hip_error() -- and the source has no entry point left
+    without the barrier."""
+    import re
+
+    from phastft_amd import _lib
+
+    l = _lib.lib()
+    l.phast_debug_throw.restype = C.c_int
+    l.phast_last_hip_error.restype = C.c_char_p
+    assert l.phast_debug_throw(0) == 0
+    assert l.phast_debug_throw(1) == 13
+    assert l.phast_debug_throw(2) == 14 and b"phast_debug_throw" in l.phast_last_hip_error()
+    assert l.phast_debug_throw(3) == 14 and b"unknown C++ exception" in l.phast_last_hip_error()
+    src = open(os.path.join(ROOT, "phastft_amd", "csrc", "c_abi.hip")).read()
+    body = src[src.index('extern "C" {'):]
+    defs = re.findall(r"^\s*(?:int|size_t|void) (phast_[\w#]+)\([^;{]*?\)\s*(try\s*)?\{", body, re.M)
+    assert len(defs) >= 55, len(defs)
+    assert [name for name, tr in defs if not tr] == [], "entry points without the exception barrier"
