@@ -155,7 +155,8 @@ template <typename T> struct Planner {
     // plans are read by every call and replaced by set_plan (a tuning hook): shared for the enqueue, exclusive to swap
     mutable std::shared_mutex plan_mu;
     // Plans a tuning run measured (tune.hpp) or wisdom supplied (wisdom.hpp), per call kind and batch bucket: looked up before
-    // the static rules (choose).  Entries are added under the exclusive hold of plan_mu and never move or go.
+    // the static rules (choose).  Entries are added, replaced and removed under the EXCLUSIVE hold of plan_mu only (a Choice that
+    // points into one lives inside a call's shared hold); kernels in flight or captured hold their arguments by value.
     struct TunedPlan {
         int kind = kC2C;
         unsigned bucket = 0;
