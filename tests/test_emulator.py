@@ -591,3 +591,27 @@ def test_builtin_wisdom_plans_thread_by_thread_vs_numpy(emu):
     finally:
         emu.phast_emu_set_plan(None)
     assert min(ran["c2c"], ran["r2c"], ran["c2r"]) >= 10 and ran["r2c_fused"] >= 3 and ran["c2r_fused"] >= 3, ran
+
+
+def test_every_builtin_wisdom_line_is_a_candidate_of_its_tuning_run(emu):
+    """csrc/builtin_wisdom.inc against csrc/plan.hpp, without a GPU: every line (all 425, every batch bucket) must name a plan the
+    tuner would enumerate for that type, length and batch TODAY -- a plan that exists as kernels and fits the LDS.  On the
+    GPU a line that no longer builds is skipped silently when a planner applies the wisdom (its speed-up is lost, nothing
+    fails); here a tile shape removed from plan.hpp, or a wisdom file regenerated by another build, shows up as a failure."""
+    import os
+    import re
+
+    emu.phast_emu_enumerate_plans.argtypes = [C.c_uint, C.c_size_t, C.c_size_t, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    emu.phast_emu_enumerate_plans.restype = C.c_int
+    path = os.path.join(os.path.dirname(__file__), "..", "phastft_amd", "csrc", "builtin_wisdom.inc")
+    has, bad = C.c_int(), C.c_int()
+    lines = 0
+    for m in re.finditer(r'^"(f64|f32) (c2c|c2ci|r2c|c2r) (\d+) (\d+) (\S+) fuse=([01])', open(path).read(), re.M):
+        ty, kind, L, bucket, plan = m.group(1), m.group(2), int(m.group(3)), int(m.group(4)), m.group(5)
+        if plan == "heuristic":
+            continue
+        inner = L - 1 if kind in ("r2c", "c2r") else L   # the real transforms' plans are the inner N/2-point transform's
+        cnt = emu.phast_emu_enumerate_plans(inner, 8 if ty == "f64" else 4, 1 << bucket, plan.encode(), C.byref(has), C.byref(bad))
+        assert cnt > 0 and bad.value == 0 and has.value == 1, (m.group(0), cnt, bad.value)
+        lines += 1
+    assert lines >= 300, lines
