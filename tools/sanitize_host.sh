@@ -5,6 +5,7 @@
 # half is the guard-band test tests/test_gpu_sanitize.py).  Build here (no GPU needed), run on the GPU box:
 #     tools/sanitize_host.sh build            # -> phastft_amd/lib/libphastft_hip_asan.so + tests/cpp/host_api_test_asan
 #     tools/sanitize_host.sh run > log        # on the GPU box
+#     tools/sanitize_host.sh build-tsan / run-tsan   # round 5: ThreadSanitizer over the same host code
 set -u
 R=$(cd "$(dirname "$0")/.." && pwd)
 LIB=$R/phastft_amd/lib/libphastft_hip_asan.so
@@ -39,6 +40,35 @@ PY
         -I "$R/include" -I "$R/tests/cpp" "$R/tests/cpp/planner_stress_test.cpp" -o "$EXE3" "$LIB" -L /opt/rocm/lib -lamdhip64 \
         -Wl,-rpath,"$R/phastft_amd/lib" -Wl,-rpath,/opt/rocm/lib -Wl,-rpath,"$RT" || exit 1
     echo "$EXE3"
+    ;;
+build-tsan)
+    # Round 5: the same host code under ThreadSanitizer ("TSan would flag them" -- the workspace fields read outside
+    # their holder).  Only c_abi.hip holds host logic (the other units are kernels and their launch wrappers): it is built
+    # -fsanitize=thread (host side; the option is ignored for amdgcn) and linked with the other units' ordinary objects.
+    python3 - <<PY || exit 1
+import os, subprocess, sys
+sys.path.insert(0, "$R")
+from phastft_amd import build as B
+B.build()
+obj = B._compile("c_abi", False, False, ("-fsanitize=thread", "-g", "-fno-omit-frame-pointer"), "_tsan")
+objs = [obj if u == "c_abi" else os.path.join(B.OBJ, u + ".o") for u in B.UNITS]
+r = subprocess.run([B.hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fsanitize=thread", "-shared-libsan", "-o",
+                    "$R/phastft_amd/lib/libphastft_hip_tsan.so", *objs], capture_output=True, text=True)
+assert r.returncode == 0, r.stderr
+PY
+    RT=$(dirname "$($CLANG -print-file-name=libclang_rt.tsan-x86_64.so)")
+    for t in concurrent_planner_test planner_stress_test; do
+        $CLANG -std=c++17 -O1 -g -pthread -fsanitize=thread -shared-libsan -fno-omit-frame-pointer -D__HIP_PLATFORM_AMD__ -I /opt/rocm/include \
+            -I "$R/include" -I "$R/tests/cpp" "$R/tests/cpp/$t.cpp" -o "$R/tests/cpp/${t}_tsan" "$R/phastft_amd/lib/libphastft_hip_tsan.so" \
+            -L /opt/rocm/lib -lamdhip64 -Wl,-rpath,"$R/phastft_amd/lib" -Wl,-rpath,/opt/rocm/lib -Wl,-rpath,"$RT" || exit 1
+        echo "$R/tests/cpp/${t}_tsan"
+    done
+    ;;
+run-tsan)
+    export TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 second_deadlock_stack=1 suppressions=$R/tools/tsan.supp exitcode=0"
+    for t in concurrent_planner_test planner_stress_test; do
+        echo "# $(date -u) TSan: tests/cpp/${t}_tsan"; timeout 50 "$R/tests/cpp/${t}_tsan"; echo "# exit code $?"
+    done
     ;;
 run)
     # Two passes, each under its own timeout.  The planner cache of the planner-less entry points (host_api.hpp: PlannerCache)
