@@ -57,7 +57,7 @@ r = subprocess.run([B.hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-fs
 assert r.returncode == 0, r.stderr
 PY
     RT=$(dirname "$($CLANG -print-file-name=libclang_rt.tsan-x86_64.so)")
-    for t in concurrent_planner_test planner_stress_test; do
+    for t in concurrent_planner_test planner_stress_test tune_beside_callers_test; do
         $CLANG -std=c++17 -O1 -g -pthread -fsanitize=thread -shared-libsan -fno-omit-frame-pointer -D__HIP_PLATFORM_AMD__ -I /opt/rocm/include \
             -I "$R/include" -I "$R/tests/cpp" "$R/tests/cpp/$t.cpp" -o "$R/tests/cpp/${t}_tsan" "$R/phastft_amd/lib/libphastft_hip_tsan.so" \
             -L /opt/rocm/lib -lamdhip64 -Wl,-rpath,"$R/phastft_amd/lib" -Wl,-rpath,/opt/rocm/lib -Wl,-rpath,"$RT" || exit 1
@@ -66,7 +66,9 @@ PY
     ;;
 run-tsan)
     export TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 second_deadlock_stack=1 suppressions=$R/tools/tsan.supp exitcode=0"
-    for t in concurrent_planner_test planner_stress_test; do
+    echo "# $(date -u) TSan positive control (a real race inside the test program, no GPU needed): PHAST_TSAN_CONTROL=1 tests/cpp/tune_beside_callers_test_tsan"
+    PHAST_TSAN_CONTROL=1 "$R/tests/cpp/tune_beside_callers_test_tsan" 2>&1 | grep -E "WARNING|SUMMARY|control"
+    for t in concurrent_planner_test planner_stress_test tune_beside_callers_test; do
         echo "# $(date -u) TSan: tests/cpp/${t}_tsan"; timeout 50 "$R/tests/cpp/${t}_tsan"; echo "# exit code $?"
     done
     ;;
