@@ -40,6 +40,10 @@ PY
         -I "$R/include" -I "$R/tests/cpp" "$R/tests/cpp/planner_stress_test.cpp" -o "$EXE3" "$LIB" -L /opt/rocm/lib -lamdhip64 \
         -Wl,-rpath,"$R/phastft_amd/lib" -Wl,-rpath,/opt/rocm/lib -Wl,-rpath,"$RT" || exit 1
     echo "$EXE3"
+    $CLANG -std=c++17 -O1 -g -pthread -fsanitize=address -shared-libsan -fno-omit-frame-pointer -D__HIP_PLATFORM_AMD__ -I /opt/rocm/include \
+        -I "$R/include" -I "$R/tests/cpp" "$R/tests/cpp/tune_beside_callers_test.cpp" -o "$R/tests/cpp/tune_beside_callers_test_asan" "$LIB" \
+        -L /opt/rocm/lib -lamdhip64 -Wl,-rpath,"$R/phastft_amd/lib" -Wl,-rpath,/opt/rocm/lib -Wl,-rpath,"$RT" || exit 1
+    echo "$R/tests/cpp/tune_beside_callers_test_asan"
     ;;
 build-tsan)
     # Round 5: the same host code under ThreadSanitizer ("TSan would flag them" -- the workspace fields read outside
@@ -89,6 +93,9 @@ run)
     echo "# exit code $?"
     echo "# $(date -u) host-side ASan pass 4 (stress: 8 threads, 3 planners, streams destroyed in between; leak check on): $EXE3"
     ASAN_OPTIONS=detect_leaks=1:halt_on_error=0:abort_on_error=0 timeout 600 "$EXE3"
+    echo "# exit code $?"
+    echo "# $(date -u) host-side ASan pass 6 (round 5: a tuning run and a Tune-mode planner beside three calling threads; leak check on)"
+    ASAN_OPTIONS=detect_leaks=1:halt_on_error=0:abort_on_error=0 timeout 120 "$R/tests/cpp/tune_beside_callers_test_asan"
     echo "# exit code $?"
     echo "# $(date -u) host-side ASan pass 5 (the same with PHAST_MAX_WORKSPACES=2)"
     ASAN_OPTIONS=detect_leaks=1:halt_on_error=0:abort_on_error=0 PHAST_MAX_WORKSPACES=2 timeout 600 "$EXE3"
