@@ -764,6 +764,33 @@ def test_tuning_while_other_threads_transform_with_the_planner(gpu, static_rules
     P.wisdom_forget()
 
 
+def test_cpp_tuning_beside_callers_program(gpu, tmp_path):
+    """tests/cpp/tune_beside_callers_test.cpp -- the interleaving of the test above as a C++ program over the C ABI (it is what
+    runs under ThreadSanitizer / AddressSanitizer, tools/sanitize_host.sh): a tuning run, a second bucket and a PHAST_MODE_TUNE
+    planner beside three calling threads; every call succeeds and every transform keeps Parseval whichever plan ran it."""
+    import json
+
+    from phastft_amd import build
+
+    lib = build.build()
+    libdir = os.path.dirname(lib)
+    exe = str(tmp_path / "tune_beside_callers_test")
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-pthread", "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include",
+           "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "tests", "cpp"),
+           os.path.join(ROOT, "tests", "cpp", "tune_beside_callers_test.cpp"), "-o", exe,
+           "-L", libdir, "-lphastft_hip", "-L", "/opt/rocm/lib", "-lamdhip64", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    env = {k: v for k, v in os.environ.items() if not k.startswith("PHAST_")}
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    print(res)
+    assert res["bad_transforms"] == 0 and min(res["calls"]) >= 13 and res["tune"]["candidates"] >= 8, res
+    if res["tune"]["adopted"]:
+        assert res["call_now"].startswith("tuned "), res
+
+
 def test_a_graph_captured_before_a_tuning_run_keeps_replaying_its_plan(gpu, static_rules):
     """A captured call holds its kernels' arguments by value -- table pointers (the planner's table cache: released with the
     planner, never with a plan) and the scratch of the workspace that went to the graph.  A tuning run afterwards widens the
