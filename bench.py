@@ -187,7 +187,7 @@ def kernel_tags(plan_list: str, dtype: str = "double"):
     return tags
 
 
-def roofline_of(pass_ms, alg_bytes, names=None, plan_used="", traffic_key=None, tags=None):
+def roofline_of(pass_ms, alg_bytes, names=None, plan_used="", traffic_key=None, tags=None, step_ms=None):
     dom = max(range(len(pass_ms)), key=lambda i: pass_ms[i])
     achieved = alg_bytes / (pass_ms[dom] * 1e-3) / 1e9
     total_ms = sum(pass_ms)
@@ -195,13 +195,51 @@ def roofline_of(pass_ms, alg_bytes, names=None, plan_used="", traffic_key=None, 
     return {
         # `frac` (the contract's key) = `frac_dominant_pass`: the dominant KERNEL's algorithmic bytes per launch / its duration /
         # peak.  `frac_transform` is SURVEY.md 8(d)'s number: the TRANSFORM's compulsory bytes (every element read once, written
-        # once) / the sum of its kernels' durations / peak -- capped at 1/passes by construction.
+        # once) / the measured time of one step (`ms_per_step`, the K-step region) / peak -- capped at 1/passes by construction.
+        # `frac_transform_pass_sum` divides by the sum of the separately timed passes instead (what rounds 1-5 printed as
+        # frac_transform: it leaves out the gaps between the kernels and read 3-6 % high).
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
         "frac_dominant_pass": achieved / HBM_PEAK_GBS,
-        "frac_transform": alg_bytes / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "passes": len(pass_ms),
+        "frac_transform": alg_bytes / ((step_ms if step_ms else total_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "frac_transform_pass_sum": alg_bytes / (total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "passes": len(pass_ms),
         "traffic": None, "kernel": label + (f" ({plan_used})" if plan_used else ""),
         "kernel_ms": pass_ms[dom], "pass_ms": pass_ms, "algorithmic_bytes_per_launch": alg_bytes,
     }, dom
+
+
+def replay_stats(torch, run, steps: int, first_ms: float, refill=None, extra: int = 2):
+    """"median and min".  `first_ms` is the contract's timed region (EXACTLY K steps, once); `extra` more
+    K-step regions are timed after it (ring re-filled before each when the steps work in place) -> per-step min / median
+    over the 1 + extra regions."""
+    per = [first_ms / steps]
+    for _ in range(extra):
+        if refill is not None:
+            refill()
+        torch.cuda.synchronize()
+        per.append(event_ms(torch, run) / steps)
+    per.sort()
+    return {"ms_per_step_min": per[0], "ms_per_step_median": per[len(per) // 2], "timed_regions": len(per)}
+
+
+def static_rule_ms(P, torch, used: str, make_planner, make_step, steps: int):
+    """where the library ran a `tuned` plan (built-in wisdom, measured on another box), the static rule's
+    plan timed beside it in this run -- the same K steps from a HIP graph on the same ring.  None when the static rule ran."""
+    if used != "tuned":
+        return None
+    was = P.wisdom_builtin(False)
+    try:
+        q = make_planner()
+    finally:
+        P.wisdom_builtin(was)
+    step = make_step(q)
+    for i in range(3):
+        step(i)
+    torch.cuda.synchronize()
+    graph, _ = capture_steps(torch, P, step, 3, steps, touch=lambda: step(0))
+    run = graph.replay if graph is not None else (lambda: [step(3 + i) for i in range(steps)])
+    per = sorted(event_ms(torch, run) / steps for _ in range(3))
+    del graph, q
+    return per[1]
 
 
 def attach_traffic(roof, key, tag, scale=1.0):
@@ -310,7 +348,9 @@ def config_f32(P, torch, dev, log_n: int, steps: int, cpu: bool):
     graph, launch = capture_steps(torch, P, step, 3, steps, touch=lambda: step(0))
     P.fill_uniform(re, im, n, seed=0xCAFE, first_id=0)
     torch.cuda.synchronize()
-    ms = event_ms(torch, graph.replay if graph is not None else (lambda: [step(3 + i) for i in range(steps)])) / steps
+    run = graph.replay if graph is not None else (lambda: [step(3 + i) for i in range(steps)])
+    ms = event_ms(torch, run) / steps
+    stats = replay_stats(torch, run, steps, ms * steps, refill=lambda: P.fill_uniform(re, im, n, seed=0xCAFE, first_id=0))
     P.fill_uniform(re, im, n, seed=0xCAFE, first_id=0)
     torch.cuda.synchronize()
     acc, reps = None, min(ring, 16)
@@ -319,12 +359,16 @@ def config_f32(P, torch, dev, log_n: int, steps: int, cpu: bool):
         acc = t if acc is None else [a + b for a, b in zip(acc, t)]
     pass_ms = [a / reps for a in acc]
     used, plan_list = plan_used(pl, 1)
-    roof, dom = roofline_of(pass_ms, 16 * n, plan_used=f"{used} plan {plan_list}")
+    roof, dom = roofline_of(pass_ms, 16 * n, plan_used=f"{used} plan {plan_list}", step_ms=ms)
     tags = kernel_tags(plan_list, "float")
     attach_traffic(roof, f"f32_2p{log_n}", tags[dom] if dom < len(tags) else None)
     out = {"workload": f"single f32 forward FFT N=2^{log_n}, in place, planar (fft_32_dit_with_planner)",
-           "value": n / (ms * 1e-3) / 1e9, "unit": "GSamples/s", "steps": steps, "ms_per_step": ms, "dtype": "f32",
-           "plan": plan_text, "launch": launch, "roofline": roof}
+           "value": n / (ms * 1e-3) / 1e9, "unit": "GSamples/s", "steps": steps, "ms_per_step": ms, **stats, "dtype": "f32",
+           "plan": plan_text, "plan_ran": f"{used} {plan_list}", "launch": launch, "roofline": roof}
+    static_ms = static_rule_ms(P, torch, used, lambda: P.PlannerDit32(n), lambda q: (lambda i: P.fft_32_dit_with_planner(
+        views[i % ring][0], views[i % ring][1], P.Direction.Forward, q)), steps)
+    if static_ms is not None:
+        out["static_ms"] = static_ms
     del re, im, views, pl, graph
     torch.cuda.empty_cache()
     if cpu:
@@ -358,15 +402,17 @@ def config_n2p26(P, torch, dev, steps: int, cpu: bool):
             P.fft_64_dit_with_planner(ring_re[i * n:(i + 1) * n], ring_im[i * n:(i + 1) * n], P.Direction.Forward, pl)
 
     ms = event_ms(torch, forward_all) / steps
+    stats = replay_stats(torch, forward_all, steps, ms * steps,
+                         refill=lambda: P.fill_uniform(ring_re, ring_im, n, seed=0xCAFE, first_id=0))
     P.fill_uniform(re, im, n, seed=0xCAFE)
     pass_ms = pl.time_passes(re, im, n, reps=3)
     used, plan_list = plan_used(pl, 1)
-    roof, dom = roofline_of(pass_ms, BYTES_PER_SAMPLE * n, plan_used=f"{used} plan {plan_list}")
+    roof, dom = roofline_of(pass_ms, BYTES_PER_SAMPLE * n, plan_used=f"{used} plan {plan_list}", step_ms=ms)
     tags = kernel_tags(plan_list)
     attach_traffic(roof, "single_2p26", tags[dom] if dom < len(tags) else None)
     fwd = {"workload": "single f64 forward FFT N=2^26, in place, planar (BASELINE metric, second size)",
-           "value": n / (ms * 1e-3) / 1e9, "unit": "GSamples/s", "steps": steps, "ms_per_step": ms, "dtype": "f64",
-           "plan": plan_text, "roofline": roof}
+           "value": n / (ms * 1e-3) / 1e9, "unit": "GSamples/s", "steps": steps, "ms_per_step": ms, **stats, "dtype": "f64",
+           "plan": plan_text, "plan_ran": f"{used} {plan_list}", "roofline": roof}
     # configs[2]: forward then inverse on the same buffers; the error against the regenerated input is part of it
     P.fill_uniform(ring_re, ring_im, n, seed=0xBEEF, first_id=0)
     torch.cuda.synchronize()
@@ -429,7 +475,9 @@ def config_r2c(P, torch, dev, steps: int, cpu: bool):
     # the headline's protocol: the K steps captured into one HIP graph and replayed inside the timed region (HIP events on
     # the launch stream) -- the Python + ctypes launch path is not the product
     graph, launch = capture_steps(torch, P, step, 0, steps, touch=lambda: step(0))
-    ms = event_ms(torch, graph.replay if graph is not None else (lambda: [step(i) for i in range(steps)])) / steps
+    run = graph.replay if graph is not None else (lambda: [step(i) for i in range(steps)])
+    ms = event_ms(torch, run) / steps
+    stats = replay_stats(torch, run, steps, ms * steps)
     acc = None
     for i in range(ring):
         t = pl.time_passes(*sets[i], reps=1)
@@ -438,6 +486,7 @@ def config_r2c(P, torch, dev, steps: int, cpu: bool):
     r2c_bytes = 4 * n + 8 * (n // 2 + 1)
     plan_text = pl.describe()
     used, r2c_list = plan_used(pl, 1, 2)
+    r2c_ran = f"{used} {r2c_list}"
     r2c_list = r2c_list.replace(" untangle-fused", "")
     n_inner = len(kernel_tags(r2c_list, "float"))
     fused = len(pass_ms) == n_inner  # round 3: the last pass takes the untangle with it (r2c_fused.hpp): no sweep of its own
@@ -454,11 +503,15 @@ def config_r2c(P, torch, dev, steps: int, cpu: bool):
     roof = {"bound": "hbm", "achieved": k_bytes[dom] / (pass_ms[dom] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": fr[dom], "traffic": None, "kernel": names[dom], "kernel_ms": pass_ms[dom], "pass_ms": pass_ms,
             "algorithmic_bytes_per_launch": k_bytes[dom], "algorithmic_bytes_per_transform": r2c_bytes,
-            "frac_dominant_pass": fr[dom], "frac_transform": r2c_bytes / (sum(pass_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "passes": len(pass_ms)}
+            "frac_dominant_pass": fr[dom], "frac_transform": r2c_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "frac_transform_pass_sum": r2c_bytes / (sum(pass_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, "passes": len(pass_ms)}
     out = {"workload": "r2c_fft_f32 N=2^24, real input -> N/2+1 planar outputs (BASELINE configs[3])",
-           "value": n / (ms * 1e-3) / 1e9, "unit": "GSamples/s (real samples)", "steps": steps, "ms_per_step": ms,
-           "dtype": "f32", "plan": plan_text, "launch": launch, "roofline": roof}
+           "value": n / (ms * 1e-3) / 1e9, "unit": "GSamples/s (real samples)", "steps": steps, "ms_per_step": ms, **stats,
+           "dtype": "f32", "plan": plan_text, "plan_ran": r2c_ran, "launch": launch, "roofline": roof}
+    static_ms = static_rule_ms(P, torch, used, lambda: P.PlannerR2c32(n),
+                               lambda q: (lambda i: P.r2c_fft_f32_with_planner(*sets[i % ring], q)), steps)
+    if static_ms is not None:
+        out["static_ms"] = static_ms
     tags = kernel_tags(r2c_list, "float")
     if fused:
         tags[-1] = tags[-1].replace("tile_fft_kernel", "r2c_last_pass_kernel").split(", true, false")[0]
@@ -491,7 +544,9 @@ def config_c2r(P, torch, dev, steps: int, cpu: bool):
         step(i)
     torch.cuda.synchronize()
     graph, launch = capture_steps(torch, P, step, 0, steps, touch=lambda: step(0))   # the headline's protocol (config_r2c)
-    ms = event_ms(torch, graph.replay if graph is not None else (lambda: [step(i) for i in range(steps)])) / steps
+    run = graph.replay if graph is not None else (lambda: [step(i) for i in range(steps)])
+    ms = event_ms(torch, run) / steps
+    stats = replay_stats(torch, run, steps, ms * steps)
     acc = None
     for i in range(ring):
         t = pl.time_c2r_passes(*sets[i], reps=1)
@@ -499,6 +554,7 @@ def config_c2r(P, torch, dev, steps: int, cpu: bool):
     pass_ms = [a / ring for a in acc]
     c2r_bytes = 4 * n + 8 * half1
     used, c2r_list = plan_used(pl, 1, 3)
+    c2r_ran = f"{used} {c2r_list}"
     fused = " preprocess-fused" in c2r_list
     c2r_list = c2r_list.replace(" preprocess-fused", "")
     tags = kernel_tags(c2r_list, "float")
@@ -516,13 +572,18 @@ def config_c2r(P, torch, dev, steps: int, cpu: bool):
     dom = max(range(len(pass_ms)), key=lambda i: pass_ms[i])
     roof = {"bound": "hbm", "achieved": k_bytes[dom] / (pass_ms[dom] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": fr[dom], "frac_dominant_pass": fr[dom],
-            "frac_transform": c2r_bytes / (sum(pass_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, "passes": len(pass_ms), "traffic": None,
+            "frac_transform": c2r_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "frac_transform_pass_sum": c2r_bytes / (sum(pass_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, "passes": len(pass_ms), "traffic": None,
             "kernel": names[dom], "kernel_ms": pass_ms[dom], "pass_ms": pass_ms, "algorithmic_bytes_per_launch": k_bytes[dom],
             "algorithmic_bytes_per_transform": c2r_bytes}
     attach_traffic(roof, "c2r_f32_2p24", tags[dom] if dom < len(tags) else "c2r_preprocess_kernel")
     out = {"workload": "c2r_fft_f32 N=2^24, N/2+1 planar inputs -> real output (inverse of BASELINE configs[3])",
-           "value": n / (ms * 1e-3) / 1e9, "unit": "GSamples/s (real samples)", "steps": steps, "ms_per_step": ms, "dtype": "f32",
-           "plan": pl.describe(), "launch": launch, "roofline": roof}
+           "value": n / (ms * 1e-3) / 1e9, "unit": "GSamples/s (real samples)", "steps": steps, "ms_per_step": ms, **stats, "dtype": "f32",
+           "plan": pl.describe(), "plan_ran": c2r_ran, "launch": launch, "roofline": roof}
+    static_ms = static_rule_ms(P, torch, used, lambda: P.PlannerR2c32(n),
+                               lambda q: (lambda i: P.c2r_fft_f32_with_planner(*sets[i % ring], q)), steps)
+    if static_ms is not None:
+        out["static_ms"] = static_ms
     del sets, ires, iims, ys, pl, graph
     torch.cuda.empty_cache()
     if cpu:
@@ -556,13 +617,28 @@ def shard_on_one_gpu(P, torch, dev, shard: int, steps: int = 5):
     P.fill_uniform(re, im, N, seed=0xCAFE, first_id=0)
     pass_ms = pl.time_passes(re, im, N, reps=2)
     used, plan_list = plan_used(pl, shard)
-    roof, dom = roofline_of(pass_ms, BYTES_PER_SAMPLE * N * shard, plan_used=f"{used} plan {plan_list}")
+    roof, dom = roofline_of(pass_ms, BYTES_PER_SAMPLE * N * shard, plan_used=f"{used} plan {plan_list}", step_ms=ms)
     tags = kernel_tags(plan_list)
     if attach_traffic(roof, "batch_2p20", tags[dom] if dom < len(tags) else None, scale=shard / 1024.0):  # profiled per 1024-transform launch
         roof["traffic_note"] = "PMC bytes of one 1024-transform launch of the same kernel (scaled to the shard if it differs)"
     return {"workload": f"{shard} independent f64 forward FFTs N=2^{LOG_N} on 1 GPU, in place (one rank's shard of "
                         f"BASELINE configs[4])", "value": shard * N / (ms * 1e-3) / 1e9, "unit": "GSamples/s",
-            "steps": steps, "ms_per_step": ms, "roofline": roof}
+            "steps": steps, "ms_per_step": ms, "plan_ran": f"{used} {plan_list}", "roofline": roof}
+
+
+def shard_cpu_leg(shard: int, transforms: int = 8):
+    """the CPU leg of configs[4] is `transforms` (8) transforms of 2^20 timed on this host and
+    extrapolated x shard / transforms -- the transforms are independent and the reference runs them one after the other on one
+    thread (default features), so the extrapolation is exact up to cache warmth."""
+    from oracle import oracle as O
+
+    O.time_fft_64_dit(N, 1)
+    total = O.time_fft_64_dit(N, transforms)
+    return {"value": transforms * N / total / 1e9, "unit": "GSamples/s", "cores": 1, "kind": "port",
+            "sample": f"{transforms} forward transforms at N=2^{LOG_N} timed ({total:.2f} s of CPU work), x {shard // transforms} "
+                      f"extrapolated to the {shard}-transform shard = {total * shard / transforms:.1f} s per step on one core; oracle/ C "
+                      f"restatement built {O.timing_build()}, 1 thread, planner outside the timer",
+            "shard_seconds_extrapolated": total * shard / transforms}
 
 
 def check_shard(P, torch, re, im, refill, step, first: int, shard: int, samples: int = 8):
@@ -852,6 +928,10 @@ def main():
         torch.cuda.synchronize()
         elapsed_wall = time.perf_counter() - t0
         elapsed = ev0.elapsed_time(ev1) * 1e-3
+        # SURVEY.md 8(d) "median and min": two more K-step regions after the contract's one (ring re-filled before each: the
+        # steps work in place), reported beside ms_per_step, never instead of it
+        head_stats = replay_stats(torch, graph.replay if graph is not None else (lambda: [step(warmup + i) for i in range(steps)]),
+                                  steps, 1e3 * elapsed, refill=lambda: P.fill_uniform(re, im, N, seed=0xCAFE, first_id=0))
         samples_per_step = N
         workload = f"single f64 forward FFT N=2^{LOG_N}, in place, planar (BASELINE configs[1])"
         # --- roofline of the dominant pass kernel, HIP events bound to the dispatches (fresh buffers) ---
@@ -876,7 +956,7 @@ def main():
         warmup = args.warmup if args.warmup is not None else 2
         import torch.distributed as dist
 
-        from phastft_amd.sharding import ShardedBatch, max_over_ranks
+        from phastft_amd.sharding import ShardedBatch, fabric_info, max_over_ranks, times_over_ranks
 
         total = args.shard * world
         first, shard = rank * args.shard, args.shard
@@ -909,7 +989,9 @@ def main():
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
-        elapsed = max_over_ranks(time.perf_counter() - t0, dist, dev)
+        mine = time.perf_counter() - t0
+        elapsed = max_over_ranks(mine, dist, dev)
+        rank_s = times_over_ranks(mine, dist, dev)   # every rank's own time: what makes a bad N-GPU point readable
         elapsed_wall = elapsed
         # after the timed region: every rank checks its shard (Parseval on all, sampled ids against the oracle), then
         # the trivial gather (RCCL over xGMI): one 32-byte digest per transform -> (total, 4) on every rank
@@ -935,7 +1017,7 @@ def main():
         if args.plan:
             used = "forced"
         alg_bytes = BYTES_PER_SAMPLE * N * units            # what ONE launch of a pass must read + write
-        roofline, dom = roofline_of(pass_ms, alg_bytes, plan_used=f"{used} plan {plan_list}")
+        roofline, dom = roofline_of(pass_ms, alg_bytes, plan_used=f"{used} plan {plan_list}", step_ms=ms_per_step)
         achieved = roofline["achieved"]
         out = {
             "metric": "GSamples/s f64 forward FFT N=2^20" + (" (N=2^26, round trip, R2C: see configs)" if not multi else ""),
@@ -947,17 +1029,33 @@ def main():
                        "wall clock between barrier + synchronize on both sides, MAX over ranks"),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic (counter-based uniform [-1,1), seed 0xCAFE, generated on device)",
+            # the driver's record keeps the SCALAR keys of `config` (strings cut at 120 characters): `plan` is the plan that
+            # ran, every table the planner holds is under top-level "plan_tables"
             "config": {"workload": workload, "n": N, "transforms_per_step": samples_per_step // N,
-                       "plan": plan_text, "plan_used": used, "launch": launch},
+                       "plan": f"{used} {plan_list}"[:110], "plan_used": used, "launch": launch[:110]},
+            "plan_tables": plan_text,
             "roofline": roofline,
         }
+        if not multi:
+            out.update(head_stats)
         if not multi and check_info is not None:
-            out["config"]["result_check"] = check_info
+            out["result_check"] = check_info
         if multi:
             out["config"]["digest_gather"] = f"all_gather of {samples_per_step // N} x 32 B digests over RCCL"
             out["config"]["digest_ok"] = digest_ok
-            out["config"]["digest_check"] = dict(check_info, what="every rank: Parseval on all transforms of its shard + "
-                                                 "sampled transforms vs digests of the CPU oracle's output; rank 0's numbers")
+            out["digest_check"] = dict(check_info, what="every rank: Parseval on all transforms of its shard + "
+                                       "sampled transforms vs digests of the CPU oracle's output; rank 0's numbers")
+            # flat, self-diagnosing keys of the N > 1 line (tests/golden/multi_gpu_line.schema.json; tests/cpp/shard_host.cpp
+            # prints the same ones): per-rank times of the timed region, the ranks the communicator really has, the collective
+            # library's version and -- where rocm-smi is there -- the XGMI link count
+            out["config"]["rank_ms_min"] = round(1e3 * min(rank_s) / steps, 6)
+            out["config"]["rank_ms_max"] = round(1e3 * max(rank_s) / steps, 6)
+            out["config"]["ranks_seen"] = len(rank_s)
+            out["config"]["backend"] = str(dist.get_backend())
+            out["config"]["shard"] = shard
+            out["config"]["parseval_max_rel_dev"] = float(check_info.get("parseval_max_rel_dev", -1.0))
+            out["config"]["oracle_digest_max_dev"] = float(check_info.get("oracle_digest_max_dev", -1.0))
+            out["config"].update(fabric_info())
         traffic = load_profiled_traffic(2 if multi else 1, dom, len(pass_ms), kernel_tags(plan_list))
         if traffic is not None:
             if multi:  # profiled per 1024-transform launch; kernel_ms / algorithmic bytes here are per pass over the shard
@@ -991,25 +1089,47 @@ def main():
         if not multi and not args.no_scaling_reference:
             out["weak_scaling_reference"] = shard_on_one_gpu(P, torch, dev, args.shard)
             add_copy_frac(out["weak_scaling_reference"]["roofline"], sp)
-        # The driver's record keeps the top-level keys and `config`: the WHOLE metric (N = 2^20 and 2^26, absolute and as a
-        # fraction of the HBM roofline) and every other configuration measured in this run go there in compact form --
-        # value [GSamples/s], ms_per_step, frac = dominant kernel / 8 TB/s, frac_transform = SURVEY 8(d)'s transform figure.
-        def brief(c):
-            r = c.get("roofline", {})
-            b = {"value": round(c["value"], 3), "ms_per_step": round(c["ms_per_step"], 6), "frac": round(r.get("frac", 0.0), 4),
-                 "frac_transform": round(r.get("frac_transform", 0.0), 4)}
-            if "cpu_baseline" in c:
-                b["cpu_value"] = round(c["cpu_baseline"]["value"], 4)
-            if r.get("traffic"):
-                b["traffic_over_algorithmic"] = round(r["traffic"] / r["algorithmic_bytes_per_launch"], 4)
-            return b
+            if cpu:
+                out["weak_scaling_reference"]["cpu_baseline"] = shard_cpu_leg(args.shard)
+        # The driver's record keeps the top-level keys and the SCALAR keys of `config` (nested dicts were dropped in rounds 3-5):
+        # the WHOLE metric -- N = 2^20 and 2^26, absolute and as a fraction of the HBM roofline -- and every other
+        # configuration measured in this run go there as flat scalars.  *_gsps GSamples/s, *_ms ms per step,
+        # *_frac_transform = compulsory bytes / ms_per_step / 8 TB/s, *_frac_pass = dominant kernel / 8 TB/s,
+        # *_static_ms = the static rule's plan timed beside a `tuned:` one.
+        cfg = out["config"]
 
-        results = {"n2p20_forward": brief(out)}
+        def flat(prefix, c, keys=("gsps", "ms", "frac_transform", "frac_pass")):
+            r = c.get("roofline", {})
+            vals = {"gsps": c["value"], "ms": c["ms_per_step"], "frac_transform": r.get("frac_transform"), "frac_pass": r.get("frac"),
+                    "ms_min": c.get("ms_per_step_min"), "ms_median": c.get("ms_per_step_median"), "static_ms": c.get("static_ms"),
+                    "cpu_gsps": c.get("cpu_baseline", {}).get("value"),
+                    "traffic_x": (r["traffic"] / r["algorithmic_bytes_per_launch"]) if r.get("traffic") else None}
+            for k in keys:
+                if vals.get(k) is not None:
+                    cfg[f"{prefix}_{k}"] = round(float(vals[k]), 6 if k.endswith("ms") or "ms_" in k else 4)
+
+        head = {"value": value, "ms_per_step": ms_per_step, "roofline": roofline, **(head_stats if not multi else {}),
+                "cpu_baseline": out.get("cpu_baseline", {})}
+        flat("n2p20", head, ("gsps", "ms", "ms_min", "ms_median", "frac_transform", "frac_pass", "cpu_gsps", "traffic_x"))
+        names = {"n2p26_forward": "n2p26", "n2p26_roundtrip": "rt2p26", "r2c_f32_2p24": "r2c_f32_2p24", "c2r_f32_2p24": "c2r_f32_2p24",
+                 "f32_2p20": "f32_2p20", "f32_2p26": "f32_2p26"}
         for name, c in out.get("configs", {}).items():
-            results[name] = brief(c)
+            flat(names.get(name, name), c, ("gsps", "ms", "ms_min", "ms_median", "frac_transform", "frac_pass", "static_ms", "cpu_gsps",
+                                            "traffic_x"))
+            if c.get("plan_ran"):
+                cfg[f"{names.get(name, name)}_plan"] = c["plan_ran"][:110]
         if "weak_scaling_reference" in out:
-            results[f"shard_{args.shard}x2p20"] = brief(out["weak_scaling_reference"])
-        out["config"]["results"] = results
+            flat(f"shard{args.shard}", out["weak_scaling_reference"], ("gsps", "ms", "frac_transform", "frac_pass", "cpu_gsps", "traffic_x"))
+        if "host_slice_api" in out:
+            cfg["host_slice_gsps"] = round(out["host_slice_api"]["value"], 4)   # the reference's calling convention: PCIe-bound
+            cfg["host_slice_ms"] = round(out["host_slice_api"]["ms_per_call"], 4)
+        if not multi and check_info is not None:
+            cfg["check_rel_l2"] = float(check_info.get("rel_l2_max", -1.0))
+            cfg["check_ok"] = bool(check_info.get("ok", False))
+        if "configs" in out and "n2p26_roundtrip" in out["configs"]:
+            cfg["rt2p26_err_ok"] = bool(out["configs"]["n2p26_roundtrip"].get("err_ok", False))
+        if not multi:
+            cfg["copy_probe_GBps"] = round(float(roofline.get("stream_probe", {}).get("copy", 0.0)), 1)
         print(json.dumps(out), flush=True)
     if multi:
         import torch.distributed as dist

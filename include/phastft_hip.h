@@ -143,13 +143,13 @@ typedef struct phast_tune_report {
 int phast_planner_dit64_tune(phast_planner_dit64 *p, size_t batch_hint, int kind, phast_tune_report *report /* or NULL */);
 int phast_planner_dit32_tune(phast_planner_dit32 *p, size_t batch_hint, int kind, phast_tune_report *report);
 /* Wisdom: what tuning runs found, as text (one line per type / kind / log2 length / batch bucket, csrc/wisdom.hpp).  Planners
- * created after an import start with the plans it names (entries measured on a device with another CU count are ignored).
+ * created after an import start with the plans it names (entries measured on a device with another CU count or gfx architecture, or by another generation of the library's kernels -- the header line's cus= / arch= / lib= -- are kept but not applied).
  * PHAST_WISDOM=<path>: read at first use, rewritten after every tuning run.  The library also carries built-in wisdom measured
  * on an MI355X (PHAST_BUILTIN_WISDOM=0 turns it off).  No device needed for these three calls. */
 int phast_wisdom_export(char *buf, size_t buf_len, size_t *needed /* bytes incl. NUL, or NULL */); /* without the built-in layer */
 int phast_wisdom_import(const char *text); /* PHAST_ERR_INVALID_ARG: not a wisdom text (nothing of it is kept); lines that do not parse are skipped */
 void phast_wisdom_forget(void);            /* everything but the built-in layer */
-void phast_wisdom_builtin(int enable);     /* the built-in layer off / on again at run time (planners made afterwards) */
+int phast_wisdom_builtin(int enable);      /* the built-in layer off / on again at run time (planners made afterwards); returns what it was (1 on, 0 off) so a caller can put it back */
 size_t phast_wisdom_count(int layer);      /* entries of a layer: 0 built-in, 1 PHAST_WISDOM file, 2 imported, 3 measured here; -1 all */
 
 /* ---- planner.rs:164-212 ---- */

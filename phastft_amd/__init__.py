@@ -105,9 +105,10 @@ def wisdom_forget() -> None:
     _lib.lib().phast_wisdom_forget()
 
 
-def wisdom_builtin(enable: bool) -> None:
-    """The wisdom compiled into the library (csrc/builtin_wisdom.inc) off / on for planners made afterwards."""
-    _lib.lib().phast_wisdom_builtin(1 if enable else 0)
+def wisdom_builtin(enable: bool) -> bool:
+    """The wisdom compiled into the library (csrc/builtin_wisdom.inc) off / on for planners made afterwards.  Returns what it
+    was before (PHAST_BUILTIN_WISDOM=0 starts it off): `was = wisdom_builtin(False) ... wisdom_builtin(was)` puts it back."""
+    return bool(_lib.lib().phast_wisdom_builtin(1 if enable else 0))
 
 
 ERR_INVALID_ARG = 16  # PHAST_ERR_INVALID_ARG (include/phastft_hip.h): e.g. a shape the strided kernels do not cover

@@ -89,7 +89,7 @@ def lib() -> C.CDLL:
     l.phast_planner_dit64_release_graph_workspaces.restype = C.c_size_t
     l.phast_planner_dit32_release_graph_workspaces.restype = C.c_size_t
     l.phast_wisdom_forget.restype = None
-    l.phast_wisdom_builtin.restype = None
+    l.phast_wisdom_builtin.restype = C.c_int
     l.phast_wisdom_builtin.argtypes = [C.c_int]
     l.phast_wisdom_count.restype = C.c_size_t
     l.phast_wisdom_count.argtypes = [C.c_int]

@@ -69,7 +69,7 @@ struct phast_twiddle_grid32 : TwiddleGrid<float> {};
 // measurement for this type, length, kind and device
 template <typename P> static int tune_new(P *p, int kind) {
     const size_t eb = sizeof(typename P::value_type);
-    if (WisdomStore::instance().lookup(eb, kind, p->wisdom_log_n(), 0, cus_of(p->device_of()), nullptr)) return PHAST_OK;
+    if (WisdomStore::instance().lookup(eb, kind, p->wisdom_log_n(), 0, cus_of(p->device_of()), arch_of(p->device_of()), nullptr)) return PHAST_OK;
     return p->tune(kind, 1, nullptr);
 }
 template <typename R> static void report_to_c(const R &r, phast_tune_report *rep) {
@@ -119,7 +119,7 @@ int phast_wisdom_import(const char *text) try {
     return WisdomStore::instance().import_text(text, 2) == 0 ? PHAST_OK : PHAST_ERR_INVALID_ARG;
 } PHAST_CATCH_RC
 void phast_wisdom_forget(void) try { WisdomStore::instance().forget(); } PHAST_CATCH_VOID
-void phast_wisdom_builtin(int enable) try { WisdomStore::instance().set_builtin(enable != 0); } PHAST_CATCH_VOID
+int phast_wisdom_builtin(int enable) try { return WisdomStore::instance().set_builtin(enable != 0) ? 1 : 0; } PHAST_CATCH_ZERO
 size_t phast_wisdom_count(int layer) try { return WisdomStore::instance().count(layer); } PHAST_CATCH_ZERO
 
 const char *phast_strerror(int code) {

@@ -345,15 +345,19 @@ static int set_plan_c(Planner<T> *p, const unsigned *log_rows, const unsigned *t
         return n_passes == 0 ? PHAST_OK : PHAST_ERR_INVALID_ARG;
     }
     std::vector<unsigned> lrs, tls;
-    if (n_passes == 0) {
-        return p->default_plans();
+    if (n_passes == 0) {  // the restore form: the library's own plans, tuned / wisdom plans in force again
+        const int rc = p->default_plans();
+        if (rc == PHAST_OK) p->set_forced(false);
+        return rc;
     } else {
         if (!log_rows || !tile_logs) return PHAST_ERR_INVALID_ARG;
         lrs.assign(log_rows, log_rows + n_passes);
         tls.assign(tile_logs, tile_logs + n_passes);
     }
     if ((points_log & 0xfu) < 3 || (points_log & 0xfu) > 5 || (points_log & ~0x1fu)) return PHAST_ERR_INVALID_ARG;
-    return p->set_plan(lrs, tls, 0, points_log);
+    const int rc = p->set_plan(lrs, tls, 0, points_log);
+    if (rc == PHAST_OK) p->set_forced(true);  // the caller's plan runs for every call kind and batch, whatever wisdom says
+    return rc;
 }
 
 }  // namespace phast

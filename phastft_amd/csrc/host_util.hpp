@@ -25,6 +25,7 @@
 #include "tile_dispatch.hpp"
 #include "r2c_fused.hpp"
 #include "c2r_fused.hpp"
+#include "wisdom.hpp"
 
 namespace phast {
 
@@ -61,6 +62,17 @@ static int cus_of(int dev) {
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess) c = prop.multiProcessorCount;
         return c > 0 ? c : 256;
     });
+}
+// gfx number of the device as hex digits (gfx950 -> 0x950; wisdom.hpp: arch_from_name), -1 cached for "unknown" -> 0
+static PerDeviceInt g_arch_of;
+static int arch_of(int dev) {
+    const int v = g_arch_of.get(dev, [&] {
+        hipDeviceProp_t prop;
+        int a = 0;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) a = arch_from_name(prop.gcnArchName);
+        return a > 0 ? a : -1;
+    });
+    return v > 0 ? v : 0;
 }
 
 // Is there a device at all, and which one is current?  The library holds no process-wide device: a planner belongs to

@@ -137,6 +137,16 @@ template <typename T> struct Planner {
     // scratch_pad_bytes); the largest over this planner's plans, fixed before the first allocation grows past it
     size_t scratch_stride = 0;
     size_t sstride() const { return scratch_stride ? scratch_stride : n; }
+    // the widest (padded) intermediate layout of any plan installed right now -- static, forced or tuned; plan_mu held
+    size_t installed_pitch_locked() const {
+        size_t need = n;
+        for (const std::vector<PassDesc> *v : {&passes, &passes_lat, &passes_mid, &passes_one, &passes_c2r_one, &passes_c2r_lat, &passes_r2c,
+                                               &passes_r2c_tp, &passes_c2r_tp})
+            for (const PassDesc &p : *v) need = std::max(need, (size_t)p.scratch_dist);
+        for (const auto &t : tuned)
+            for (const PassDesc &p : t->passes) need = std::max(need, (size_t)p.scratch_dist);
+        return need;
+    }
     mutable std::atomic<size_t> reserve{1};
     int device = -1;  // the device this planner's tables and scratch live on (current at creation); calls run there
     // Twiddle tables, keyed by what they hold: every plan of this planner -- the static ones, those a tuning run tries, those
@@ -167,7 +177,16 @@ template <typename T> struct Planner {
     };
     mutable std::vector<std::unique_ptr<TunedPlan>> tuned;
     mutable std::mutex tune_mu;  // one tuning run at a time per planner
+    // set by the public plan hook (phast_planner_*_set_plan / _set_inner_plan with a plan), cleared by the hook's restore form
+    // and by a later tuning run: while it is set, calls run the plan that was forced -- not a tuned or built-in-wisdom plan
+    // that happens to exist for the (kind, bucket) (a forced plan was silently ignored there).  Guarded by plan_mu.
+    bool forced = false;
+    void set_forced(bool f) {
+        std::unique_lock<std::shared_mutex> plans(plan_mu);
+        forced = f;
+    }
     const TunedPlan *tuned_for(int kind, size_t batch) const {
+        if (forced) return nullptr;
         const unsigned b = batch_bucket(batch);
         for (const auto &t : tuned)
             if (t->kind == kind && t->bucket == b) return t.get();

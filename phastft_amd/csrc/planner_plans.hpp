@@ -199,6 +199,7 @@ int Planner<T>::install_built(int kind, unsigned bucket, const PlanSpec &spec, b
     // exclusive: no call is enqueueing with a Choice that points into the entry that goes (calls hold plan_mu shared while
     // they enqueue; kernels in flight read tables, which are the planner's)
     std::unique_lock<std::shared_mutex> plans(plan_mu);
+    forced = false;  // a tuning run (or an import) after set_plan: the newest instruction wins
     if (need > sstride()) scratch_stride = need;
     for (auto &e : tuned)
         if (e->kind == kind && e->bucket == bucket) {
@@ -221,11 +222,11 @@ template <typename T> void Planner<T>::remove_tuned(int kind, unsigned bucket) {
 // install nothing).  Entries that no longer build -- a tile shape that went -- are skipped.
 template <typename T> int Planner<T>::apply_wisdom(unsigned real_log_n) {
     if (passes.empty()) return PHAST_OK;
-    const int cus = cus_of(device);
+    const int cus = cus_of(device), arch = arch_of(device);
     for (int kind : {(int)kC2C, (int)kC2CI, (int)kR2C, (int)kC2R}) {
         const bool real = kind == kR2C || kind == kC2R;
         if (real != (real_log_n != 0)) continue;
-        for (const auto &kv : WisdomStore::instance().lookup_all(sizeof(T), kind, real ? real_log_n : log_n, cus)) {
+        for (const auto &kv : WisdomStore::instance().lookup_all(sizeof(T), kind, real ? real_log_n : log_n, cus, arch)) {
             const WisdomEntry &e = kv.second;
             if (e.heuristic) continue;
             int rc = install_tuned(kind, kv.first, e.spec, e.fuse, e.us, e.us_heur);
@@ -391,6 +392,7 @@ template <typename T> std::string Planner<T>::describe_call(int kind, size_t bat
     const Choice c = choose(kind, batch ? batch : 1, batch ? batch : 1);
     const std::vector<PassDesc> *v = c.passes;
     std::string s = c.tuned                  ? "tuned"
+                    : forced                 ? "forced"
                     : v == &passes           ? "throughput"
                     : v == &passes_mid       ? "mid"
                     : v == &passes_lat       ? "latency"
@@ -414,6 +416,8 @@ template <typename T> std::string Planner<T>::describe_call(int kind, size_t bat
 }
 
 template <typename T> std::string Planner<T>::describe() const {
+    // shared hold: a tuning run beside this call installs / removes entries of `tuned` under the exclusive lock
+    std::shared_lock<std::shared_mutex> plans(plan_mu);
     char buf[512];
     std::string s = "n=2^" + std::to_string(log_n);
     auto add = [&](const char *tag, const std::vector<PassDesc> &v) {

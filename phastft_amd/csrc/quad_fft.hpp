@@ -80,18 +80,22 @@ template <typename T> struct QuadBody {
     // row of register q: 64 (q >> 2) + 16 (q & 3) + 4 w + tau
     PHAST_HD static void load_raw(const TileArgs &a, int wave, int lane, Regs &r) {
         const size_t ubase = in_tile_base(a, r.xform, r.g0);
-        const unsigned voff = (unsigned)(4 * wave + tau_of(lane)) * (unsigned)a.in_row_stride + (unsigned)col_of(lane);
-        const T *pr = reinterpret_cast<const T *>(a.in_re) + ubase;
-        const T *pi = reinterpret_cast<const T *>(a.in_im) + ubase;
+        // the wave's rows start at 4 wave (wave-uniform: the kernel takes it through readfirstlane); the lane's part of the
+        // address is ONE 32-bit byte offset shared by the 32 loads (wave_fft.hpp: load_raw)
+        const unsigned vbyte = ((unsigned)tau_of(lane) * (unsigned)a.in_row_stride + (unsigned)col_of(lane)) * (unsigned)sizeof(T);
+        const T *pr = reinterpret_cast<const T *>(a.in_re) + ubase + (size_t)(4 * wave) * a.in_row_stride;
+        const T *pi = reinterpret_cast<const T *>(a.in_im) + ubase + (size_t)(4 * wave) * a.in_row_stride;
         static_for<0, P>([&](auto q) {
             constexpr int Q = decltype(q)::value;
             const size_t urow = (size_t)(64 * (Q >> 2) + 16 * (Q & 3)) * a.in_row_stride;
+            const T *qr = reinterpret_cast<const T *>(reinterpret_cast<const char *>(pr + urow) + vbyte);
+            const T *qi = reinterpret_cast<const T *>(reinterpret_cast<const char *>(pi + urow) + vbyte);
             if constexpr (NT_LOAD) {
-                r.re[Q] = __builtin_nontemporal_load(pr + urow + voff);
-                r.im[Q] = __builtin_nontemporal_load(pi + urow + voff);
+                r.re[Q] = __builtin_nontemporal_load(qr);
+                r.im[Q] = __builtin_nontemporal_load(qi);
             } else {
-                r.re[Q] = (pr + urow)[voff];
-                r.im[Q] = (pi + urow)[voff];
+                r.re[Q] = *qr;
+                r.im[Q] = *qi;
             }
         });
     }
@@ -158,35 +162,53 @@ template <typename T> struct QuadBody {
         static_for<0, 4>([&](auto u) { fft_reg_dif_s<T, 4, decltype(u)::value, 4, P>(r.re, r.im); });
     }
 
-    PHAST_HD static unsigned krow_lane(int wave, int lane) {
-        constexpr unsigned br2[4] = {0u, 2u, 1u, 3u};
-        return br2[tau_of(lane)] + 4u * br2[wave];
-    }
+    PHAST_HD static unsigned br2(unsigned v) { return ((v & 1u) << 1) | (v >> 1); }
+    PHAST_HD static unsigned krow_lane(int wave, int lane) { return br2((unsigned)tau_of(lane)) + 4u * br2((unsigned)wave); }
     template <int Q> PHAST_HD static constexpr unsigned krow_const() {  // register Q = u + 4 v
         return 16u * (unsigned)bitrev_c(Q & 3, 2) + 64u * (unsigned)bitrev_c(Q >> 2, 2);
     }
-    PHAST_HD static void store(const TileArgs &a, int wave, int lane, const Regs &r) {
+    // planar or (re, im) pairs, scaled (the last pass of an inverse transform) or not: decided ONCE per tile, outside the
+    // sixteen stores -- inside it was a scalar branch per store and 32 multiplications by one in every forward pass
+    template <bool PAIRS, bool SCALE> PHAST_HD static void store_as(const TileArgs &a, int wave, int lane, const Regs &r) {
         const size_t base = (size_t)(r.g0 & ((1u << a.out_lo_bits) - 1u)) * a.out_s1 + (size_t)(r.g0 >> a.out_lo_bits) * a.out_s2 +
-                            (size_t)r.xform * a.out_dist;
-        const unsigned voff = (unsigned)col_of(lane) * (unsigned)a.out_s1 + krow_lane(wave, lane) * (unsigned)a.out_row_stride;
+                            (size_t)r.xform * a.out_dist + (size_t)(4u * br2((unsigned)wave)) * a.out_row_stride;
+        const unsigned vbyte = ((unsigned)col_of(lane) * (unsigned)a.out_s1 + br2((unsigned)tau_of(lane)) * (unsigned)a.out_row_stride) *
+                               (unsigned)sizeof(T);
         const T scale = (T)a.scale;
         static_for<0, P>([&](auto Q) {
-            const size_t at = base + (size_t)krow_const<decltype(Q)::value>() * a.out_row_stride + voff;
-            if (!a.out_interleaved) {
+            const size_t at = base + (size_t)krow_const<decltype(Q)::value>() * a.out_row_stride;
+            T re = r.re[Q], im = r.im[Q];
+            if constexpr (SCALE) {
+                re *= scale;
+                im *= scale;
+            }
+            if constexpr (!PAIRS) {
+                T *qr = reinterpret_cast<T *>(reinterpret_cast<char *>(reinterpret_cast<T *>(a.out_re) + at) + vbyte);
+                T *qi = reinterpret_cast<T *>(reinterpret_cast<char *>(reinterpret_cast<T *>(a.out_im) + at) + vbyte);
                 if constexpr (NT_STORE) {
-                    __builtin_nontemporal_store(r.re[Q] * scale, reinterpret_cast<T *>(a.out_re) + at);
-                    __builtin_nontemporal_store(r.im[Q] * scale, reinterpret_cast<T *>(a.out_im) + at);
+                    __builtin_nontemporal_store(re, qr);
+                    __builtin_nontemporal_store(im, qi);
                 } else {
-                    reinterpret_cast<T *>(a.out_re)[at] = r.re[Q] * scale;
-                    reinterpret_cast<T *>(a.out_im)[at] = r.im[Q] * scale;
+                    *qr = re;
+                    *qi = im;
                 }
             } else {
                 cx v;
-                v.x = (a.out_interleaved == 2 ? r.im[Q] : r.re[Q]) * scale;
-                v.y = (a.out_interleaved == 2 ? r.re[Q] : r.im[Q]) * scale;
-                reinterpret_cast<cx *>(a.out_re)[at] = v;
+                v.x = a.out_interleaved == 2 ? im : re;
+                v.y = a.out_interleaved == 2 ? re : im;
+                *reinterpret_cast<cx *>(reinterpret_cast<char *>(reinterpret_cast<cx *>(a.out_re) + at) + 2u * vbyte) = v;
             }
         });
+    }
+    PHAST_HD static void store(const TileArgs &a, int wave, int lane, const Regs &r) {
+        const bool scaled = a.scale != 1.0;
+        if (!a.out_interleaved) {
+            if (scaled) store_as<false, true>(a, wave, lane, r);
+            else store_as<false, false>(a, wave, lane, r);
+        } else {
+            if (scaled) store_as<true, true>(a, wave, lane, r);
+            else store_as<true, false>(a, wave, lane, r);
+        }
     }
 };
 
@@ -209,7 +231,9 @@ template <typename T> __device__ __forceinline__ void quad_lane_exchange(T (&re)
 }
 
 // (Staggering the workgroups' or the waves' first loads, as wave_fft.hpp does, buys nothing here: profiles/r02_stagger.log.)
-template <typename T> __global__ void __launch_bounds__(256) quad_fft_kernel(const TileArgs a) {
+// ONE: the grid has one workgroup per tile (a single transform: 256 tiles on 256 CUs) -- no tile loop, so the second
+// load site, its hoisted 64-bit lane offsets and the SGPRs parked in VGPR lanes across the loop are gone.
+template <typename T, bool ONE> __global__ void __launch_bounds__(256) quad_fft_kernel(const TileArgs a) {
     using Body = QuadBody<T>;
     using cx = cx_t<T>;
     pin_tile_args(a);
@@ -218,7 +242,8 @@ template <typename T> __global__ void __launch_bounds__(256) quad_fft_kernel(con
     T *ex_im = ex_re + Body::EXCH;
     cx *l_tw3 = reinterpret_cast<cx *>(ex_im + Body::EXCH);
     cx *l_twq = l_tw3 + (3u << a.tw_bits);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: row bases and table rows live in SGPRs
     typename Body::Regs r;
     // tables: global loads first, the first tile's loads right behind them (loads return in order: see wave_fft.hpp).
     // Four named registers, not an array: an array here lands in scratch memory as soon as control flow separates
@@ -256,6 +281,7 @@ template <typename T> __global__ void __launch_bounds__(256) quad_fft_kernel(con
         quad_lane_exchange<T>(r.re, r.im);
         Body::step4(r);
         Body::store(a, wave, lane, r);
+        if constexpr (ONE) break;
         t += gridDim.x;
         if (t >= a.tiles_total) break;
         Body::locate(a, t, r);
@@ -267,15 +293,16 @@ template <typename T>
 hipError_t launch_quad_inst(unsigned grid, hipStream_t stream, const TileArgs &a, bool query_only, int *blocks_per_cu,
                             size_t *lds_out, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr) {
     using Body = QuadBody<T>;
-    auto kern = quad_fft_kernel<T>;
+    const bool one = !query_only && grid == a.tiles_total;
+    auto kern = one ? quad_fft_kernel<T, true> : quad_fft_kernel<T, false>;
     const size_t lds = Body::lds_bytes(a.tw_bits);
     if (lds_out) *lds_out = lds;
     if (lds > (size_t)160 * 1024) {
         if (query_only && blocks_per_cu) *blocks_per_cu = 0;
         return query_only ? hipSuccess : hipErrorInvalidValue;
     }
-    static PerDeviceLimit lds_limit;
-    if (hipError_t e = raise_lds_limit(lds_limit, reinterpret_cast<const void *>(kern), lds); e != hipSuccess) return e;
+    static PerDeviceLimit lds_limit[2];
+    if (hipError_t e = raise_lds_limit(lds_limit[one], reinterpret_cast<const void *>(kern), lds); e != hipSuccess) return e;
     if (query_only) {
         if (blocks_per_cu) *blocks_per_cu = (int)((160 * 1024) / lds) < 2 ? (int)((160 * 1024) / lds) : 2;
         return hipSuccess;

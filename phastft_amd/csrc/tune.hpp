@@ -112,7 +112,21 @@ int Planner<T>::tune_core(int kind, size_t batch, unsigned wisdom_log_n, int rin
             cands.push_back(std::move(c));
         }
     }
-    {  // one scratch pitch for every candidate, before a workspace is cut for it
+    // One scratch pitch for every candidate, before a workspace is cut for it -- for the duration of the run only.  The pitch
+    // goes back to what the installed plans need when the run ends (the static plans, the tuned ones and an adopted winner):
+    // left at the maximum over up to a thousand candidates that were never adopted, every later scratch was larger than any
+    // plan in force needs and every existing workspace had to be re-cut.  A tuning run still re-cuts the workspace
+    // it used: like set_plan, tune() is followed by one eager call before a capture (phastft_hip.h).
+    struct RestorePitch {
+        Planner<T> *p;
+        size_t before;
+        ~RestorePitch() {  // (what the plans installed NOW need: a set_plan that slipped in after the lease went is counted)
+            std::unique_lock<std::shared_mutex> plans(p->plan_mu);
+            const size_t want = std::max(before, p->installed_pitch_locked());
+            p->scratch_stride = want > p->n ? want : 0;
+        }
+    } restore_pitch{this, scratch_stride};
+    {
         std::unique_lock<std::shared_mutex> plans(plan_mu);
         if (need_max > sstride()) scratch_stride = need_max;
     }
@@ -282,6 +296,8 @@ int Planner<T>::tune_core(int kind, size_t batch, unsigned wisdom_log_n, int rin
     we.us = adopted ? med_best : med_heur;
     we.us_heur = med_heur;
     we.cus = cus_of(device);
+    we.arch = arch_of(device);
+    we.lib = kWisdomLib;
     we.layer = 3;
     if (adopted) {
         Cand &w = cands[(size_t)best];

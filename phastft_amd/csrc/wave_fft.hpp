@@ -63,7 +63,7 @@ template <typename T, bool PRE_TW, bool TRANSPOSE> struct WaveBody {
 
     static size_t lds_bytes(unsigned tw_bits) {
         (void)tw_bits;  // the inter-pass tables are read from global memory (six entries per lane)
-        return (size_t)WAVES * (32 * sizeof(cx) + (size_t)2 * XP * sizeof(T));  // per wave: W_64 table, transposing buffer
+        return (size_t)WAVES * (64 * sizeof(cx) + (size_t)2 * XP * sizeof(T));  // per wave: W_64 table, transposing buffer
     }
 
     PHAST_HD static int col_of(int lane) { return lane & (COLS - 1); }
@@ -87,14 +87,21 @@ template <typename T, bool PRE_TW, bool TRANSPOSE> struct WaveBody {
         if (PRE_TW || !a.in_interleaved) {
             const T *pr = reinterpret_cast<const T *>(a.in_re) + ubase;
             const T *pi = reinterpret_cast<const T *>(a.in_im) + ubase;
+            // the lane's part of the address as a 32-bit BYTE offset: with the tile's base wave-uniform (the kernel takes the
+            // wave index through readfirstlane) every load is  scalar row base + one shared VGPR offset  -- no 64-bit
+            // vector address arithmetic per load (it was 4-6 VALU instructions of each of the 32 loads and 32 stores of a
+            // tile, on a wave that has its SIMD to itself: nothing hides them).  launch_wave_inst checks the range.
+            const unsigned vbyte = voff * (unsigned)sizeof(T);
             static_for<0, P>([&](auto j) {
                 const size_t urow = (size_t)(decltype(j)::value * TAUS) * a.in_row_stride;
+                const T *qr = reinterpret_cast<const T *>(reinterpret_cast<const char *>(pr + urow) + vbyte);
+                const T *qi = reinterpret_cast<const T *>(reinterpret_cast<const char *>(pi + urow) + vbyte);
                 if constexpr (NT_LOAD) {
-                    r.re[j] = __builtin_nontemporal_load(pr + urow + voff);
-                    r.im[j] = __builtin_nontemporal_load(pi + urow + voff);
+                    r.re[j] = __builtin_nontemporal_load(qr);
+                    r.im[j] = __builtin_nontemporal_load(qi);
                 } else {
-                    r.re[j] = (pr + urow)[voff];
-                    r.im[j] = (pi + urow)[voff];
+                    r.re[j] = *qr;
+                    r.im[j] = *qi;
                 }
             });
         } else {  // first pass of an interleaved / real transform: (re, im) or (im, re) pairs
@@ -133,11 +140,18 @@ template <typename T, bool PRE_TW, bool TRANSPOSE> struct WaveBody {
         if constexpr (PRE_TW) pre_twiddle_apply(pre_twiddle_fetch(a, tw3, lane, r), r);
     }
 
-    // W_64^e, e < 64, from the first 32 entries of host_twr(64): W^(e + 32) = -W^e
+    // W_64^e, e < 64.  The kernel stages all 64 entries in LDS (the second half negated once, when the table is staged);
+    // the host emulator reads the planner's 32-entry table, W^(e + 32) = -W^e -- bitwise the same values
     PHAST_HD static void w64(const cx *twr, unsigned e, T &wr, T &wi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const cx w = twr[e];
+        wr = w.x;
+        wi = w.y;
+#else
         const cx w = twr[e & 31u];
         wr = (e & 32u) ? -w.x : w.x;
         wi = (e & 32u) ? -w.y : w.y;
+#endif
     }
 
     PHAST_HD static void step1(const cx *twr, int lane, Regs &r) {
@@ -172,36 +186,50 @@ template <typename T, bool PRE_TW, bool TRANSPOSE> struct WaveBody {
         return (size_t)(r.g0 & ((1u << a.out_lo_bits) - 1u)) * a.out_s1 + (size_t)(r.g0 >> a.out_lo_bits) * a.out_s2 +
                (size_t)r.xform * a.out_dist;
     }
-    template <bool PAIRS> PHAST_HD static void put(const TileArgs &a, size_t ubase, unsigned voff, T re, T im, T scale) {
+    // ubase: wave-uniform element offset; vbyte: the lane's part as a 32-bit byte offset (see load_raw)
+    template <bool PAIRS, bool SCALE> PHAST_HD static void put(const TileArgs &a, size_t ubase, unsigned vbyte, T re, T im, T scale) {
+        if constexpr (SCALE) {
+            re *= scale;
+            im *= scale;
+        }
         if constexpr (!PAIRS) {
+            T *qr = reinterpret_cast<T *>(reinterpret_cast<char *>(reinterpret_cast<T *>(a.out_re) + ubase) + vbyte);
+            T *qi = reinterpret_cast<T *>(reinterpret_cast<char *>(reinterpret_cast<T *>(a.out_im) + ubase) + vbyte);
             if constexpr (NT_STORE) {
-                __builtin_nontemporal_store(re * scale, reinterpret_cast<T *>(a.out_re) + ubase + voff);
-                __builtin_nontemporal_store(im * scale, reinterpret_cast<T *>(a.out_im) + ubase + voff);
+                __builtin_nontemporal_store(re, qr);
+                __builtin_nontemporal_store(im, qi);
             } else {
-                (reinterpret_cast<T *>(a.out_re) + ubase)[voff] = re * scale;
-                (reinterpret_cast<T *>(a.out_im) + ubase)[voff] = im * scale;
+                *qr = re;
+                *qi = im;
             }
         } else {
             cx v;
-            v.x = (a.out_interleaved == 2 ? im : re) * scale;
-            v.y = (a.out_interleaved == 2 ? re : im) * scale;
-            (reinterpret_cast<cx *>(a.out_re) + ubase)[voff] = v;
+            v.x = a.out_interleaved == 2 ? im : re;
+            v.y = a.out_interleaved == 2 ? re : im;
+            *reinterpret_cast<cx *>(reinterpret_cast<char *>(reinterpret_cast<cx *>(a.out_re) + ubase) + 2u * vbyte) = v;
         }
     }
     // later passes: same column-wide pattern out as in.  The planar / (re, im)-pair decision is taken ONCE, outside the
     // sixteen stores (inside, it was a scalar branch per store).
-    PHAST_HD static void store_rows(const TileArgs &a, int lane, const Regs &r) {
+    // The multiplication by `scale` (1/N of an inverse transform's last pass, else exactly 1) is a wave-uniform branch too:
+    // a forward pass does not carry 32 multiplications by one.
+    template <bool PAIRS, bool SCALE> PHAST_HD static void store_rows_as(const TileArgs &a, int lane, const Regs &r) {
         const size_t base = out_base(a, r);
-        const unsigned voff = (unsigned)col_of(lane) * (unsigned)a.out_s1 + krow_lane(lane) * (unsigned)a.out_row_stride;
+        const unsigned vbyte =
+            ((unsigned)col_of(lane) * (unsigned)a.out_s1 + krow_lane(lane) * (unsigned)a.out_row_stride) * (unsigned)sizeof(T);
         const T scale = (T)a.scale;
+        static_for<0, P>([&](auto Q) {
+            put<PAIRS, SCALE>(a, base + (size_t)krow_const<decltype(Q)::value>() * a.out_row_stride, vbyte, r.re[Q], r.im[Q], scale);
+        });
+    }
+    PHAST_HD static void store_rows(const TileArgs &a, int lane, const Regs &r) {
+        const bool scaled = a.scale != 1.0;
         if (!a.out_interleaved) {
-            static_for<0, P>([&](auto Q) {
-                put<false>(a, base + (size_t)krow_const<decltype(Q)::value>() * a.out_row_stride, voff, r.re[Q], r.im[Q], scale);
-            });
+            if (scaled) store_rows_as<false, true>(a, lane, r);
+            else store_rows_as<false, false>(a, lane, r);
         } else {
-            static_for<0, P>([&](auto Q) {
-                put<true>(a, base + (size_t)krow_const<decltype(Q)::value>() * a.out_row_stride, voff, r.re[Q], r.im[Q], scale);
-            });
+            if (scaled) store_rows_as<true, true>(a, lane, r);
+            else store_rows_as<true, false>(a, lane, r);
         }
     }
     // pass A: through the wave-private buffer [col][k], then register Q holds row k = lane of column Q
@@ -209,11 +237,10 @@ template <typename T, bool PRE_TW, bool TRANSPOSE> struct WaveBody {
         return col_of(lane) * CS + (int)krow_lane(lane) + (int)krow_const<Q>();
     }
     template <int Q> PHAST_HD static int xp_read_addr(int lane) { return Q * CS + lane; }
-    PHAST_HD static void store_runs(const TileArgs &a, int lane, const Regs &r) {
+    PHAST_HD static void store_runs(const TileArgs &a, int lane, const Regs &r) {  // a first pass: never the scaled last one
         const size_t base = out_base(a, r);
-        const unsigned voff = (unsigned)lane * (unsigned)a.out_row_stride;
-        const T scale = (T)a.scale;
-        static_for<0, P>([&](auto Q) { put<false>(a, base + (size_t)decltype(Q)::value * a.out_s1, voff, r.re[Q], r.im[Q], scale); });
+        const unsigned vbyte = (unsigned)lane * (unsigned)a.out_row_stride * (unsigned)sizeof(T);
+        static_for<0, P>([&](auto Q) { put<false, false>(a, base + (size_t)decltype(Q)::value * a.out_s1, vbyte, r.re[Q], r.im[Q], (T)1); });
     }
 };
 
@@ -311,11 +338,16 @@ __global__ void __launch_bounds__(64 * PHAST_WAVE_TILES_PER_BLOCK) wave_fft_kern
     pin_tile_args(a);
     pin_scalars(blocks_total, stagger);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform, and the compiler is told so: tile bases live in SGPRs
+#else
+    const int wave = tid >> 6;
+#endif
     // everything in LDS is private to a wave: its copy of the W_64 step-twiddle table and its transposing buffer.  No
     // workgroup barrier anywhere: the four waves of a block are four independent tiles.
-    cx *l_twr = reinterpret_cast<cx *>(smem + (size_t)wave * (32 * sizeof(cx) + (size_t)2 * Body::XP * sizeof(T)));
-    T *xp = reinterpret_cast<T *>(l_twr + 32);
+    cx *l_twr = reinterpret_cast<cx *>(smem + (size_t)wave * (64 * sizeof(cx) + (size_t)2 * Body::XP * sizeof(T)));
+    T *xp = reinterpret_cast<T *>(l_twr + 64);
     if ((blockIdx.x * Body::WAVES + (unsigned)wave) >= a.tiles_total) return;
 
     // Twiddle tables: their global loads go out FIRST and the tile's loads right behind them.  Loads return in order
@@ -338,10 +370,17 @@ __global__ void __launch_bounds__(64 * PHAST_WAVE_TILES_PER_BLOCK) wave_fft_kern
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
 #if defined(PHAST_WAVE_DEBUG_SKIP) && PHAST_WAVE_DEBUG_SKIP >= 4  // tools only: no table staging
-    if (a.tiles_total == 0xffffffffu) l_twr[lane & 31] = twr_stage;
+    if (a.tiles_total == 0xffffffffu) l_twr[lane] = twr_stage;
     if constexpr (TRANSPOSE) { } else { Body::store_rows(a, lane, r); return; }
 #endif
-    l_twr[lane & 31] = twr_stage;  // both half-waves write the same values
+    {  // all 64 powers: lanes 32..63 store W^(e + 32) = -W^e, so step1 needs no sign selects (74 v_cndmask per tile)
+        cx w = twr_stage;
+        if (lane & 32) {
+            w.x = -w.x;
+            w.y = -w.y;
+        }
+        l_twr[lane] = w;
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");

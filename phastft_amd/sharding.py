@@ -64,6 +64,47 @@ class ShardedBatch:
         return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)
 
 
+def times_over_ranks(seconds: float, dist=None, device=None) -> list:
+    """Every rank's own time for the timed region (all-gather of one scalar): what one needs to read a bad N-GPU point --
+    a straggler shows as one outlier, a slow fabric or a clock-capped box as a uniform shift."""
+    if dist is None:
+        return [seconds]
+    import torch
+
+    if dist.get_backend() == "gloo":
+        device = "cpu"
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, t)
+    return [float(p.item()) for p in parts]
+
+
+def fabric_info() -> dict:
+    """Flat, best-effort description of the collective library and the GPU fabric for the N > 1 bench line: `rccl_version`
+    (torch.cuda.nccl.version() -- RCCL on ROCm) and, when `rocm-smi --showtopo` is on PATH, `xgmi_links` = the number of
+    GPU pairs it reports as XGMI-linked.  Missing pieces are simply absent; nothing here is needed by the data path."""
+    info = {}
+    try:
+        import torch
+
+        v = torch.cuda.nccl.version()
+        info["rccl_version"] = ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception:
+        pass
+    try:
+        import shutil
+        import subprocess
+
+        exe = shutil.which("rocm-smi")
+        if exe:
+            r = subprocess.run([exe, "--showtopotype"], capture_output=True, text=True, timeout=20)
+            if r.returncode == 0:
+                info["xgmi_links"] = sum(line.count("XGMI") for line in r.stdout.splitlines() if line.startswith("GPU")) // 2
+    except Exception:
+        pass
+    return info
+
+
 def max_over_ranks(seconds: float, dist=None, device=None) -> float:
     """The bench contract: a step is as slow as its slowest rank."""
     if dist is None:

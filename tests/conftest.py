@@ -41,6 +41,6 @@ def static_rules():
     tuner measured a faster one."""
     import phastft_amd as P
 
-    P.wisdom_builtin(False)
+    was = P.wisdom_builtin(False)
     yield
-    P.wisdom_builtin(True)
+    P.wisdom_builtin(was)   # what it WAS: a suite run under PHAST_BUILTIN_WISDOM=0 stays on the static rules (ADVICE r05)

@@ -119,6 +119,7 @@ def test_wisdom_store_without_a_device():
     import phastft_amd as P
 
     P.wisdom_forget()
+    was = P.wisdom_builtin(True)
     assert P.wisdom_count(0) > 100         # the built-in layer (csrc/builtin_wisdom.inc) is there without a device, too ...
     base = P.wisdom_export()
     assert base == "phastft-hip-wisdom 1 cus=0\n"   # ... and never exported: a text that carried it would pin this build's plans
@@ -151,8 +152,22 @@ def test_wisdom_store_without_a_device():
     assert "f64 c2c 22 0" not in P.wisdom_export()
     P.wisdom_forget()
     assert P.wisdom_export() == base
-    P.wisdom_builtin(True)
+    assert P.wisdom_builtin(True) is False   # the switch reports what it was ...
     assert P.wisdom_count(0) > 100 and P.wisdom_count(-1) == P.wisdom_count(0)
+    # ... an entry of a later layer shadows the built-in one of the same key, and forget() brings the built-in plan back
+    # (with one map for all layers the built-in entry was lost until the layer was switched on again)
+    n0 = P.wisdom_count(0)
+    key = next(ln for ln in open(os.path.join(ROOT, "phastft_amd", "csrc", "builtin_wisdom.inc")).read().splitlines()
+               if ln.startswith('"f'))[1:].split(" fuse=")[0].rsplit(" ", 1)[0]
+    P.wisdom_import("phastft-hip-wisdom 1 cus=256\n" + key + " heuristic fuse=0 us=1.00 heur=1.00\n")
+    assert P.wisdom_count(0) == n0 - 1 and P.wisdom_count(2) == 1
+    P.wisdom_forget()
+    assert P.wisdom_count(0) == n0 and P.wisdom_count(-1) == n0
+    # the header's arch= / lib= travel with the entries and come out again; a text without them comes out as it went in
+    P.wisdom_import("phastft-hip-wisdom 1 cus=256 arch=gfx950 lib=6\nf64 c2c 20 0 7,7,6@12,12,12:p8 fuse=0 us=22.00 heur=24.00\n")
+    assert P.wisdom_export().startswith("phastft-hip-wisdom 1 cus=256 arch=gfx950 lib=6\n")
+    P.wisdom_forget()
+    P.wisdom_builtin(was)
 
 
 def test_wisdom_file_is_loaded_at_first_use(tmp_path):
@@ -189,7 +204,7 @@ def test_wisdom_import_survives_arbitrary_text():
     body = st.lists(line, max_size=12).map("\n".join)
     text = st.tuples(st.sampled_from(["phastft-hip-wisdom 1 cus=256\n", "phastft-hip-wisdom 1\n", "phastft-hip-wisdom 2 cus=1\n", ""]), body).map("".join)
 
-    P.wisdom_builtin(False)
+    was = P.wisdom_builtin(False)
     try:
         @settings(max_examples=300, deadline=None, suppress_health_check=list(HealthCheck))
         @given(text)
@@ -210,7 +225,7 @@ def test_wisdom_import_survives_arbitrary_text():
         check()
     finally:
         P.wisdom_forget()
-        P.wisdom_builtin(True)
+        P.wisdom_builtin(was)
 
 
 def test_no_cxx_exception_crosses_the_c_abi():

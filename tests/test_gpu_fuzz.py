@@ -5,9 +5,9 @@ in double precision (forward unnormalised, reverse scaled by 1/N: algorithms/dit
 import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
+from tests import tolerances as tol
 
-F64_REL, F32_REL = 1e-13, 1e-5
+pytestmark = pytest.mark.gpu
 
 
 def _cases(seed, count):
@@ -42,14 +42,13 @@ def test_random_batches_against_pocketfft(gpu, chunk):
             planners[key] = (gpu.PlannerDit64 if dt == "f64" else gpu.PlannerDit32)(n)
         gpu.fft_dit_batched(d_re, d_im, n, gpu.Direction.Reverse if reverse else gpu.Direction.Forward, planners[key], dist=dist)
         g_re, g_im = d_re.cpu().numpy(), d_im.cpu().numpy()
-        tol = F64_REL if dt == "f64" else F32_REL
         for b in range(batch):
             sl = slice(b * dist, b * dist + n)
             z = re[sl].astype(np.float64) + 1j * im[sl].astype(np.float64)
             want = np.fft.ifft(z) if reverse else np.fft.fft(z)
             got = g_re[sl].astype(np.float64) + 1j * g_im[sl].astype(np.float64)
-            err = np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-300)
-            assert err <= tol, (k, batch, pad, dt, reverse, b, err)
+            # against float64 pocketfft nothing of the reference's needs absorbing: the measured-error formulas, every bin
+            tol.check_c(f"fuzz_c2c k={k} batch={batch} pad={pad} rev={int(reverse)} b={b}", dt, k, got, want)
         # the padding between transforms is not touched
         if pad:
             for b in range(batch - 1):
@@ -61,7 +60,8 @@ def test_random_batches_against_pocketfft(gpu, chunk):
 def test_random_real_batches_against_pocketfft(gpu, chunk):
     """R2C and C2R batches (inputs n apart, spectra n/2 + 1 apart): rfft / irfft in double precision.  The reference's
     R2C twiddles are an f64 rotation recurrence (planner.rs:120-162) -- the GPU tables are exact to rounding, so f64
-    stays within 1e-13 of pocketfft (tests/test_gpu_parity.py compares with the oracle's drift separately)."""
+    stays within the f64 formula of tests/tolerances.py of pocketfft (tests/test_gpu_parity.py compares with the oracle's drift
+    separately)."""
     import torch
 
     rng0 = np.random.default_rng(0xBEA1 + chunk)
@@ -71,7 +71,6 @@ def test_random_real_batches_against_pocketfft(gpu, chunk):
         batch = int(min(rng0.choice([1, 2, 3, 5, 8, 16, 17, 33]), max(1, (1 << 23) >> k)))
         dt = "f64" if rng0.random() < 0.6 else "f32"
         np_t = np.float64 if dt == "f64" else np.float32
-        tol = F64_REL if dt == "f64" else F32_REL
         rng = np.random.default_rng(k * 100 + batch)
         x = rng.uniform(-1, 1, batch * n).astype(np_t)
         planner = (gpu.PlannerR2c64 if dt == "f64" else gpu.PlannerR2c32)(n)
@@ -85,8 +84,7 @@ def test_random_real_batches_against_pocketfft(gpu, chunk):
         for b in range(batch):
             want = np.fft.rfft(x[b * n:(b + 1) * n].astype(np.float64))
             got = g_re[b * half:(b + 1) * half] + 1j * g_im[b * half:(b + 1) * half]
-            err = np.linalg.norm(got - want) / np.linalg.norm(want)
-            assert err <= tol, ("r2c", k, batch, dt, b, err)
+            tol.check_c(f"fuzz_r2c k={k} batch={batch} b={b}", dt, k, got, want)
         # C2R of a random Hermitian-consistent spectrum
         s_re = rng.uniform(-1, 1, batch * half).astype(np_t)
         s_im = rng.uniform(-1, 1, batch * half).astype(np_t)
@@ -98,5 +96,4 @@ def test_random_real_batches_against_pocketfft(gpu, chunk):
         for b in range(batch):
             spec = s_re[b * half:(b + 1) * half].astype(np.float64) + 1j * s_im[b * half:(b + 1) * half].astype(np.float64)
             want = np.fft.irfft(spec, n)
-            err = np.linalg.norm(g[b * n:(b + 1) * n] - want) / np.linalg.norm(want)
-            assert err <= tol, ("c2r", k, batch, dt, b, err)
+            tol.check_real(f"fuzz_c2r k={k} batch={batch} b={b}", dt, k, g[b * n:(b + 1) * n], want)

@@ -15,6 +15,8 @@ import sys
 import numpy as np
 import pytest
 
+from tests import tolerances as tol_mod
+
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -100,19 +102,14 @@ def test_c2r_fused_first_pass_non_hermitian_vs_oracle(gpu, oracle, k, batch, dt,
     inner = pl.describe()
     ms = pl.time_c2r_passes(ire[:h1], iim[:h1], torch.empty(n, dtype=tdt, device="cuda"), reps=1)
     assert len(ms) <= 3 and (len(ms) == 2 or "3p[" in inner), (ms, inner)   # no preprocess sweep: the fused path ran
-    tol_or, tol_m, tol_s = (1e-9, 1e-13, 1e-11) if dt == "f64" else (1e-5, 1e-5, 2e-3)
     for b in (0, batch - 1):
         s_re, s_im = h_re[b * h1:(b + 1) * h1], h_im[b * h1:(b + 1) * h1]
         want = np.zeros(n, ndt)
         (oracle.c2r_fft_f64 if dt == "f64" else oracle.c2r_fft_f32)(s_re.copy(), s_im.copy(), want)
         got = y[b * n:(b + 1) * n].cpu().numpy().astype(np.float64)
         model = _c2r_model_f64(s_re.astype(np.float64), s_im.astype(np.float64), n)
-        den = np.sqrt(np.sum(model ** 2))
-        rms = den / np.sqrt(n)
-        assert np.sqrt(np.sum((got - want) ** 2)) / den <= tol_or, (b, inner)
-        assert np.sqrt(np.sum((got - model) ** 2)) / den <= tol_m, (b, inner)
-        assert np.max(np.abs(got - model)) / rms <= tol_s, (b, inner)
-        assert np.max(np.abs(got - want.astype(np.float64))) / rms <= max(tol_s, 1e-7), (b, inner)
+        tol_mod.check_real("c2r_non_hermitian_vs_oracle " + inner[:60], dt, n.bit_length() - 1, got, want, against="oracle_real")
+        tol_mod.check_real("c2r_non_hermitian_vs_model " + inner[:60], dt, n.bit_length() - 1, got, model)
 
 
 # ---------------------------------------------------------------- graphs survive buffer growth
@@ -256,11 +253,8 @@ def test_r2c_f32_2p27_fused_every_output(gpu, oracle, static_rules):
     oracle.r2c_fft_f32(hx, ref_re, ref_im)
     g_re, g_im = ore.cpu().numpy().astype(np.float64), oim.cpu().numpy().astype(np.float64)
     ind = np.fft.rfft(hx.astype(np.float64))
-    den = np.sqrt(np.sum(ind.real ** 2 + ind.imag ** 2))
-    assert np.sqrt(np.sum((g_re - ind.real) ** 2 + (g_im - ind.imag) ** 2)) / den <= 1e-5
-    assert np.sqrt(np.sum((g_re - ref_re) ** 2 + (g_im - ref_im) ** 2)) / den <= 1e-5
-    rms = den / np.sqrt(h1)
-    assert max(np.max(np.abs(g_re - ind.real)), np.max(np.abs(g_im - ind.imag))) / rms <= 2e-3
+    tol_mod.check("r2c_f32_2p27_vs_rfft", "f32", 27, g_re, g_im, ind.real, ind.imag)
+    tol_mod.check("r2c_f32_2p27_vs_oracle", "f32", 27, g_re, g_im, ref_re.astype(np.float64), ref_im.astype(np.float64), against="oracle")
     assert g_im[0] == 0 and g_im[-1] == 0
     del ind, ref_re, ref_im, g_re, g_im
     back = torch.empty_like(x)
@@ -279,8 +273,9 @@ def test_real_transform_plans_every_output(gpu, k, dt, static_rules):
 
     n = 1 << k
     h1 = n // 2 + 1
-    ndt, tdt, tol, tol_bin, tol_back = ((np.float64, torch.float64, 1e-13, 1e-11, 1e-10) if dt == "f64" else
-                                        (np.float32, torch.float32, 1e-5, 2e-3, 2e-4))
+    ndt, tdt, tol, tol_bin, tol_back = ((np.float64, torch.float64, tol_mod.f64_rel(k), tol_mod.f64_bin(k), tol_mod.ROUNDTRIP_ABS["f64"])
+                                        if dt == "f64" else
+                                        (np.float32, torch.float32, tol_mod.f32_rel(k), tol_mod.f32_bin(k), 100 * tol_mod.ROUNDTRIP_ABS["f32"]))
     pl = (gpu.PlannerR2c64 if dt == "f64" else gpu.PlannerR2c32)(n)
     desc = pl.describe()
     assert "r2c-single=" in desc or "c2r-single=" in desc, desc
@@ -353,8 +348,9 @@ def test_r2c_f64_large_fused_vs_c2c_route(gpu, k, static_rules):
     gpu.fft_64_dit_with_planner(c_re, c_im, gpu.Direction.Forward, gpu.PlannerDit64(n))
     d_re, d_im = ore - c_re[:h1], oim - c_im[:h1]
     den = float((c_re[:h1] ** 2 + c_im[:h1] ** 2).sum().sqrt())
-    assert float((d_re ** 2 + d_im ** 2).sum().sqrt()) / den <= 1e-13
-    assert max(float(d_re.abs().max()), float(d_im.abs().max())) / (den / np.sqrt(h1)) <= 1e-11
+    k_ = n.bit_length() - 1   # two f64 transforms of the same data through different plans: twice the f64 gates at most
+    assert float((d_re ** 2 + d_im ** 2).sum().sqrt()) / den <= 2 * tol_mod.f64_rel(k_)
+    assert max(float(d_re.abs().max()), float(d_im.abs().max())) / (den / np.sqrt(h1)) <= 2 * tol_mod.f64_bin(k_)
     assert float(oim[0]) == 0.0 and float(oim[-1]) == 0.0
     del c_re, c_im, d_re, d_im
     back = torch.empty_like(x)
@@ -374,7 +370,7 @@ def test_one_transform_of_8192_points_runs_the_multi_pass_twin(gpu, oracle, dt, 
 
     f64 = dt == "f64"
     npdt, tdt = (np.float64, torch.float64) if f64 else (np.float32, torch.float32)
-    tol = 1e-13 if f64 else 1e-5   # the suites' F64_REL / F32_REL against the oracle
+    tol = tol_mod.rel_gate(dt, 13, against="oracle")   # tests/tolerances.py, against the oracle
     n = 1 << 13
     pl = (gpu.PlannerDit64 if f64 else gpu.PlannerDit32)(n)
     assert "one pass" in pl.describe() and " single=2p[" in pl.describe(), pl.describe()
@@ -409,7 +405,7 @@ def test_one_transform_of_8192_points_runs_the_multi_pass_twin(gpu, oracle, dt, 
     assert pl.device_bytes() > 2 * n * (8 if f64 else 4)          # the twin's scratch and tables are counted
     # the inverse through the twin: back to the input
     fft(d_re, d_im, gpu.Direction.Reverse, pl)
-    assert float((d_re.cpu() - torch.from_numpy(h_re)).abs().max()) <= (1e-13 if f64 else 1e-5)
+    assert float((d_re.cpu() - torch.from_numpy(h_re)).abs().max()) <= (tol_mod.f64_bin(13) if f64 else 5 * tol_mod.ROUNDTRIP_ABS["f32"])
     # batches: up to 128 transforms on the twin (one workgroup each would leave half the chip idle), the one-pass kernel
     # beyond -- the same transform to rounding level either way, every row of a batch the same bits
     for batch in (5, 160):
@@ -431,7 +427,7 @@ def test_one_transform_of_8192_points_runs_the_multi_pass_twin(gpu, oracle, dt, 
     ore, oim = np.zeros(m // 2 + 1, npdt), np.zeros(m // 2 + 1, npdt)
     r2c(x, ore, oim, rp)                                           # host slices
     e = np.sqrt((np.abs(ore - ref.real) ** 2 + np.abs(oim - ref.imag) ** 2).sum() / (np.abs(ref) ** 2).sum())
-    assert e <= (1e-13 if f64 else 1e-5), e
+    assert e <= tol_mod.rel_gate(dt, 14), e          # against float64 pocketfft
     t_x = torch.from_numpy(x.copy()).cuda()
     t_re, t_im = torch.zeros(m // 2 + 1, dtype=tdt, device="cuda"), torch.zeros(m // 2 + 1, dtype=tdt, device="cuda")
     r2c(t_x, t_re, t_im, rp)                                       # device pointers: the same bits
@@ -447,7 +443,7 @@ def test_one_transform_of_8192_points_runs_the_multi_pass_twin(gpu, oracle, dt, 
         got = bre.cpu().numpy().reshape(batch, -1), bim.cpu().numpy().reshape(batch, -1)
         for b in (0, batch // 2, batch - 1):
             e = np.sqrt((np.abs(got[0][b] - ref.real) ** 2 + np.abs(got[1][b] - ref.imag) ** 2).sum() / (np.abs(ref) ** 2).sum())
-            assert e <= (1e-13 if f64 else 1e-5), (batch, b, e)
+            assert e <= tol_mod.rel_gate(dt, 14), (batch, b, e)
 
 
 def test_small_twin_switch_restores_the_one_pass_kernel(gpu):
@@ -473,8 +469,9 @@ def test_batched_real_transforms_run_the_plans_ranked_for_batches(gpu, k, dt, st
     n = 1 << k
     h1 = n // 2 + 1
     batch = 1 << (26 - k)
-    ndt, tdt, tol, tol_bin, tol_back = ((np.float64, torch.float64, 1e-13, 1e-11, 1e-10) if dt == "f64" else
-                                        (np.float32, torch.float32, 1e-5, 2e-3, 2e-4))
+    ndt, tdt, tol, tol_bin, tol_back = ((np.float64, torch.float64, tol_mod.f64_rel(k), tol_mod.f64_bin(k), tol_mod.ROUNDTRIP_ABS["f64"])
+                                        if dt == "f64" else
+                                        (np.float32, torch.float32, tol_mod.f32_rel(k), tol_mod.f32_bin(k), 100 * tol_mod.ROUNDTRIP_ABS["f32"]))
     pl = (gpu.PlannerR2c64 if dt == "f64" else gpu.PlannerR2c32)(n)
     desc = pl.describe()
     assert "r2c-batch=" in desc or "c2r-batch=" in desc, desc
@@ -544,7 +541,7 @@ def test_capture_after_growth_and_after_a_plan_change_picks_a_workspace_that_fit
     ref_re, ref_im = h_re.copy(), h_im.copy()
     oracle.fft_64_dit(ref_re, ref_im, oracle.FORWARD)
     err = np.sqrt(((a1b.cpu().numpy() - ref_re) ** 2 + (b1b.cpu().numpy() - ref_im) ** 2).sum() / (ref_re ** 2 + ref_im ** 2).sum())
-    assert err <= 1e-13
+    assert err <= tol_mod.f64_rel(18)
     # the first two graphs still replay (their workspaces and tables were never freed)
     a1.copy_(torch.from_numpy(h_re)); b1.copy_(torch.from_numpy(h_im))
     g1.replay()
