@@ -209,12 +209,13 @@ def roofline_of(pass_ms, alg_bytes, names=None, plan_used="", traffic_key=None, 
 
 def replay_stats(torch, run, steps: int, first_ms: float, refill=None, extra: int = 2):
     """"median and min".  `first_ms` is the contract's timed region (EXACTLY K steps, once); `extra` more
-    K-step regions are timed after it (ring re-filled before each when the steps work in place) -> per-step min / median
-    over the 1 + extra regions."""
+    K-step regions are timed after it -> per-step min / median over the 1 + extra regions.  The regions run back to back on
+    the same ring WITHOUT a refill in between (in-place steps transform their buffers again: values grow by <= N per step,
+    three regions stay far from overflow in either type) -- a refill's write-back tail would run into the timed region and
+    the regions would not start from the state the first one started from (the untimed replay before it)."""
+    del refill
     per = [first_ms / steps]
     for _ in range(extra):
-        if refill is not None:
-            refill()
         torch.cuda.synchronize()
         per.append(event_ms(torch, run) / steps)
     per.sort()

@@ -20,6 +20,24 @@ template <> struct Cx<float> { using type = float2; };
 template <> struct Cx<double> { using type = double2; };
 template <typename T> using cx_t = typename Cx<T>::type;
 
+// ---- the register type of a lane: one scalar, or (f32 wave / four-wave tiles, round 6) TWO ADJACENT COLUMNS packed in 8 bytes.
+// A lane of an f32 wave tile holds float2 column pairs, so that its rows are 128 bytes per plane with 8-byte accesses and the
+// f64 tiles' lane layout, exchanges and instruction count carry over unchanged (the arithmetic is elementwise on the pair;
+// step twiddles are scalars, broadcast).  Arithmetic helpers below are written for either: constants and table entries are
+// scalars (scalar_t<V>), data are V.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <typename V> struct ScalarOf { using type = V; static constexpr int W = 1; };
+template <> struct ScalarOf<f32x2> { using type = float; static constexpr int W = 2; };
+template <typename V> using scalar_t = typename ScalarOf<V>::type;
+template <> struct Cx<f32x2> { using type = float2; };  // twiddle tables hold scalar complex numbers
+template <typename T> struct LaneVec { using type = T; };
+template <> struct LaneVec<float> { using type = f32x2; };
+template <typename T> using lane_vec_t = typename LaneVec<T>::type;  // double -> double, float -> f32x2
+template <typename V> PHAST_HD V splat(scalar_t<V> s) {
+    if constexpr (ScalarOf<V>::W == 1) return s;
+    else return V{s, s};
+}
+
 // compile-time loop: f(std::integral_constant<int, I>{}) for I in [B, E)
 template <int B, int E, typename F> PHAST_HD void static_for(F &&f) {
     if constexpr (B < E) {
@@ -39,6 +57,13 @@ constexpr int ilog2_c(int x) { return x <= 1 ? 0 : 1 + ilog2_c(x >> 1); }
 template <typename T> PHAST_HD void cmul(T &re, T &im, T wr, T wi) {
     T r = re * wr - im * wi;
     T i = re * wi + im * wr;
+    re = r;
+    im = i;
+}
+// ... a packed pair of columns times ONE scalar twiddle
+PHAST_HD void cmul(f32x2 &re, f32x2 &im, float wr, float wi) {
+    f32x2 r = re * wr - im * wi;
+    f32x2 i = re * wi + im * wr;
     re = r;
     im = i;
 }
@@ -88,7 +113,7 @@ template <typename T, int P, int G, typename F> PHAST_HD void tw_progression(T b
             ai[S + I] = ar[I] * qi + ai[I] * qr;
         });
         const T t = qr * qr - qi * qi;
-        qi = (T)2 * (qr * qi);
+        qi = (qr * qi) * (scalar_t<T>)2;
         qr = t;
     });
     static_for<0, P / G>([&](auto h) {

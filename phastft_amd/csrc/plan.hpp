@@ -150,7 +150,7 @@ struct PassGeom {
     unsigned lr = 0, lc = 0;
     unsigned lp = 4;  // log2(points per thread): 4 = throughput tiles, 3 = latency tiles (twice the waves)
     bool wave = false;  // one wave per 64-row x 128-byte tile, exchange by cross-lane swaps (wave_fft.hpp)
-    bool quad = false;  // four waves per 256 x 16 tile, one LDS + one cross-lane exchange (quad_fft.hpp; f64, later passes)
+    bool quad = false;  // four waves per 256-row x 128-byte tile, one LDS + one cross-lane exchange (quad_fft.hpp; later passes)
     bool pre_tw = false, transpose = false;
     unsigned log_s_in = 0, out_lo_bits = 0, tw_bits = 1;
     unsigned long long out_s1 = 0, out_s2 = 0, out_row_stride = 0;
@@ -409,7 +409,7 @@ inline bool make_passes(unsigned L, const std::vector<unsigned> &lrs, const std:
         ps[i].lr = lrs[i];
         ps[i].lc = tl - lrs[i];
         ps[i].wave = want_wave && lrs[i] == 6 && tl == (elem_bytes == 8 ? 10u : 11u);
-        ps[i].quad = want_wave && elem_bytes == 8 && lrs[i] == 8 && tl == 12 && i > 0;
+        ps[i].quad = want_wave && lrs[i] == 8 && tl == (elem_bytes == 8 ? 12u : 13u) && i > 0;
         ps[i].lp = ps[i].wave ? (elem_bytes == 8 ? 4u : 5u) : ps[i].quad ? 4u : lp;
         if (!ps[i].wave && !ps[i].quad && !shape_exists(lrs[i], tl - lrs[i], lp, elem_bytes)) return false;
     }
@@ -601,15 +601,8 @@ inline double plan_model_us(const std::vector<PassGeom> &ps, unsigned L, size_t 
 inline void enumerate_plans(unsigned L, size_t elem_bytes, size_t batch, unsigned tl_lo, unsigned tl_hi, std::vector<PlanSpec> &out) {
     out.clear();
     if (L < kTwinMinLog || L > 31) return;
-    const unsigned lps64[] = {3, 4, 5, 3 | kWaveTiles, 4 | kWaveTiles};
-#ifdef PHAST_EXPERIMENTAL_WAVE_F32  // (build.py --experimental: the f32 wave tiles are candidates too)
-    const unsigned lps32[] = {3, 4, 5, 3 | kWaveTiles, 4 | kWaveTiles};
+    const unsigned lps[] = {3, 4, 5, 3 | kWaveTiles, 4 | kWaveTiles};
     const unsigned n_lps = 5;
-#else
-    const unsigned lps32[] = {3, 4, 5};
-    const unsigned n_lps = elem_bytes == 8 ? 5 : 3;
-#endif
-    const unsigned *lps = elem_bytes == 8 ? lps64 : lps32;
     std::vector<std::pair<double, PlanSpec>> scored;
     std::vector<PassGeom> geo;
     for (unsigned np = 2; np <= 3; ++np) {
@@ -623,7 +616,7 @@ inline void enumerate_plans(unsigned L, size_t elem_bytes, size_t batch, unsigne
                     bool cols_ok = true, wave_shaped = false;
                     for (unsigned i = 0; i < np; ++i) {
                         if (tl[i] < lr[i] + 2 || tl[i] > lr[i] + 7) cols_ok = false;
-                        if ((lr[i] == 6 && tl[i] == (elem_bytes == 8 ? 10u : 11u)) || (elem_bytes == 8 && lr[i] == 8 && tl[i] == 12 && i > 0))
+                        if ((lr[i] == 6 && tl[i] == (elem_bytes == 8 ? 10u : 11u)) || (lr[i] == 8 && tl[i] == (elem_bytes == 8 ? 12u : 13u) && i > 0))
                             wave_shaped = true;
                     }
                     for (unsigned k = 0; k < n_lps && cols_ok; ++k) {

@@ -69,16 +69,12 @@ template <> struct Types<double> {
 template <typename T> static hipError_t launch_wave(bool transpose, hipStream_t s, const TileArgs &a, bool q, int *b, size_t *l,
                                                     hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
     if constexpr (sizeof(T) == 8) return launch_wave_f64(transpose, s, a, q, b, l, e0, e1);
-#ifdef PHAST_EXPERIMENTAL_WAVE_F32
     else return launch_wave_f32(transpose, s, a, q, b, l, e0, e1);
-#else
-    else return hipErrorInvalidValue;  // the f32 wave tiles are not in the product library (build.py --experimental)
-#endif
 }
 template <typename T> static hipError_t launch_quad(unsigned grid, hipStream_t s, const TileArgs &a, bool q, int *b, size_t *l,
                                                     hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
     if constexpr (sizeof(T) == 8) return launch_quad_f64(grid, s, a, q, b, l, e0, e1);
-    else return hipErrorInvalidValue;
+    else return launch_quad_f32(grid, s, a, q, b, l, e0, e1);
 }
 template <> struct Types<float> {
     static hipError_t launch_a(int lr, int lc, int lp, unsigned g, hipStream_t s, const TileArgs &a, bool q, int *b,

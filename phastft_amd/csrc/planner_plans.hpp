@@ -104,11 +104,6 @@ template <typename T> int Planner<T>::set_plan(const std::vector<unsigned> &lrs,
 template <typename T> int Planner<T>::build_plan(const PlanSpec &spec, std::vector<PassDesc> &ps, size_t *scratch_need) const {
     std::vector<PassGeom> geo;
     if (!make_passes(log_n, spec.lrs(), spec.tls(), geo, spec.lp, sizeof(T))) return PHAST_ERR_INVALID_ARG;
-#ifndef PHAST_EXPERIMENTAL_WAVE_F32
-    if (sizeof(T) == 4)  // f32 wave tiles: measured, slower than the generic tiles everywhere, built with --experimental only
-        for (const PassGeom &g : geo)
-            if (g.wave) return PHAST_ERR_INVALID_ARG;
-#endif
     PHAST_ON_DEVICE(device);
     ps.assign(geo.size(), PassDesc());
     for (size_t i = 0; i < geo.size(); ++i) static_cast<PassGeom &>(ps[i]) = geo[i];

@@ -46,8 +46,13 @@ template <typename T, int R, int OFF, int STRIDE, int P> PHAST_HD void fft_reg_d
 
 template <typename T> struct QuadBody {
     using cx = cx_t<T>;
-    static constexpr int LR = 8, LC = 4, ROWS = 256, COLS = 16, P = 16, WAVES = 4, NT = 256;
-    static constexpr int EXCH = P * NT;  // elements per plane of the exchange buffer [register][wave][lane]
+    // the register type of a lane: one f64, or (round 6) two adjacent f32 columns in 8 bytes -- wave_fft.hpp: WaveBody::V.  The
+    // f32 tile is 256 rows x 32 columns (8192 points, 128-byte rows per plane) on the same four waves, 32 points per lane.
+    using V = lane_vec_t<T>;
+    static constexpr int VW = ScalarOf<V>::W, LV = VW == 2 ? 1 : 0;
+    static constexpr int LR = 8, LCL = 4, LC = LCL + LV, ROWS = 256, COLS = 1 << LC, P = 16, WAVES = 4, NT = 256;
+    static constexpr int EXCH = P * NT;  // registers (V) per plane of the exchange buffer [register][wave][lane]
+    typedef V VU __attribute__((aligned(sizeof(T))));  // a register's worth in the caller's memory: element alignment only
     static constexpr int TWQ = 128;      // staged entries of the step-twiddle table: W_256^j (j < 64), then W_64^j (j < 64)
 #ifndef PHAST_WQ_NT_LOADS
 #define PHAST_WQ_NT_LOADS 1
@@ -55,19 +60,19 @@ template <typename T> struct QuadBody {
 #ifndef PHAST_WQ_NT_STORES
 #define PHAST_WQ_NT_STORES 1
 #endif
-    static constexpr bool NT_LOAD = PHAST_WQ_NT_LOADS && COLS * sizeof(T) >= 128;
-    static constexpr bool NT_STORE = PHAST_WQ_NT_STORES && COLS * sizeof(T) >= 128;
+    static constexpr bool NT_LOAD = PHAST_WQ_NT_LOADS, NT_STORE = PHAST_WQ_NT_STORES;
 
     struct Regs {
-        T re[P], im[P];
+        V re[P], im[P];
         unsigned xform, g0;
     };
 
     static size_t lds_bytes(unsigned tw_bits) {
-        return (size_t)(3u << tw_bits) * sizeof(cx) + TWQ * sizeof(cx) + (size_t)2 * EXCH * sizeof(T);
+        return (size_t)(3u << tw_bits) * sizeof(cx) + TWQ * sizeof(cx) + (size_t)2 * EXCH * sizeof(V);
     }
 
-    PHAST_HD static int col_of(int lane) { return lane & 15; }
+    PHAST_HD static int lcol_of(int lane) { return lane & 15; }
+    PHAST_HD static int col_of(int lane) { return (lane & 15) << LV; }  // first (scalar) column of the lane
     PHAST_HD static int tau_of(int lane) { return lane >> 4; }
 
     PHAST_HD static void locate(const TileArgs &a, unsigned t, Regs &r) {  // as TileBody::locate
@@ -88,8 +93,8 @@ template <typename T> struct QuadBody {
         static_for<0, P>([&](auto q) {
             constexpr int Q = decltype(q)::value;
             const size_t urow = (size_t)(64 * (Q >> 2) + 16 * (Q & 3)) * a.in_row_stride;
-            const T *qr = reinterpret_cast<const T *>(reinterpret_cast<const char *>(pr + urow) + vbyte);
-            const T *qi = reinterpret_cast<const T *>(reinterpret_cast<const char *>(pi + urow) + vbyte);
+            const VU *qr = reinterpret_cast<const VU *>(reinterpret_cast<const char *>(pr + urow) + vbyte);
+            const VU *qi = reinterpret_cast<const VU *>(reinterpret_cast<const char *>(pi + urow) + vbyte);
             if constexpr (NT_LOAD) {
                 r.re[Q] = __builtin_nontemporal_load(qr);
                 r.im[Q] = __builtin_nontemporal_load(qi);
@@ -102,11 +107,24 @@ template <typename T> struct QuadBody {
 
     // W^(n lo), n = (4 w + tau) + 16 (jj + 4 n_hi): base W^((4w+tau) lo) times the power (jj + 4 n_hi) of D = W^(16 lo)
     PHAST_HD static void pre_twiddle(const TileArgs &a, const cx *tw3, int wave, int lane, Regs &r) {
-        const unsigned lo = ((r.g0 + (unsigned)col_of(lane)) >> a.tw_shift) & a.tw_mask;
-        T br, bi, dr, di;
-        tw3_lookup<T>(tw3, a.tw_bits, (unsigned)(4 * wave + tau_of(lane)) * lo, br, bi);
-        tw3_lookup<T>(tw3, a.tw_bits, 16u * lo, dr, di);
-        tw_progression<T, P, 4>(br, bi, dr, di, [&](auto q, T wr, T wi) {  // register q = jj + 4 n_hi holds row 16 q + (4 wave + tau)
+        V br, bi, dr, di;
+        if constexpr (VW == 1) {
+            const unsigned lo = ((r.g0 + (unsigned)col_of(lane)) >> a.tw_shift) & a.tw_mask;
+            tw3_lookup<T>(tw3, a.tw_bits, (unsigned)(4 * wave + tau_of(lane)) * lo, br, bi);
+            tw3_lookup<T>(tw3, a.tw_bits, 16u * lo, dr, di);
+        } else {  // per column of the pair
+            T b_r[2], b_i[2], d_r[2], d_i[2];
+            static_for<0, 2>([&](auto e) {
+                const unsigned lo = ((r.g0 + (unsigned)col_of(lane) + (unsigned)decltype(e)::value) >> a.tw_shift) & a.tw_mask;
+                tw3_lookup<T>(tw3, a.tw_bits, (unsigned)(4 * wave + tau_of(lane)) * lo, b_r[e], b_i[e]);
+                tw3_lookup<T>(tw3, a.tw_bits, 16u * lo, d_r[e], d_i[e]);
+            });
+            br = V{b_r[0], b_r[1]};
+            bi = V{b_i[0], b_i[1]};
+            dr = V{d_r[0], d_r[1]};
+            di = V{d_i[0], d_i[1]};
+        }
+        tw_progression<V, P, 4>(br, bi, dr, di, [&](auto q, V wr, V wi) {  // register q = jj + 4 n_hi holds row 16 q + (4 wave + tau)
             cmul(r.re[decltype(q)::value], r.im[decltype(q)::value], wr, wi);
         });
     }
@@ -114,7 +132,7 @@ template <typename T> struct QuadBody {
     // steps 1 and 2 (both in registers) with their twiddles; twq = [W_256^j | W_64^j], j < 64 each
     PHAST_HD static void steps12(const cx *twq, int wave, int lane, Regs &r) {
         const unsigned m = (unsigned)(4 * wave + tau_of(lane));  // the part of n_lo that lives in (wave, lane)
-        static_for<0, 4>([&](auto jj) { fft_reg_dif_s<T, 4, decltype(jj)::value, 4, P>(r.re, r.im); });
+        static_for<0, 4>([&](auto jj) { fft_reg_dif_s<V, 4, decltype(jj)::value, 4, P>(r.re, r.im); });
         static_for<1, 4>([&](auto s) {  // k_a = bitrev2(s) != 0: x W_256^((16 jj + m) k_a) = W_16^(jj k_a) W_256^(m k_a)
             constexpr int KA = bitrev_c(decltype(s)::value, 2);
             const cx w = twq[m * KA];
@@ -122,14 +140,14 @@ template <typename T> struct QuadBody {
                 constexpr int Q = decltype(jj)::value + 4 * decltype(s)::value;
                 cmul(r.re[Q], r.im[Q], w.x, w.y);
                 constexpr int J = decltype(jj)::value * KA;  // W_16^J, J <= 9: W_16^(J) = -W_16^(J - 8) beyond the half turn
-                mul_w<T, 16, J % 8>(r.re[Q], r.im[Q]);
+                mul_w<V, 16, J % 8>(r.re[Q], r.im[Q]);
                 if constexpr (J >= 8) {
                     r.re[Q] = -r.re[Q];
                     r.im[Q] = -r.im[Q];
                 }
             });
         });
-        static_for<0, 4>([&](auto s) { fft_reg_dif<T, 4, 4 * decltype(s)::value, P>(r.re, r.im); });
+        static_for<0, 4>([&](auto s) { fft_reg_dif<V, 4, 4 * decltype(s)::value, P>(r.re, r.im); });
         static_for<1, 4>([&](auto t) {  // k_b = bitrev2(t): x W_64^(m k_b)
             constexpr int KB = bitrev_c(decltype(t)::value, 2);
             const cx w = twq[64 + m * KB];
@@ -147,7 +165,7 @@ template <typename T> struct QuadBody {
     }
     // step 3 (radix-4 over the source wave) and its twiddle W_16^(tau k_c) = W_64^(4 tau k_c)
     PHAST_HD static void step3(const cx *twq, int lane, Regs &r) {
-        static_for<0, 4>([&](auto s) { fft_reg_dif<T, 4, 4 * decltype(s)::value, P>(r.re, r.im); });
+        static_for<0, 4>([&](auto s) { fft_reg_dif<V, 4, 4 * decltype(s)::value, P>(r.re, r.im); });
         const unsigned tau = (unsigned)tau_of(lane);
         static_for<1, 4>([&](auto u) {
             constexpr int KC = bitrev_c(decltype(u)::value, 2);
@@ -159,7 +177,7 @@ template <typename T> struct QuadBody {
         });
     }
     PHAST_HD static void step4(Regs &r) {
-        static_for<0, 4>([&](auto u) { fft_reg_dif_s<T, 4, decltype(u)::value, 4, P>(r.re, r.im); });
+        static_for<0, 4>([&](auto u) { fft_reg_dif_s<V, 4, decltype(u)::value, 4, P>(r.re, r.im); });
     }
 
     PHAST_HD static unsigned br2(unsigned v) { return ((v & 1u) << 1) | (v >> 1); }
@@ -177,14 +195,14 @@ template <typename T> struct QuadBody {
         const T scale = (T)a.scale;
         static_for<0, P>([&](auto Q) {
             const size_t at = base + (size_t)krow_const<decltype(Q)::value>() * a.out_row_stride;
-            T re = r.re[Q], im = r.im[Q];
+            V re = r.re[Q], im = r.im[Q];
             if constexpr (SCALE) {
                 re *= scale;
                 im *= scale;
             }
             if constexpr (!PAIRS) {
-                T *qr = reinterpret_cast<T *>(reinterpret_cast<char *>(reinterpret_cast<T *>(a.out_re) + at) + vbyte);
-                T *qi = reinterpret_cast<T *>(reinterpret_cast<char *>(reinterpret_cast<T *>(a.out_im) + at) + vbyte);
+                VU *qr = reinterpret_cast<VU *>(reinterpret_cast<char *>(reinterpret_cast<T *>(a.out_re) + at) + vbyte);
+                VU *qi = reinterpret_cast<VU *>(reinterpret_cast<char *>(reinterpret_cast<T *>(a.out_im) + at) + vbyte);
                 if constexpr (NT_STORE) {
                     __builtin_nontemporal_store(re, qr);
                     __builtin_nontemporal_store(im, qi);
@@ -193,10 +211,22 @@ template <typename T> struct QuadBody {
                     *qi = im;
                 }
             } else {
-                cx v;
-                v.x = a.out_interleaved == 2 ? im : re;
-                v.y = a.out_interleaved == 2 ? re : im;
-                *reinterpret_cast<cx *>(reinterpret_cast<char *>(reinterpret_cast<cx *>(a.out_re) + at) + 2u * vbyte) = v;
+                const V x = a.out_interleaved == 2 ? im : re, y = a.out_interleaved == 2 ? re : im;
+                cx *q = reinterpret_cast<cx *>(reinterpret_cast<char *>(reinterpret_cast<cx *>(a.out_re) + at) + 2u * vbyte);
+                if constexpr (VW == 1) {
+                    cx v;
+                    v.x = x;
+                    v.y = y;
+                    *q = v;
+                } else {
+                    cx v0, v1;
+                    v0.x = x[0];
+                    v0.y = y[0];
+                    v1.x = x[1];
+                    v1.y = y[1];
+                    q[0] = v0;
+                    q[1] = v1;
+                }
             }
         });
     }
@@ -238,8 +268,9 @@ template <typename T, bool ONE> __global__ void __launch_bounds__(256) quad_fft_
     using cx = cx_t<T>;
     pin_tile_args(a);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    T *ex_re = reinterpret_cast<T *>(smem);
-    T *ex_im = ex_re + Body::EXCH;
+    using V = typename Body::V;
+    V *ex_re = reinterpret_cast<V *>(smem);
+    V *ex_im = ex_re + Body::EXCH;
     cx *l_tw3 = reinterpret_cast<cx *>(ex_im + Body::EXCH);
     cx *l_twq = l_tw3 + (3u << a.tw_bits);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -278,7 +309,7 @@ template <typename T, bool ONE> __global__ void __launch_bounds__(256) quad_fft_
             r.im[Q] = ex_im[Body::template raddr<decltype(Q)::value>(wave, lane)];
         });
         Body::step3(l_twq, lane, r);
-        quad_lane_exchange<T>(r.re, r.im);
+        quad_lane_exchange<V>(r.re, r.im);
         Body::step4(r);
         Body::store(a, wave, lane, r);
         if constexpr (ONE) break;
@@ -307,6 +338,13 @@ hipError_t launch_quad_inst(unsigned grid, hipStream_t stream, const TileArgs &a
         if (blocks_per_cu) *blocks_per_cu = (int)((160 * 1024) / lds) < 2 ? (int)((160 * 1024) / lds) : 2;
         return hipSuccess;
     }
+    {  // the lane's part of every address is a 32-bit byte offset; the packed (f32) tile's two columns are adjacent in memory
+        const unsigned long long esz = sizeof(T) * (a.out_interleaved ? 2u : 1u);
+        if (((unsigned long long)4 * a.in_row_stride + Body::COLS) * sizeof(T) >= (1ull << 32) ||
+            ((unsigned long long)Body::COLS * a.out_s1 + 4ull * a.out_row_stride) * esz >= (1ull << 32))
+            return hipErrorInvalidValue;
+        if (Body::VW == 2 && a.out_s1 != 1) return hipErrorInvalidValue;
+    }
     if (ev_start && ev_stop)
         hipExtLaunchKernelGGL(kern, dim3(grid), dim3(Body::NT), (uint32_t)lds, stream, ev_start, ev_stop, 0, a);
     else
@@ -318,7 +356,7 @@ hipError_t launch_quad_inst(unsigned grid, hipStream_t stream, const TileArgs &a
 template <typename T> void emulate_quad_pass(const TileArgs &a) {
     using Body = QuadBody<T>;
     using Regs = typename Body::Regs;
-    std::vector<T> ex_re(Body::EXCH), ex_im(Body::EXCH);
+    std::vector<typename Body::V> ex_re(Body::EXCH), ex_im(Body::EXCH);
     std::vector<Regs> regs(Body::NT), nxt(Body::NT);
     const cx_t<T> *tw3 = reinterpret_cast<const cx_t<T> *>(a.tw3), *twq = reinterpret_cast<const cx_t<T> *>(a.twr);
     for (unsigned t = 0; t < a.tiles_total; ++t) {
@@ -343,7 +381,7 @@ template <typename T> void emulate_quad_pass(const TileArgs &a) {
         }
         // lane bits (5, 4) <-> register bits (3, 2): new[lane (b5 b4)][reg (s1 s0 | u)] = old[lane (s1 s0)][reg (b5 b4 | u)]
         for (int tid = 0; tid < Body::NT; ++tid) {
-            const int lane = tid & 63, wave = tid >> 6, col = lane & 15, b = lane >> 4;
+            const int lane = tid & 63, wave = tid >> 6, col = Body::lcol_of(lane), b = lane >> 4;
             nxt[tid] = regs[tid];
             for (int q = 0; q < 16; ++q) {
                 const int src = wave * 64 + (((q >> 2) << 4) | col), src_reg = (b << 2) | (q & 3);

@@ -97,12 +97,14 @@ hipError_t launch_tile_f32_bc(int lr, int lc, int lp, unsigned grid, hipStream_t
 hipError_t launch_wave_f64(bool transpose, hipStream_t s, const TileArgs &a, bool q, int *b, size_t *l,
                            hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 
-// defined in wave_f32.hip: the f32 twin, one wave per 64 x 32 tile
+// defined in wave_f32.hip: the f32 wave tile, one wave per 64 x 32 tile, a lane holds float2 column pairs (round 6)
 hipError_t launch_wave_f32(bool transpose, hipStream_t s, const TileArgs &a, bool q, int *b, size_t *l,
                            hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 
-// defined in quad_f64.hip: four waves per 256 x 16 tile, pre-twiddle passes (quad_fft.hpp)
+// defined in quad_f64.hip / quad_f32.hip: four waves per 256 x 16 (f32: 256 x 32) tile, pre-twiddle passes (quad_fft.hpp)
 hipError_t launch_quad_f64(unsigned grid, hipStream_t s, const TileArgs &a, bool q, int *b, size_t *l,
+                           hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+hipError_t launch_quad_f32(unsigned grid, hipStream_t s, const TileArgs &a, bool q, int *b, size_t *l,
                            hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 
 }  // namespace phast

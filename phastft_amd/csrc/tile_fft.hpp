@@ -59,8 +59,9 @@ template <typename T> PHAST_HD constexpr T cos_pi16(int a) {
                                   0.0L};
     return a <= 8 ? (T)c[a] : (T)-c[16 - a];
 }
-template <typename T, int N, int J> PHAST_HD void mul_w(T &re, T &im) {
-    constexpr T S = (T)0.70710678118654752440L;
+template <typename T, int N, int J> PHAST_HD void mul_w(T &re, T &im) {  // T: a scalar or a packed pair (common.hpp: f32x2)
+    using Sc = scalar_t<T>;
+    constexpr Sc S = (Sc)0.70710678118654752440L;
     if constexpr (J == 0) {
     } else if constexpr (4 * J == N) {  // -i
         T t = re;
@@ -79,8 +80,8 @@ template <typename T, int N, int J> PHAST_HD void mul_w(T &re, T &im) {
     } else {
         static_assert(N == 16 || N == 32, "general twiddle only for N = 16, 32");
         constexpr int A = J * (32 / N);                 // angle in units of pi/16, 0 < A < 16
-        constexpr T c = cos_pi16<T>(A);
-        constexpr T s = cos_pi16<T>(A <= 8 ? 8 - A : A - 8);  // sin(A pi/16) = cos((8 - A) pi/16) > 0
+        constexpr Sc c = cos_pi16<Sc>(A);
+        constexpr Sc s = cos_pi16<Sc>(A <= 8 ? 8 - A : A - 8);  // sin(A pi/16) = cos((8 - A) pi/16) > 0
         T r = re * c + im * s;
         T i = im * c - re * s;
         re = r;

@@ -1,5 +1,5 @@
-// wave_f32.hip -- the f32 wave-tile pass kernels (wave_fft.hpp: 64 rows x 32 columns, 32 points per lane): first pass
-// (transposing) and pre-twiddle passes.
+// wave_f32.hip -- the f32 wave-tile pass kernels (wave_fft.hpp: 64 rows x 32 columns, a lane holds float2 column pairs): first
+// pass (transposing) and pre-twiddle passes.
 #include "tile_dispatch.hpp"
 #include "wave_fft.hpp"
 

@@ -34,42 +34,58 @@
 
 namespace phast {
 
-template <typename T, bool PRE_TW, bool TRANSPOSE> struct WaveBody {
-    using cx = cx_t<T>;
-    static constexpr int LR = 6, LC = sizeof(T) == 8 ? 4 : 5;  // 128-byte rows
-    static constexpr int LT = 6 - LC, LP = 6 - LT;               // lanes per column 2^LT, points per lane 2^LP
-    static constexpr int ROWS = 64, COLS = 1 << LC, P = 1 << LP, TAUS = 1 << LT;
-    static_assert(P == COLS, "the transposing buffer of pass A hands register Q column Q");
-// tiles (= waves) per workgroup: 4 measured best for the single 2^20 transform (26.5 us; 27.2 / 27.5 / 29.2 at 1 / 2 / 8)
+// tiles (= waves) per workgroup: 4 measured best for the single 2^20 f64 transform (26.5 us; 27.2 / 27.5 / 29.2 at 1 / 2 / 8);
+// the f32 tile is twice the points: 2 per workgroup keeps one workgroup per CU at 2^20
 #ifndef PHAST_WAVE_TILES_PER_BLOCK
 #define PHAST_WAVE_TILES_PER_BLOCK 4
 #endif
-    static constexpr int WAVES = PHAST_WAVE_TILES_PER_BLOCK, NT = 64 * WAVES;  // tiles (= waves) per workgroup
+#ifndef PHAST_WAVE_TILES_PER_BLOCK_F32
+#define PHAST_WAVE_TILES_PER_BLOCK_F32 2
+#endif
+template <typename T> constexpr int wave_block_threads() { return 64 * (sizeof(T) == 4 ? PHAST_WAVE_TILES_PER_BLOCK_F32 : PHAST_WAVE_TILES_PER_BLOCK); }
+
+template <typename T, bool PRE_TW, bool TRANSPOSE> struct WaveBody {
+    using cx = cx_t<T>;
+    // The register type of a lane (common.hpp): one f64, or -- round 6 -- TWO ADJACENT f32 COLUMNS in 8 bytes.  Either way a lane
+    // moves 8 bytes per access, a tile row is 128 bytes per plane, lane = (16 lane-columns, 4 taus) and a lane holds 16 registers
+    // per plane: the f32 tile is the f64 tile with every register carrying a column pair (64 x 32 = 2048 points per wave, 32
+    // per lane).  Round 3's f32 twin (32 lane-columns of 4 bytes, 2 taus, 32 registers: 64 four-byte loads and 142 VGPRs per
+    // lane, profiles/r03_sweep_wave_f32.log) is replaced by this.
+    using V = lane_vec_t<T>;
+    static constexpr int VW = ScalarOf<V>::W, LV = VW == 2 ? 1 : 0;
+    static constexpr int LR = 6, LCL = 4;             // 64 rows, 16 lane-columns
+    static constexpr int LC = LCL + LV;               // log2 of the tile's (scalar) columns: 16 f64 / 32 f32
+    static constexpr int LT = 2, LP = 4;              // lanes per column 2^LT, registers per lane and plane 2^LP
+    static constexpr int ROWS = 64, COLS = 1 << LC, P = 1 << LP, TAUS = 1 << LT;
+    static constexpr int NT = wave_block_threads<T>(), WAVES = NT / 64;  // tiles (= waves) per workgroup
     static constexpr int CS = ROWS + 1;               // column pitch of the transposing buffer: odd => conflict-free
-    static constexpr int XP = TRANSPOSE ? COLS * CS : 0;  // elements per plane per wave
+    static constexpr int XP = TRANSPOSE ? COLS * CS : 0;  // scalar elements per plane per wave
 #ifndef PHAST_WQ_NT_LOADS
 #define PHAST_WQ_NT_LOADS 1
 #endif
 #ifndef PHAST_WQ_NT_STORES
 #define PHAST_WQ_NT_STORES 1
 #endif
-    static constexpr bool NT_LOAD = PHAST_WQ_NT_LOADS && COLS * sizeof(T) >= 128;
-    static constexpr bool NT_STORE = PHAST_WQ_NT_STORES && COLS * sizeof(T) >= 128;
+    static constexpr bool NT_LOAD = PHAST_WQ_NT_LOADS, NT_STORE = PHAST_WQ_NT_STORES;
+    // a register's worth in the caller's memory: aligned to ONE ELEMENT only (`&mut v[1..]` is a legal slice: no more than
+    // element alignment may be assumed of a caller's pointer; the hardware takes unaligned dword-multiple accesses)
+    typedef V VU __attribute__((aligned(sizeof(T))));
 
     struct Regs {
-        T re[P], im[P];
+        V re[P], im[P];
         unsigned xform, g0;
     };
 
     static size_t lds_bytes(unsigned tw_bits) {
-        (void)tw_bits;  // the inter-pass tables are read from global memory (six entries per lane)
+        (void)tw_bits;  // the inter-pass tables are read from global memory (six entries per lane and column)
         return (size_t)WAVES * (64 * sizeof(cx) + (size_t)2 * XP * sizeof(T));  // per wave: W_64 table, transposing buffer
     }
 
-    PHAST_HD static int col_of(int lane) { return lane & (COLS - 1); }
-    PHAST_HD static int tau_of(int lane) { return lane >> LC; }
+    PHAST_HD static int lcol_of(int lane) { return lane & 15; }
+    PHAST_HD static int col_of(int lane) { return (lane & 15) << LV; }  // first (scalar) column of the lane
+    PHAST_HD static int tau_of(int lane) { return lane >> LCL; }
 
-    // tile index -> (transform, first column); XCD-aware: workgroup b (on XCD b % 8) owns 4 adjacent tiles and each XCD
+    // tile index -> (transform, first column); XCD-aware: workgroup b (on XCD b % 8) owns WAVES adjacent tiles and each XCD
     // gets one contiguous run of workgroups (cf. TileBody::locate)
     PHAST_HD static void locate(const TileArgs &a, unsigned block, unsigned blocks_total, unsigned wave, Regs &r) {
         const unsigned b = ((blocks_total & 7u) == 0u) ? (block & 7u) * (blocks_total >> 3) + (block >> 3) : block;
@@ -94,8 +110,8 @@ template <typename T, bool PRE_TW, bool TRANSPOSE> struct WaveBody {
             const unsigned vbyte = voff * (unsigned)sizeof(T);
             static_for<0, P>([&](auto j) {
                 const size_t urow = (size_t)(decltype(j)::value * TAUS) * a.in_row_stride;
-                const T *qr = reinterpret_cast<const T *>(reinterpret_cast<const char *>(pr + urow) + vbyte);
-                const T *qi = reinterpret_cast<const T *>(reinterpret_cast<const char *>(pi + urow) + vbyte);
+                const VU *qr = reinterpret_cast<const VU *>(reinterpret_cast<const char *>(pr + urow) + vbyte);
+                const VU *qi = reinterpret_cast<const VU *>(reinterpret_cast<const char *>(pi + urow) + vbyte);
                 if constexpr (NT_LOAD) {
                     r.re[j] = __builtin_nontemporal_load(qr);
                     r.im[j] = __builtin_nontemporal_load(qi);
@@ -104,35 +120,58 @@ template <typename T, bool PRE_TW, bool TRANSPOSE> struct WaveBody {
                     r.im[j] = *qi;
                 }
             });
-        } else {  // first pass of an interleaved / real transform: (re, im) or (im, re) pairs
+        } else {  // first pass of an interleaved / real transform: (re, im) or (im, re) pairs, VW of them side by side
             const cx *pz = reinterpret_cast<const cx *>(a.in_re) + ubase;
             static_for<0, P>([&](auto j) {
                 const size_t urow = (size_t)(decltype(j)::value * TAUS) * a.in_row_stride;
-                cx v = (pz + urow)[voff];
-                r.re[j] = a.in_interleaved == 2 ? v.y : v.x;
-                r.im[j] = a.in_interleaved == 2 ? v.x : v.y;
+                if constexpr (VW == 1) {
+                    cx v = (pz + urow)[voff];
+                    r.re[j] = a.in_interleaved == 2 ? v.y : v.x;
+                    r.im[j] = a.in_interleaved == 2 ? v.x : v.y;
+                } else {
+                    const cx v0 = (pz + urow)[voff], v1 = (pz + urow)[voff + 1];
+                    const V x{v0.x, v1.x}, y{v0.y, v1.y};
+                    r.re[j] = a.in_interleaved == 2 ? y : x;
+                    r.im[j] = a.in_interleaved == 2 ? x : y;
+                }
             });
         }
     }
 
     // inter-pass twiddle W_{64 S}^{row * lo}: row = tau + TAUS j  =>  W^(tau lo) * (W^(TAUS lo))^j.  Two table look-ups and a
     // geometric progression (tw_progression: 4 running values stepped by D^4, 17 products where a table of the powers costs
-    // 30) instead of 16 look-ups (48 LDS reads): its rounding (<= 7 extra complex products, ~1.1e-16 each) is far inside the 1e-13 budget (measured rel-L2 unchanged, tests/test_gpu_parity.py)
+    // 30) instead of 16 look-ups (48 LDS reads): its rounding (<= 7 extra complex products, ~1.1e-16 each) is inside the gates
+    // of tests/tolerances.py (measured rel-L2 unchanged).  Per COLUMN: the packed f32 lane looks up two sets and runs the
+    // progression on the pair.
     struct TwRaw {
-        Tw3Raw<T> b, d;
+        Tw3Raw<T> b[VW], d[VW];
     };
     PHAST_HD static TwRaw pre_twiddle_fetch(const TileArgs &a, const cx *tw3, int lane, const Regs &r) {
-        const unsigned lo = ((r.g0 + (unsigned)col_of(lane)) >> a.tw_shift) & a.tw_mask;
         TwRaw t;
-        t.b = tw3_fetch<T>(tw3, a.tw_bits, (unsigned)tau_of(lane) * lo);
-        t.d = tw3_fetch<T>(tw3, a.tw_bits, (unsigned)TAUS * lo);
+        static_for<0, VW>([&](auto e) {
+            const unsigned lo = ((r.g0 + (unsigned)col_of(lane) + (unsigned)decltype(e)::value) >> a.tw_shift) & a.tw_mask;
+            t.b[e] = tw3_fetch<T>(tw3, a.tw_bits, (unsigned)tau_of(lane) * lo);
+            t.d[e] = tw3_fetch<T>(tw3, a.tw_bits, (unsigned)TAUS * lo);
+        });
         return t;
     }
     PHAST_HD static void pre_twiddle_apply(const TwRaw &t, Regs &r) {
-        T br, bi, dr, di;
-        tw3_combine<T>(t.b, br, bi);
-        tw3_combine<T>(t.d, dr, di);
-        tw_progression<T, P, 4>(br, bi, dr, di, [&](auto j, T wr, T wi) {
+        V br, bi, dr, di;
+        if constexpr (VW == 1) {
+            tw3_combine<T>(t.b[0], br, bi);
+            tw3_combine<T>(t.d[0], dr, di);
+        } else {
+            T b0r, b0i, b1r, b1i, d0r, d0i, d1r, d1i;
+            tw3_combine<T>(t.b[0], b0r, b0i);
+            tw3_combine<T>(t.b[1], b1r, b1i);
+            tw3_combine<T>(t.d[0], d0r, d0i);
+            tw3_combine<T>(t.d[1], d1r, d1i);
+            br = V{b0r, b1r};
+            bi = V{b0i, b1i};
+            dr = V{d0r, d1r};
+            di = V{d0i, d1i};
+        }
+        tw_progression<V, P, 4>(br, bi, dr, di, [&](auto j, V wr, V wi) {
             cmul(r.re[decltype(j)::value], r.im[decltype(j)::value], wr, wi);
         });
     }
@@ -155,27 +194,26 @@ template <typename T, bool PRE_TW, bool TRANSPOSE> struct WaveBody {
     }
 
     PHAST_HD static void step1(const cx *twr, int lane, Regs &r) {
-        fft_reg_dif<T, P, 0, P>(r.re, r.im);
+        fft_reg_dif<V, P, 0, P>(r.re, r.im);
         const unsigned tau = (unsigned)tau_of(lane);
         static_for<1, P>([&](auto p) {
             constexpr int K1 = bitrev_c(decltype(p)::value, LP);
             T wr, wi;
-            w64(twr, tau * K1, wr, wi);
+            w64(twr, tau * K1, wr, wi);   // one scalar twiddle for the lane's column pair
             cmul(r.re[p], r.im[p], wr, wi);
         });
     }
 
     PHAST_HD static void step2(Regs &r) {
-        static_for<0, P / TAUS>([&](auto g) { fft_reg_dif<T, TAUS, decltype(g)::value * TAUS, P>(r.re, r.im); });
+        static_for<0, P / TAUS>([&](auto g) { fft_reg_dif<V, TAUS, decltype(g)::value * TAUS, P>(r.re, r.im); });
     }
 
     // output row held by register Q = TAUS g + s of lane tau' after step2:  k1 + P k2,
     //   k1 = bitrev_LP((g << LT) | tau') = (bitrev_LT(tau') << (LP - LT)) + bitrev_(LP-LT)(g),   k2 = bitrev_LT(s)
-    //   (f64: k1 = bitrev4(p3 p2 b5 b4) = 8 b4 + 4 b5 + 2 p2 + p3;  f32: k1 = bitrev5(p4 p3 p2 p1 b5) = 16 b5 + bitrev4(g))
+    //   (k1 = bitrev4(p3 p2 b5 b4) = 8 b4 + 4 b5 + 2 p2 + p3)
     PHAST_HD static unsigned krow_lane(int lane) {
         const unsigned t = (unsigned)tau_of(lane);
-        if constexpr (LT == 2) return ((t & 1u) << 3) | ((t >> 1) << 2);
-        else return t << (LP - LT);
+        return ((t & 1u) << 3) | ((t >> 1) << 2);
     }
     template <int Q> PHAST_HD static constexpr unsigned krow_const() {
         constexpr int G = Q >> LT, S = Q & (TAUS - 1);
@@ -187,14 +225,14 @@ template <typename T, bool PRE_TW, bool TRANSPOSE> struct WaveBody {
                (size_t)r.xform * a.out_dist;
     }
     // ubase: wave-uniform element offset; vbyte: the lane's part as a 32-bit byte offset (see load_raw)
-    template <bool PAIRS, bool SCALE> PHAST_HD static void put(const TileArgs &a, size_t ubase, unsigned vbyte, T re, T im, T scale) {
+    template <bool PAIRS, bool SCALE> PHAST_HD static void put(const TileArgs &a, size_t ubase, unsigned vbyte, V re, V im, T scale) {
         if constexpr (SCALE) {
             re *= scale;
             im *= scale;
         }
         if constexpr (!PAIRS) {
-            T *qr = reinterpret_cast<T *>(reinterpret_cast<char *>(reinterpret_cast<T *>(a.out_re) + ubase) + vbyte);
-            T *qi = reinterpret_cast<T *>(reinterpret_cast<char *>(reinterpret_cast<T *>(a.out_im) + ubase) + vbyte);
+            VU *qr = reinterpret_cast<VU *>(reinterpret_cast<char *>(reinterpret_cast<T *>(a.out_re) + ubase) + vbyte);
+            VU *qi = reinterpret_cast<VU *>(reinterpret_cast<char *>(reinterpret_cast<T *>(a.out_im) + ubase) + vbyte);
             if constexpr (NT_STORE) {
                 __builtin_nontemporal_store(re, qr);
                 __builtin_nontemporal_store(im, qi);
@@ -203,16 +241,28 @@ template <typename T, bool PRE_TW, bool TRANSPOSE> struct WaveBody {
                 *qi = im;
             }
         } else {
-            cx v;
-            v.x = a.out_interleaved == 2 ? im : re;
-            v.y = a.out_interleaved == 2 ? re : im;
-            *reinterpret_cast<cx *>(reinterpret_cast<char *>(reinterpret_cast<cx *>(a.out_re) + ubase) + 2u * vbyte) = v;
+            const V x = a.out_interleaved == 2 ? im : re, y = a.out_interleaved == 2 ? re : im;
+            cx *q = reinterpret_cast<cx *>(reinterpret_cast<char *>(reinterpret_cast<cx *>(a.out_re) + ubase) + 2u * vbyte);
+            if constexpr (VW == 1) {
+                cx v;
+                v.x = x;
+                v.y = y;
+                *q = v;
+            } else {
+                cx v0, v1;
+                v0.x = x[0];
+                v0.y = y[0];
+                v1.x = x[1];
+                v1.y = y[1];
+                q[0] = v0;
+                q[1] = v1;
+            }
         }
     }
-    // later passes: same column-wide pattern out as in.  The planar / (re, im)-pair decision is taken ONCE, outside the
-    // sixteen stores (inside, it was a scalar branch per store).
-    // The multiplication by `scale` (1/N of an inverse transform's last pass, else exactly 1) is a wave-uniform branch too:
-    // a forward pass does not carry 32 multiplications by one.
+    // later passes: same column-wide pattern out as in (the lane's columns are adjacent in memory: out_s1 = 1, checked by
+    // launch_wave_inst for the packed tile).  The planar / pair decision and the multiplication by `scale` (1/N of an inverse
+    // transform's last pass, else exactly 1) are wave-uniform branches taken ONCE, outside the sixteen stores: a forward
+    // pass does not carry 32 multiplications by one.
     template <bool PAIRS, bool SCALE> PHAST_HD static void store_rows_as(const TileArgs &a, int lane, const Regs &r) {
         const size_t base = out_base(a, r);
         const unsigned vbyte =
@@ -232,15 +282,43 @@ template <typename T, bool PRE_TW, bool TRANSPOSE> struct WaveBody {
             else store_rows_as<true, false>(a, lane, r);
         }
     }
-    // pass A: through the wave-private buffer [col][k], then register Q holds row k = lane of column Q
-    template <int Q> PHAST_HD static int xp_write_addr(int lane) {
-        return col_of(lane) * CS + (int)krow_lane(lane) + (int)krow_const<Q>();
+    // pass A: through the wave-private buffer [column][k] (scalars): afterwards every store instruction writes whole runs --
+    // f64: register Q = column Q, lane = row k (one 512-byte run); f32: register Q = columns 2 Q and 2 Q + 1 on the two half-waves,
+    // lane & 31 = the row pair (2 l, 2 l + 1) (two 256-byte runs)
+    PHAST_HD static void xp_park(T *xp, int lane, const Regs &r) {
+        static_for<0, P>([&](auto Q) {
+            const int at = col_of(lane) * CS + (int)krow_lane(lane) + (int)krow_const<decltype(Q)::value>();
+            if constexpr (VW == 1) {
+                xp[at] = r.re[Q];
+                xp[XP + at] = r.im[Q];
+            } else {
+                xp[at] = r.re[Q][0];
+                xp[at + CS] = r.re[Q][1];
+                xp[XP + at] = r.im[Q][0];
+                xp[XP + at + CS] = r.im[Q][1];
+            }
+        });
     }
-    template <int Q> PHAST_HD static int xp_read_addr(int lane) { return Q * CS + lane; }
+    PHAST_HD static void xp_pick(const T *xp, int lane, Regs &r) {
+        static_for<0, P>([&](auto Q) {
+            if constexpr (VW == 1) {
+                r.re[Q] = xp[decltype(Q)::value * CS + lane];
+                r.im[Q] = xp[XP + decltype(Q)::value * CS + lane];
+            } else {
+                const int at = (2 * decltype(Q)::value + (lane >> 5)) * CS + 2 * (lane & 31);
+                r.re[Q] = V{xp[at], xp[at + 1]};
+                r.im[Q] = V{xp[XP + at], xp[XP + at + 1]};
+            }
+        });
+    }
     PHAST_HD static void store_runs(const TileArgs &a, int lane, const Regs &r) {  // a first pass: never the scaled last one
         const size_t base = out_base(a, r);
-        const unsigned vbyte = (unsigned)lane * (unsigned)a.out_row_stride * (unsigned)sizeof(T);
-        static_for<0, P>([&](auto Q) { put<false, false>(a, base + (size_t)decltype(Q)::value * a.out_s1, vbyte, r.re[Q], r.im[Q], (T)1); });
+        const unsigned vbyte = VW == 1 ? (unsigned)lane * (unsigned)a.out_row_stride * (unsigned)sizeof(T)
+                                       : ((unsigned)(lane >> 5) * (unsigned)a.out_s1 + 2u * (unsigned)(lane & 31) * (unsigned)a.out_row_stride) *
+                                             (unsigned)sizeof(T);
+        static_for<0, P>([&](auto Q) {
+            put<false, false>(a, base + (size_t)(VW * decltype(Q)::value) * a.out_s1, vbyte, r.re[Q], r.im[Q], (T)1);
+        });
     }
 };
 
@@ -291,7 +369,19 @@ template <bool HALVES> __device__ __forceinline__ void swap_pair(float &a, float
     a = __uint_as_float(x);
     b = __uint_as_float(y);
 }
-template <typename T> __device__ __forceinline__ void wave_exchange(T (&re)[16], T (&im)[16]) {  // f64: two lane bits
+template <bool HALVES> __device__ __forceinline__ void swap_pair(f32x2 &a, f32x2 &b) {  // a packed column pair: 8 bytes, as a double
+    unsigned a0 = __float_as_uint(a[0]), a1 = __float_as_uint(a[1]), b0 = __float_as_uint(b[0]), b1 = __float_as_uint(b[1]);
+    if constexpr (HALVES) {
+        swap_lane_halves(a0, b0);
+        swap_lane_halves(a1, b1);
+    } else {
+        swap_lane_rows(a0, b0);
+        swap_lane_rows(a1, b1);
+    }
+    a = f32x2{__uint_as_float(a0), __uint_as_float(a1)};
+    b = f32x2{__uint_as_float(b0), __uint_as_float(b1)};
+}
+template <typename T> __device__ __forceinline__ void wave_exchange(T (&re)[16], T (&im)[16]) {  // two lane bits
     static_for<0, 16>([&](auto p) {  // round 1: lane bit 5 <-> register bit 1
         constexpr int Pp = decltype(p)::value;
         if constexpr ((Pp & 2) == 0) {
@@ -307,16 +397,6 @@ template <typename T> __device__ __forceinline__ void wave_exchange(T (&re)[16],
         }
     });
 }
-template <typename T> __device__ __forceinline__ void wave_exchange(T (&re)[32], T (&im)[32]) {  // f32: one lane bit
-    static_for<0, 32>([&](auto p) {  // lane bit 5 <-> register bit 0
-        constexpr int Pp = decltype(p)::value;
-        if constexpr ((Pp & 1) == 0) {
-            swap_pair<true>(re[Pp], re[Pp | 1]);
-            swap_pair<true>(im[Pp], im[Pp | 1]);
-        }
-    });
-}
-
 // Stagger of the waves' loads (see the kernel): group g = ((block & 1) << 2 | wave) & mask sleeps g * units * 64 cycles.
 // Packed as units | mask << 8; PHAST_WAVE_STAGGER="units,mask" overrides the default (tuning, tools/sweep_stagger.py).
 #ifndef PHAST_WAVE_STAGGER_DEFAULT
@@ -332,7 +412,7 @@ inline unsigned wave_stagger_setting() {
     return v;
 }
 template <typename T, bool PRE_TW, bool TRANSPOSE>
-__global__ void __launch_bounds__(64 * PHAST_WAVE_TILES_PER_BLOCK) wave_fft_kernel(const TileArgs a, unsigned blocks_total, unsigned stagger) {
+__global__ void __launch_bounds__((wave_block_threads<T>())) wave_fft_kernel(const TileArgs a, unsigned blocks_total, unsigned stagger) {
     using Body = WaveBody<T, PRE_TW, TRANSPOSE>;
     using cx = cx_t<T>;
     pin_tile_args(a);
@@ -354,6 +434,7 @@ __global__ void __launch_bounds__(64 * PHAST_WAVE_TILES_PER_BLOCK) wave_fft_kern
     // (one vmcnt counter), so the other way round the table values would sit behind all 32 tile loads.  The inter-pass
     // tables are not staged at all: a lane needs six entries (two three-level look-ups), read straight from global
     // memory (a few KiB, L2-resident).
+    using V = typename Body::V;
     typename Body::Regs r;
     Body::locate(a, blockIdx.x, blocks_total, (unsigned)wave, r);
     const cx twr_stage = reinterpret_cast<const cx *>(a.twr)[lane & 31];
@@ -390,24 +471,18 @@ __global__ void __launch_bounds__(64 * PHAST_WAVE_TILES_PER_BLOCK) wave_fft_kern
 #endif
     Body::step1(l_twr, lane, r);
 #if !defined(PHAST_WAVE_DEBUG_SKIP) || PHAST_WAVE_DEBUG_SKIP < 2
-    wave_exchange<T>(r.re, r.im);
+    wave_exchange<V>(r.re, r.im);
 #endif
     Body::step2(r);
 #endif
     if constexpr (TRANSPOSE) {
         // wave-private transposition: this wave writes and then reads its own buffer; LDS operations of one wave
         // execute in order, and the compiler's s_waitcnt lgkmcnt covers the data dependency -- no barrier
-        static_for<0, Body::P>([&](auto Q) {
-            xp[Body::template xp_write_addr<decltype(Q)::value>(lane)] = r.re[Q];
-            xp[Body::XP + Body::template xp_write_addr<decltype(Q)::value>(lane)] = r.im[Q];
-        });
+        Body::xp_park(xp, lane, r);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        static_for<0, Body::P>([&](auto Q) {
-            r.re[Q] = xp[Body::template xp_read_addr<decltype(Q)::value>(lane)];
-            r.im[Q] = xp[Body::XP + Body::template xp_read_addr<decltype(Q)::value>(lane)];
-        });
+        Body::xp_pick(xp, lane, r);
         Body::store_runs(a, lane, r);
     } else {
         Body::store_rows(a, lane, r);
@@ -431,6 +506,16 @@ hipError_t launch_wave_inst(hipStream_t stream, const TileArgs &a, bool query_on
     if (query_only) {
         if (blocks_per_cu) *blocks_per_cu = (int)((160 * 1024) / lds) < 4 ? (int)((160 * 1024) / lds) : 4;
         return hipSuccess;
+    }
+    // what the kernel's addressing takes for granted: the lane's part of every address fits a 32-bit BYTE offset, and the
+    // packed (f32) tile's two columns -- in a first pass its two rows -- are adjacent in memory
+    {
+        const unsigned long long esz = sizeof(T) * (a.in_interleaved || a.out_interleaved ? 2u : 1u);
+        const unsigned long long in_span = ((unsigned long long)(Body::TAUS - 1) * a.in_row_stride + Body::COLS) * esz;
+        const unsigned long long out_span = TRANSPOSE ? ((unsigned long long)a.out_s1 + 64ull * a.out_row_stride) * esz
+                                                      : ((unsigned long long)Body::COLS * a.out_s1 + 16ull * a.out_row_stride) * esz;
+        if (in_span >= (1ull << 32) || out_span >= (1ull << 32)) return hipErrorInvalidValue;
+        if (Body::VW == 2 && (TRANSPOSE ? a.out_row_stride != 1 : a.out_s1 != 1)) return hipErrorInvalidValue;
     }
     const unsigned blocks = (a.tiles_total + Body::WAVES - 1) / Body::WAVES;
     // the stagger pays when every wave of the launch is resident at once and they would all move in step: at most one
@@ -462,25 +547,18 @@ template <typename T, bool PRE_TW, bool TRANSPOSE> void emulate_wave_pass(const 
             }
             for (int l = 0; l < 64; ++l) {  // new[lane tau'][register (g, s)] = old[lane tau = s][register (g, tau')]
                 nxt[l] = regs[l];
-                const int col = Body::col_of(l), b = Body::tau_of(l);
+                const int col = Body::lcol_of(l), b = Body::tau_of(l);
                 for (int q = 0; q < Body::P; ++q) {
-                    const int src_lane = ((q & (Body::TAUS - 1)) << Body::LC) | col, src_reg = (q & ~(Body::TAUS - 1)) | b;
+                    const int src_lane = ((q & (Body::TAUS - 1)) << Body::LCL) | col, src_reg = (q & ~(Body::TAUS - 1)) | b;
                     nxt[l].re[q] = regs[src_lane].re[src_reg];
                     nxt[l].im[q] = regs[src_lane].im[src_reg];
                 }
             }
             for (int l = 0; l < 64; ++l) Body::step2(nxt[l]);
             if constexpr (TRANSPOSE) {
-                for (int l = 0; l < 64; ++l)
-                    static_for<0, Body::P>([&](auto Q) {
-                        xp[Body::template xp_write_addr<decltype(Q)::value>(l)] = nxt[l].re[Q];
-                        xp[Body::XP + Body::template xp_write_addr<decltype(Q)::value>(l)] = nxt[l].im[Q];
-                    });
+                for (int l = 0; l < 64; ++l) Body::xp_park(xp.data(), l, nxt[l]);
                 for (int l = 0; l < 64; ++l) {
-                    static_for<0, Body::P>([&](auto Q) {
-                        nxt[l].re[Q] = xp[Body::template xp_read_addr<decltype(Q)::value>(l)];
-                        nxt[l].im[Q] = xp[Body::XP + Body::template xp_read_addr<decltype(Q)::value>(l)];
-                    });
+                    Body::xp_pick(xp.data(), l, nxt[l]);
                     Body::store_runs(a, l, nxt[l]);
                 }
             } else {

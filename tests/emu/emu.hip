@@ -565,12 +565,6 @@ template <typename T> static int check_tables(int *n_entries) {
             if (!ok) {
                 std::fprintf(stderr, "plan table %d, %zu-byte elements, L = %u: not a plan\n", which, sizeof(T), L);
                 ++bad;
-            } else if (sizeof(T) == 4) {
-                for (const PassGeom &g : geo)
-                    if (g.wave) {  // the product library refuses f32 wave tiles (planner_plans.hpp: set_plan)
-                        std::fprintf(stderr, "plan table %d, f32, L = %u: asks for wave tiles\n", which, L);
-                        ++bad;
-                    }
             }
         }
     return bad;

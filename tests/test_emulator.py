@@ -265,12 +265,14 @@ def test_strided_batch_geometry_vs_oracle(emu, oracle, L, s, sb):
 
 @pytest.mark.parametrize("L,lrs,tl", [(18, (6, 6, 6), 11), (17, (6, 6, 5), 11)])
 def test_f32_wave_tiles_vs_oracle(emu, oracle, L, lrs, tl):
-    """round 3: the f32 twin of the wave tiles (64 rows x 32 columns, 32 points per lane, ONE lane bit exchanged by
-    v_permlane32_swap; wave_fft.hpp) -- all passes of 2^18 as wave tiles, forward and inverse, against the oracle; a
-    plan whose last pass is not 64 rows long must be refused or run the generic tiles for it."""
+    """The f32 wave tiles (round 6: 64 rows x 32 columns, a lane holds float2 COLUMN PAIRS -- the f64 tile's lane layout,
+    exchanges and instruction count with every register carrying two columns; wave_fft.hpp) -- all passes of 2^18 as wave
+    tiles, forward and inverse, against the oracle AND float64 pocketfft; a plan whose last pass is not 64 rows long must be
+    refused or run the generic tiles for it."""
     n = 1 << L
     for direction, odir in ((1, oracle.FORWARD), (-1, oracle.REVERSE)):
         re, im = oracle.fill(n, np.float32, transform_id=L)
+        z = re.astype(np.float64) + 1j * im.astype(np.float64)
         a, b = re.copy(), im.copy()
         rc = run(emu, a, b, direction, lrs, tl, 3 | 0x10)
         if lrs[-1] != 6:
@@ -281,6 +283,32 @@ def test_f32_wave_tiles_vs_oracle(emu, oracle, L, lrs, tl):
         err = np.sqrt(np.sum((a.astype(np.float64) - re) ** 2 + (b.astype(np.float64) - im) ** 2) /
                       np.sum(re.astype(np.float64) ** 2 + im.astype(np.float64) ** 2))
         assert err <= 1e-5, err
+        want = np.fft.fft(z) if direction == 1 else np.fft.ifft(z)
+        got = a.astype(np.float64) + 1j * b.astype(np.float64)
+        assert np.linalg.norm(got - want) / np.linalg.norm(want) <= 1.5e-7 * L, (direction, L)
+
+
+@pytest.mark.parametrize("plan,L", [("6,8,6@11,13,11:p8w", 20), ("6,8,6@12,13,11:p8w", 20), ("6,8@11,13:p8w", 14), ("7,8,6@12,13,11:p8w", 21),
+                                    ("6,8,8@11,13,13:p8w", 22)])
+def test_f32_four_wave_pass_vs_oracle(emu, oracle, plan, L):
+    """round 6: the f32 four-wave 256-row pass (quad_fft.hpp on float2 column pairs: 256 rows x 32 columns) between / behind
+    f32 wave tiles and generic tiles -- the plan of ONE f32 transform of 2^20 points [64x32A w][256x32 q][64x32 w] among them;
+    every output against float64 pocketfft at the f32 gate of tests/tolerances.py, forward and inverse."""
+    emu.phast_emu_set_plan.argtypes = [C.c_char_p]
+    n = 1 << L
+    try:
+        assert emu.phast_emu_set_plan(plan.encode()) == 0, plan
+        for direction in (1, -1):
+            re, im = oracle.fill(n, np.float32, transform_id=L + 40)
+            z = re.astype(np.float64) + 1j * im.astype(np.float64)
+            a, b = re.copy(), im.copy()
+            assert run(emu, a, b, direction) == 0, plan
+            want = np.fft.fft(z) if direction == 1 else np.fft.ifft(z)
+            got = a.astype(np.float64) + 1j * b.astype(np.float64)
+            assert np.linalg.norm(got - want) / np.linalg.norm(want) <= 1.5e-7 * L, (plan, direction)
+            assert np.max(np.abs(got - want)) / np.sqrt(np.mean(np.abs(want) ** 2)) <= 2e-6 * L, (plan, direction)
+    finally:
+        emu.phast_emu_set_plan(None)
 
 
 def _emu_r2c(emu, x, lrs=(), tile_log=0, points_log=0):
@@ -440,7 +468,7 @@ def test_every_instantiated_shape_as_fused_first_pass_of_c2r_and_last_pass_of_r2
 
 def test_every_plan_table_entry_is_a_plan_that_exists(emu):
     """plan.hpp: single_plan / real_plan / real_batch_plan (round 4: 77 entries ranked on the GPU) -- rows add up to the length,
-    every pass is an instantiated shape, make_passes accepts the geometry; no f32 entry asks for the (experimental) wave tiles.
+    every pass is an instantiated shape, make_passes accepts the geometry.
     A bad entry would not fail anywhere else: an optional plan that cannot be built is skipped silently."""
     n = C.c_int()
     emu.phast_emu_check_plan_tables.argtypes = [C.POINTER(C.c_int)]

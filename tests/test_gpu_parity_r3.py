@@ -342,20 +342,45 @@ def test_planner_follows_its_device_not_the_callers(gpu, oracle):
     assert errs[0] <= tol_mod.f64_rel(20) and errs[2] <= tol_mod.f64_rel(20) and errs[1] == 0 and errs[3] == 0, errs
 
 
-# ---------------------------------------------------------------- f32 wave tiles (the f32 twin of wave_fft.hpp)
-def test_f32_wave_tiles_are_not_in_the_product_library(gpu, static_rules):
-    """wave_fft.hpp in f32 (one wave per 64-row x 32-column tile, 32 points per lane): built, emulated on the CPU
-    (tests/test_emulator.py::test_f32_wave_tiles_vs_oracle) and parity-tested on the GPU in round 3, slower than the generic
-    4096-point tiles for every plan measured (profiles/r03_sweep_wave_f32.log) -- round 4 took them out of the product
-    library (`python -m phastft_amd.build --experimental` builds lib/libphastft_hip_exp.so with them for tools/): a plan that
-    asks for them is refused, nothing else changes."""
-    planner = gpu.PlannerDit32(1 << 18)
-    before = planner.describe()
-    with pytest.raises(Exception):
-        planner.set_plan((6, 6, 6), 11, 3 | 0x10)
-    assert planner.describe() == before and " w32 " not in before
-    planner.set_plan((6, 6, 6), 12, 3)          # the same factorisation on generic tiles is fine
-    assert planner.describe().count("[64x64") == 3, planner.describe()
+# ---------------------------------------------------------------- f32 wave / four-wave tiles (float2 column pairs, round 6)
+@pytest.mark.parametrize("k,plan", [(18, ((6, 6, 6), 11, 3 | 0x10)), (20, ((6, 8, 6), (11, 13, 11), 3 | 0x10)), (20, ((6, 8, 6), (12, 13, 11), 3 | 0x10)),
+                                    (14, ((6, 8), (11, 13), 3 | 0x10)), (21, ((7, 8, 6), (12, 13, 11), 3 | 0x10)),
+                                    (22, ((6, 8, 8), (11, 13, 13), 3 | 0x10))])
+def test_f32_wave_and_four_wave_tiles_vs_oracle(gpu, oracle, k, plan):
+    """Round 6: the f32 one-wave tile (64 rows x 32 columns) and the f32 four-wave 256-row pass (256 x 32), both on float2 COLUMN
+    PAIRS (wave_fft.hpp / quad_fft.hpp: the f64 tiles' lane layout with every register carrying two adjacent columns, 8-byte
+    accesses, 128-byte rows).  Forced plans with them in every position -- first (transposing), middle, last -- alone and next
+    to generic tiles: every output against the oracle and float64 pocketfft, forward, inverse (1/N in the last store),
+    `Complex<f32>` pairs in and out, and a batch."""
+    import torch
+
+    n = 1 << k
+    lrs, tls, lp = plan
+    planner = gpu.PlannerDit32(n)
+    planner.set_plan(lrs, tls, lp)
+    desc = planner.describe_call()
+    assert desc.startswith("forced") and (" w32]" in desc or " q32]" in desc), desc
+    h_re, h_im = oracle.fill(n, np.float32, seed=0xF32, transform_id=k)
+    z = np.fft.fft(h_re.astype(np.float64) + 1j * h_im.astype(np.float64))
+    d_re, d_im = dev(h_re.copy()), dev(h_im.copy())
+    gpu.fft_32_dit_with_planner(d_re, d_im, gpu.Direction.Forward, planner)
+    g_re, g_im = d_re.cpu().numpy(), d_im.cpu().numpy()
+    tol_mod.check("f32_wave_quad " + desc, "f32", k, g_re, g_im, z.real, z.imag)
+    o_re, o_im = h_re.copy(), h_im.copy()
+    oracle.fft_32_dit(o_re, o_im, oracle.FORWARD)
+    tol_mod.check("f32_wave_quad_vs_oracle " + desc, "f32", k, g_re, g_im, o_re.astype(np.float64), o_im.astype(np.float64), against="oracle")
+    gpu.fft_32_dit_with_planner(d_re, d_im, gpu.Direction.Reverse, planner)        # the scaled last store
+    assert float((d_re.cpu() - torch.from_numpy(h_re)).abs().max()) < 5 * tol_mod.ROUNDTRIP_ABS["f32"]
+    assert float((d_im.cpu() - torch.from_numpy(h_im)).abs().max()) < 5 * tol_mod.ROUNDTRIP_ABS["f32"]
+    zi = torch.from_numpy((h_re + 1j * h_im).astype(np.complex64)).cuda()          # pairs in (first pass) and out (last pass)
+    gpu.fft_32_interleaved_with_planner(zi, gpu.Direction.Forward, planner)
+    tol_mod.check_c("f32_wave_quad_pairs " + desc, "f32", k, zi.cpu().numpy().astype(np.complex128), z)
+    batch = 3                                                                        # several transforms per launch
+    b_re, b_im = dev(np.tile(h_re, batch)), dev(np.tile(h_im, batch))
+    gpu.fft_dit_batched(b_re, b_im, n, gpu.Direction.Forward, planner)
+    rows_re, rows_im = b_re.cpu().numpy().reshape(batch, n), b_im.cpu().numpy().reshape(batch, n)
+    for b in range(batch):
+        assert np.array_equal(rows_re[b], g_re) and np.array_equal(rows_im[b], g_im), b
 
 
 def test_transform_list_one_call_many_single_transforms(gpu, oracle):

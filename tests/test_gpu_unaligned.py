@@ -152,14 +152,25 @@ def test_interleaved_on_element_aligned_views(gpu, oracle, dt, k, off):
     tol.check_c(f"unaligned_interleaved off={off}", dt, k, v.cpu().numpy().astype(np.complex128), want)
     h = buf.cpu().numpy()
     assert np.all(h[:off] == GUARD) and np.all(h[off + n:] == GUARD)
-    # (b) a view ONE SCALAR into the storage: pairs that straddle the natural 2-scalar alignment
+    # (b) a pointer ONE SCALAR into the storage: pairs that straddle the natural 2-scalar alignment.  torch cannot express
+    # such a complex view (view_as_complex wants an even storage offset), a C or Rust caller can: straight through the C ABI
+    import ctypes as C
+
+    from phastft_amd import _lib
+
     rdt = torch.float64 if dt == "f64" else torch.float32
     flat = torch.full((2 * n + 2 * off + 9,), GUARD, dtype=rdt, device="cuda")
     start = 2 * off - 1                                            # odd: the pair (re, im) starts on an odd scalar index
-    pair_view = torch.view_as_complex(flat[start:start + 2 * n].view(n, 2)) if hasattr(torch, "view_as_complex") else None
-    if pair_view is not None and pair_view.data_ptr() % (16 if dt == "f64" else 8) != 0:
-        pair_view.copy_(torch.from_numpy(z0))
-        fft(pair_view, gpu.Direction.Forward, planner)
-        tol.check_c(f"unaligned_interleaved_scalar off={off}", dt, k, pair_view.cpu().numpy().astype(np.complex128), want)
-        h = flat.cpu().numpy()
-        assert np.all(h[:start] == GUARD) and np.all(h[start + 2 * n:] == GUARD)
+    view = flat[start:start + 2 * n]
+    assert view.data_ptr() % (16 if dt == "f64" else 8) != 0
+    view.copy_(torch.from_numpy(np.ascontiguousarray(z0).view(ndt)))
+    sfx = "64" if dt == "f64" else "32"
+    rc = getattr(_lib.lib(), f"phast_fft_{sfx}_interleaved_dev")(C.c_void_p(view.data_ptr()), C.c_size_t(n), C.c_size_t(1), C.c_size_t(n),
+                                                                  C.c_int(int(gpu.Direction.Forward)), planner._h,
+                                                                  C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    got = view.cpu().numpy().astype(np.float64)
+    tol.check_c(f"unaligned_interleaved_scalar off={off}", dt, k, got[0::2] + 1j * got[1::2], want)
+    h = flat.cpu().numpy()
+    assert np.all(h[:start] == GUARD) and np.all(h[start + 2 * n:] == GUARD)
