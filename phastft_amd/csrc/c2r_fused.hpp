@@ -27,6 +27,9 @@
 #ifndef PHAST_C2R_PAIRS
 #define PHAST_C2R_PAIRS 1
 #endif
+#ifndef PHAST_C2R_NT
+#define PHAST_C2R_NT 0
+#endif
 
 namespace phast {
 
@@ -90,10 +93,22 @@ template <typename T, int LR, int LC, int LP, bool SEQ> struct C2rFirstBody {
             static_for<0, CH>([&](auto i) {
                 constexpr int I = decltype(i)::value, J = C0 + I;
                 const size_t urow = (size_t)(J * M) << a.log_s_in, mrow = (size_t)((P - 1 - J) * M) << a.log_s_in;
+                // (cache hints on the two streams -- PHAST_C2R_NT: 1 = the mirrored partner stream non-temporal (its second and
+                //  last use), 2 = the tile's own stream, 3 = both; measured in profiles/r06_c2r_first_pass_ab.log)
+#if PHAST_C2R_NT & 2
+                x_re[I] = __builtin_nontemporal_load(pr + urow + voff);
+                x_im[I] = __builtin_nontemporal_load(pi + urow + voff);
+#else
                 x_re[I] = (pr + urow)[voff];
                 x_im[I] = (pi + urow)[voff];
+#endif
+#if PHAST_C2R_NT & 1
+                m_re[I] = __builtin_nontemporal_load(qr + mrow + moff);
+                m_im[I] = __builtin_nontemporal_load(qi + mrow + moff);
+#else
                 m_re[I] = (qr + mrow)[moff];
                 m_im[I] = (qi + mrow)[moff];
+#endif
             });
             // (the rows' table entries four at a time -- as r2c_fused.hpp: untangle; all CH of them with the data loads cost the
             //  16-point f64 kernels a wave of occupancy, 139 -> 211 VGPRs: measured in kernel_resources.json, round 4)

@@ -253,7 +253,10 @@ inline bool single_plan(unsigned L, std::vector<unsigned> &lrs, std::vector<unsi
                             {19, 6, 7, 6, 10, 11, 10, 3 | W}, {20, 6, 8, 6, 10, 12, 10, 3 | W},
                             {21, 6, 8, 7, 10, 12, 12, 3 | W}, {22, 8, 7, 7, 13, 12, 13, 4},     {23, 7, 9, 7, 13, 12, 13, 4},     {24, 8, 9, 7, 13, 12, 13, 4},
                             {25, 8, 9, 8, 12, 12, 14, 4},     {27, 8, 10, 9, 13, 14, 14, 5},    {28, 9, 9, 10, 14, 14, 14, 5}};
-    static const E f32[] = {{12, 6, 6, 0, 10, 10, 0, 3},  {14, 7, 7, 0, 11, 11, 0, 3},  {15, 8, 7, 0, 12, 11, 0, 3},  {19, 6, 7, 6, 11, 11, 11, 3}, {22, 7, 8, 7, 13, 13, 13, 4}, {23, 8, 8, 7, 12, 12, 12, 4}, {25, 8, 9, 8, 14, 13, 14, 4}};
+    // f32, round 6: the one-wave 64 x 32 tiles and the four-wave 256 x 32 pass on float2 column pairs (W) where they won the same-box
+    // A/B against the plan that stood (profiles/r06_f32_wave_quad_ab.log): 2^19 19.0 -> 17.8 us, 2^20 22.8 -> 19.4, 2^22 43.2 -> 39.1
+    static const E f32[] = {{12, 6, 6, 0, 10, 10, 0, 3},  {14, 7, 7, 0, 11, 11, 0, 3},  {15, 8, 7, 0, 12, 11, 0, 3},  {19, 6, 7, 6, 11, 12, 11, 3 | W},
+                            {20, 6, 8, 6, 11, 13, 11, 3 | W}, {22, 6, 8, 8, 11, 13, 13, 3 | W}, {23, 8, 8, 7, 12, 12, 12, 4}, {25, 8, 9, 8, 14, 13, 14, 4}};
     const E *tab = sizeof(T) == 8 ? f64 : f32;
     const size_t cnt = (sizeof(T) == 8 ? sizeof f64 : sizeof f32) / sizeof(E);
     for (size_t i = 0; i < cnt; ++i)
