@@ -30,8 +30,19 @@
 #ifndef PHAST_C2R_NT
 #define PHAST_C2R_NT 0
 #endif
+#ifndef PHAST_C2R_DUAL  // two-tile workgroups (a tile and its mirror side by side): built, parity-green, measured, NOT faster --
+#define PHAST_C2R_DUAL 0  // profiles/r06_c2r_first_pass_ab.log; -DPHAST_C2R_DUAL=1 (tools/build_variant.py) instantiates them
+#endif
 
 namespace phast {
+
+inline bool c2r_dual_enabled() {  // PHAST_C2R_DUAL=0 (environment): single-tile workgroups, for A/B runs
+    static const bool on = [] {
+        const char *e = getenv("PHAST_C2R_DUAL");
+        return !(e && *e == '0');
+    }();
+    return on;
+}
 
 struct C2rFuseArgs {
     const void *tw3n;   // [3][1 << twn_bits] complex: W_N^e, N = 2 h (the R2C planner's table)
@@ -57,7 +68,13 @@ template <typename T, int LR, int LC, int LP, bool SEQ> struct C2rFirstBody {
     // position t of the launch -> (transform, first column): XCD-aware as TileBody::locate (workgroup b runs on XCD b % 8
     // and gets one contiguous run of positions); inside a transform positions 2q and 2q + 1 are tile q and its mirror
     PHAST_HD static void locate(const TileArgs &a, unsigned t, Regs &r) {
-        const unsigned pos = ((a.tiles_total & 7u) == 0u) ? (t & 7u) * (a.tiles_total >> 3) + (t >> 3) : t;
+        locate_pos(a, ((a.tiles_total & 7u) == 0u) ? (t & 7u) * (a.tiles_total >> 3) + (t >> 3) : t, r);
+    }
+    // two-tile workgroups: workgroup b takes the positions 2 j and 2 j + 1 (a tile and its mirror) of ITS XCD's run
+    PHAST_HD static unsigned dual_pos(const TileArgs &a, unsigned b, unsigned half) {
+        return ((a.tiles_total & 15u) == 0u) ? (b & 7u) * (a.tiles_total >> 3) + 2u * (b >> 3) + half : 2u * b + half;
+    }
+    PHAST_HD static void locate_pos(const TileArgs &a, unsigned pos, Regs &r) {
         r.xform = pos >> (unsigned)__builtin_ctz(a.tiles_per_xform);
         const unsigned ti = pos & (a.tiles_per_xform - 1u), q = ti >> 1;
 #if PHAST_C2R_PAIRS
@@ -134,29 +151,44 @@ template <typename T, int LR, int LC, int LP, bool SEQ> struct C2rFirstBody {
     }
 };
 
-template <typename T, int LR, int LC, int LP, bool SEQ>
-__global__ void __launch_bounds__(1 << (LR + LC - LP)) c2r_first_pass_kernel(const TileArgs a, const C2rFuseArgs f) {
+// DUAL (round 6, measured and not adopted): one workgroup of 2 NT threads runs a tile AND its mirror tile side by side
+// (positions 2 j and 2 j + 1 of its XCD's run, each half with its own LDS region and its own copy of the tables; the barriers
+// are shared, both halves run the same instruction stream).  The idea: every line of the half-spectrum is wanted twice -- as the
+// tile's own element and as the mirror tile's partner -- and with both on ONE CU at the same time the second request would be
+// a hit in that CU's vector L1.  Measured (profiles/r06_c2r_first_pass_ab.log): f32 2^24 40.3 -> 39.7 us, f64 2^24 71 -> 81,
+// f32 2^26 157 -> 173: the 512-thread workgroups cost more than the L1 hits give.
+template <typename T, int LR, int LC, int LP, bool SEQ, bool DUAL>
+__global__ void __launch_bounds__((DUAL ? 2 : 1) << (LR + LC - LP)) c2r_first_pass_kernel(const TileArgs a, const C2rFuseArgs f, unsigned lds_half) {
     using CB = C2rFirstBody<T, LR, LC, LP, SEQ>;
     using Body = typename CB::Body;
     using cx = cx_t<T>;
     constexpr int NT = Body::NT;
     pin_tile_args(a);
 
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+    const unsigned half = DUAL ? (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >= (unsigned)NT)) : 0u;  // wave-uniform
+    unsigned char *smem = smem_all + (size_t)half * lds_half;
     T *ex_re = reinterpret_cast<T *>(smem);
     cx *l_twr = reinterpret_cast<cx *>(smem + (size_t)Body::EXCH * sizeof(T) * (Body::PLANE_SEQ ? 1 : 2));
     const typename Body::Shared sh{ex_re, Body::PLANE_SEQ ? ex_re : ex_re + Body::EXCH, l_twr, l_twr};
 
-    int tid = threadIdx.x;
-    unsigned wave_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
+    int tid = (int)threadIdx.x - (int)half * NT;
+    unsigned wave_base = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u) - (int)half * NT);
     auto fresh_tid = [&]() {  // see tile_fft_kernel
         asm volatile("" : "+s"(wave_base));
         return (int)(wave_base | __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
     };
     typename Body::Regs r;
+    // t counts workgroup rounds: a tile per round (DUAL: a tile and its mirror -- tiles_total is even, both halves make the
+    // same number of rounds and meet at the same barriers)
     unsigned t = blockIdx.x;
-    if (t < a.tiles_total) {  // the first tile's loads go out before the table is staged
-        CB::locate(a, t, r);
+    const unsigned t_end = DUAL ? a.tiles_total / 2u : a.tiles_total;
+    auto place = [&]() {
+        if constexpr (DUAL) CB::locate_pos(a, CB::dual_pos(a, t, half), r);
+        else CB::locate(a, t, r);
+    };
+    if (t < t_end) {  // the first tile's loads go out before the table is staged
+        place();
         CB::load_pre(a, f, tid, r);
     }
     for (int i = tid; i < Body::TWR; i += NT) l_twr[i] = reinterpret_cast<const cx *>(a.twr)[i];
@@ -187,14 +219,14 @@ __global__ void __launch_bounds__(1 << (LR + LC - LP)) c2r_first_pass_kernel(con
         tid = fresh_tid();
         Body::template step<decltype(i)::value>(sh, tid, r);
     };
-    while (t < a.tiles_total) {
+    while (t < t_end) {
         Body::chain(do_step, exchange);
         tid = fresh_tid();
         Body::store(a, tid, r);
         t += gridDim.x;
-        if (t < a.tiles_total) {
+        if (t < t_end) {
             tid = fresh_tid();
-            CB::locate(a, t, r);
+            place();
             CB::load_pre(a, f, tid, r);
         }
     }
@@ -204,12 +236,33 @@ template <typename T, int LR, int LC, int LP, bool SEQ>
 hipError_t launch_c2r_first_inst(unsigned grid, hipStream_t stream, const TileArgs &a, const C2rFuseArgs &f, bool query_only,
                                  int *blocks_per_cu, hipEvent_t ev_start, hipEvent_t ev_stop) {
     using Body = TileBody<T, LR, LC, LP, false, true, SEQ>;
-    auto kern = c2r_first_pass_kernel<T, LR, LC, LP, SEQ>;
-    const size_t lds = Body::lds_bytes(a.tw_bits);
-    if (lds > (size_t)160 * 1024) {
+    const size_t lds_one = (Body::lds_bytes(a.tw_bits) + 15) & ~(size_t)15;
+    if (lds_one > (size_t)160 * 1024) {
         if (query_only && blocks_per_cu) *blocks_per_cu = 0;
         return query_only ? hipSuccess : hipErrorInvalidValue;
     }
+    // two tiles (a tile and its mirror) per workgroup where 2 NT threads and twice the LDS fit -- the launch form, not the
+    // occupancy query (which stays in single-tile workgroups: the grid below is derived from it).  PHAST_C2R_DUAL=0: tools.
+    constexpr bool kCanDual = PHAST_C2R_DUAL && Body::NT <= 256;  // (512-thread workgroups: 256 registers per lane; 1024 would halve them and spill)
+    const bool dual = kCanDual && !query_only && 2 * lds_one <= (size_t)160 * 1024 && (a.tiles_total & 1u) == 0u && c2r_dual_enabled();
+    if constexpr (kCanDual) {
+        if (dual) {
+            auto kern2 = c2r_first_pass_kernel<T, LR, LC, LP, SEQ, true>;
+            static PerDeviceLimit lds_limit2;
+            if (hipError_t e = raise_lds_limit(lds_limit2, reinterpret_cast<const void *>(kern2), 2 * lds_one); e != hipSuccess) return e;
+            unsigned g2 = (grid + 1) / 2;
+            if (g2 > a.tiles_total / 2) g2 = a.tiles_total / 2;
+            if (g2 >= 8 && (a.tiles_total & 15u) == 0u) g2 &= ~7u;   // workgroup b stays in the run of XCD b % 8 (dual_pos)
+            if (g2 == 0) g2 = 1;
+            if (ev_start && ev_stop)
+                hipExtLaunchKernelGGL(kern2, dim3(g2), dim3(2 * Body::NT), (uint32_t)(2 * lds_one), stream, ev_start, ev_stop, 0, a, f, (unsigned)lds_one);
+            else
+                hipLaunchKernelGGL(kern2, dim3(g2), dim3(2 * Body::NT), 2 * lds_one, stream, a, f, (unsigned)lds_one);
+            return hipGetLastError();
+        }
+    }
+    auto kern = c2r_first_pass_kernel<T, LR, LC, LP, SEQ, false>;
+    const size_t lds = lds_one;
     static PerDeviceLimit lds_limit;
     if (hipError_t e = raise_lds_limit(lds_limit, reinterpret_cast<const void *>(kern), lds); e != hipSuccess) return e;
     if (query_only) {
@@ -227,9 +280,9 @@ hipError_t launch_c2r_first_inst(unsigned grid, hipStream_t stream, const TileAr
         return hipSuccess;
     }
     if (ev_start && ev_stop)
-        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(Body::NT), (uint32_t)lds, stream, ev_start, ev_stop, 0, a, f);
+        hipExtLaunchKernelGGL(kern, dim3(grid), dim3(Body::NT), (uint32_t)lds, stream, ev_start, ev_stop, 0, a, f, (unsigned)lds);
     else
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(Body::NT), lds, stream, a, f);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(Body::NT), lds, stream, a, f, (unsigned)lds);
     return hipGetLastError();
 }
 

@@ -178,6 +178,9 @@ int main(int argc, char **argv) {
         if (g_failed) std::_Exit(1);  // a failed device thread would leave the others at a barrier
     });
     for (auto &t : threads) t.join();
+    int comm_count = 0, nccl_version = 0;
+    (void)ncclCommCount(comms[0], &comm_count);
+    (void)ncclGetVersion(&nccl_version);
     for (int g = 0; g < G; ++g) ncclCommDestroy(comms[g]);
     if (g_failed) return 1;
 
@@ -194,6 +197,11 @@ int main(int argc, char **argv) {
         std::fclose(f);
     }
     const double ms = 1e3 * worst / steps, value = (double)total * (double)n * steps / worst / 1e9;
+    double fastest = worst;
+    for (double s : seconds) fastest = s < fastest ? s : fastest;
+    // the self-diagnosing keys of the N > 1 line (tests/golden/multi_gpu_line.schema.json; bench.py --gpus N prints the same
+    // ones): every device thread's own time, the ranks the communicator really has, the collective library's version
+    const int ranks_seen = comm_count;
     char name[128] = "";
     int cus = 0;
     phast_device_info(name, sizeof name, &cus, nullptr, nullptr);
@@ -203,7 +211,10 @@ int main(int argc, char **argv) {
                 "\"config\": {\"workload\": \"%zu independent f64 forward FFTs N=2^%d, %zu per GPU, in place (BASELINE configs[4])\", "
                 "\"host\": \"tests/cpp/shard_host.cpp: one C++ thread per device over the C ABI, no torch\", "
                 "\"digest_gather\": \"ncclAllGather of %zu x 32 B digests (librccl, ncclCommInitAll over %d device(s))\", "
-                "\"digests_finite\": %s, \"plan_used\": \"%s\", \"device\": \"%s\"}}\n",
-                log_n, value, G, steps, warmup, ms, total, log_n, shard, total, G, finite ? "true" : "false", plans[0].c_str(), name);
+                "\"digest_ok\": %s, \"plan_used\": \"%s\", \"device\": \"%s\", "
+                "\"rank_ms_min\": %.6f, \"rank_ms_max\": %.6f, \"ranks_seen\": %d, \"backend\": \"rccl\", \"shard\": %zu, "
+                "\"rccl_version\": \"%d.%d.%d\"}}\n",
+                log_n, value, G, steps, warmup, ms, total, log_n, shard, total, G, finite ? "true" : "false", plans[0].c_str(), name,
+                1e3 * fastest / steps, ms, ranks_seen, shard, nccl_version / 10000, (nccl_version / 100) % 100, nccl_version % 100);
     return finite ? 0 : 1;
 }

@@ -102,3 +102,65 @@ def test_bench_self_launch_command_is_the_drivers():
     assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
     assert cmd[-5].endswith("bench.py") and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+
+
+# ---------------------------------------------------------------- the N > 1 line's schema
+def validate_multi_gpu_line(line: dict):
+    """tests/golden/multi_gpu_line.schema.json: the keys both hosts of BASELINE configs[4] print.  Returns a list of problems."""
+    import json
+
+    schema = json.load(open(os.path.join(ROOT, "tests", "golden", "multi_gpu_line.schema.json")))
+    ok_type = {"string": lambda v: isinstance(v, str), "number": lambda v: isinstance(v, (int, float)) and not isinstance(v, bool),
+               "integer": lambda v: isinstance(v, int) and not isinstance(v, bool), "boolean": lambda v: isinstance(v, bool),
+               "object": lambda v: isinstance(v, dict), "null-or-number": lambda v: v is None or isinstance(v, (int, float))}
+    bad = []
+    for k, t in schema["top"]["required"].items():
+        if k not in line:
+            bad.append(f"missing {k}")
+        elif not ok_type[t](line[k]):
+            bad.append(f"{k}: not a {t}")
+    for k, v in schema["top"]["fixed"].items():
+        if line.get(k) != v:
+            bad.append(f"{k} != {v!r}")
+    cfg = line.get("config", {})
+    for k, t in schema["config"]["required"].items():
+        if k not in cfg:
+            bad.append(f"missing config.{k}")
+        elif not ok_type[t](cfg[k]):
+            bad.append(f"config.{k}: not a {t}")
+    for k, t in schema["config"]["optional"].items():
+        if k in cfg and not ok_type[t](cfg[k]):
+            bad.append(f"config.{k}: not a {t}")
+    if not bad:
+        if cfg["ranks_seen"] != line["n_gpus"]:
+            bad.append("config.ranks_seen != n_gpus")
+        if cfg["rank_ms_min"] > cfg["rank_ms_max"]:
+            bad.append("rank_ms_min > rank_ms_max")
+        if abs(cfg["rank_ms_max"] - line["ms_per_step"]) > 0.02 * line["ms_per_step"] + 0.05:
+            bad.append("rank_ms_max is not the step time")
+    return bad
+
+
+def test_multi_gpu_schema_and_both_hosts_name_its_keys():
+    """No GPU here: the schema loads, a well-formed line passes, broken ones are caught -- and the SOURCES of the two hosts
+    (bench.py's N > 1 branch, tests/cpp/shard_host.cpp's printf) carry every required key of `config` (the run itself is
+    tests/test_gpu_parity_r5.py::test_both_hosts_print_the_same_multi_gpu_schema on a GPU box)."""
+    import json
+
+    schema = json.load(open(os.path.join(ROOT, "tests", "golden", "multi_gpu_line.schema.json")))
+    good = {"metric": "GSamples/s f64 forward FFT N=2^20", "value": 660.0, "unit": "GSamples/s", "n_gpus": 8, "steps": 10, "warmup": 2,
+            "ms_per_step": 13.0, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "8192 ...", "plan_used": "throughput", "digest_gather": "all_gather ...", "digest_ok": True,
+                       "rank_ms_min": 12.7, "rank_ms_max": 13.0, "ranks_seen": 8, "backend": "nccl", "shard": 1024, "rccl_version": "2.26.6",
+                       "xgmi_links": 28}}
+    assert validate_multi_gpu_line(good) == []
+    assert validate_multi_gpu_line(dict(good, n_gpus=4)) == ["config.ranks_seen != n_gpus"]
+    broken = json.loads(json.dumps(good))
+    del broken["config"]["rank_ms_min"]
+    broken["config"]["shard"] = "1024"
+    assert validate_multi_gpu_line(broken) == ["missing config.rank_ms_min", "config.shard: not a integer"]
+    bench_src = open(os.path.join(ROOT, "bench.py")).read()
+    host_src = open(os.path.join(ROOT, "tests", "cpp", "shard_host.cpp")).read()
+    for k in schema["config"]["required"]:
+        assert f'"{k}"' in bench_src, f"bench.py does not print config.{k}"
+        assert f'\\"{k}\\"' in host_src, f"shard_host.cpp does not print config.{k}"

@@ -559,8 +559,19 @@ def test_torch_free_sharded_host_with_rccl_gather(gpu, oracle, tmp_path):
     assert len(line) == 1, r.stdout
     out = json.loads(line[0])
     total = shard * gpus
-    assert out["n_gpus"] == gpus and out["scaling"] == "weak" and out["config"]["digests_finite"] is True
+    assert out["n_gpus"] == gpus and out["scaling"] == "weak" and out["config"]["digest_ok"] is True
     assert "ncclAllGather" in out["config"]["digest_gather"]
+    # round 6: the line validates against the schema both hosts share, and so does bench.py's N > 1 line
+    # (two ranks on this box's one GPU through gloo: the same code path as the driver's torch.distributed.run launch)
+    from tests.test_bench_helpers import validate_multi_gpu_line
+
+    assert validate_multi_gpu_line(out) == [], out
+    rb = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--same-gpu", "--backend", "gloo", "--shard", "8",
+                         "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert rb.returncode == 0, rb.stdout[-2000:] + rb.stderr[-3000:]
+    bl = json.loads([ln for ln in rb.stdout.splitlines() if ln.startswith("{")][-1])
+    assert validate_multi_gpu_line(bl) == [], bl
+    assert bl["n_gpus"] == 2 and bl["config"]["ranks_seen"] == 2 and bl["config"]["backend"] == "gloo" and bl["config"]["shard"] == 8
     d = np.fromfile(dig, dtype=np.float64).reshape(total, 4)
     # Parseval on every transform: sum |X|^2 = N sum |x|^2, inputs regenerated with the same counter-based generator
     ids = sorted({0, 1, shard // 2, shard - 1, total - 1})
