@@ -32,7 +32,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", 
          "-ffp-contract=fast", "-Rpass-analysis=kernel-resource-usage"]
 # per-unit compiler options (the scheduling strategy is a translation-unit option: tile_dispatch.hpp says why)
 UNIT_FLAGS = {"tile_f64_bc_wide": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
-              "tile_f32_bc_wide": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
+              "tile_f32_bc_wide": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+              # the f32 wave / four-wave tiles run one wave per SIMD: registers are free, latency is not -- max-ilp issues the 15
+              # step-twiddle LDS reads of a tile up front instead of two ahead of their use (one f32 transform of 2^20 points
+              # 19.45 -> 19.10 us; the f64 twins did not move: profiles/r06_max_ilp_ab.log)
+              "wave_f32": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+              "quad_f32": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 RESOURCES = os.path.join(LIB_DIR, "kernel_resources.json")  # per kernel: VGPRs, scratch bytes per lane, occupancy, spills
 
 

@@ -275,6 +275,21 @@ template <typename T, bool ONE> __global__ void __launch_bounds__(256) quad_fft_
     cx *l_twq = l_tw3 + (3u << a.tw_bits);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: row bases and table rows live in SGPRs
+#ifdef PHAST_TRACE  // phase stamps (tools/trace_wave_quad.py): one row of 16 per wave of the first tile, lane 0 writes
+    int stamp_i = 0;
+    auto stamp = [&](bool drain) {
+        if (a.trace != nullptr) {
+            if (drain) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            if (lane == 0 && stamp_i < 16) a.trace[((size_t)blockIdx.x * 4 + (size_t)wave) * 16 + stamp_i] = now;
+            ++stamp_i;
+        }
+    };
+#define PHAST_STAMP(d) stamp(d)
+#else
+#define PHAST_STAMP(d)
+#endif
+    PHAST_STAMP(false);  // 0: entry
     typename Body::Regs r;
     // tables: global loads first, the first tile's loads right behind them (loads return in order: see wave_fft.hpp).
     // Four named registers, not an array: an array here lands in scratch memory as soon as control flow separates
@@ -289,6 +304,7 @@ template <typename T, bool ONE> __global__ void __launch_bounds__(256) quad_fft_
     if (t >= a.tiles_total) return;  // uniform over the workgroup
     Body::locate(a, t, r);
     Body::load_raw(a, wave, lane, r);
+    PHAST_STAMP(false);  // 1: loads issued
     if (tid < Body::TWQ) l_twq[tid] = twq_stage;
     if (i0 < n_tw3) l_tw3[i0] = ts0;
     if (i1 < n_tw3) l_tw3[i1] = ts1;
@@ -297,27 +313,37 @@ template <typename T, bool ONE> __global__ void __launch_bounds__(256) quad_fft_
     for (unsigned i = i3 + Body::NT; i < n_tw3; i += Body::NT) l_tw3[i] = g_tw3[i];
     for (;;) {
         __syncthreads();  // tables visible / the previous tile's exchange reads done
+        PHAST_STAMP(false);  // 2: tables staged, first barrier passed
+        PHAST_STAMP(true);   // 3: loads back
         Body::pre_twiddle(a, l_tw3, wave, lane, r);
         Body::steps12(l_twq, wave, lane, r);
+        PHAST_STAMP(false);  // 4: pre-twiddle + two radix-4 steps
         static_for<0, 16>([&](auto Q) {
             ex_re[Body::template waddr<decltype(Q)::value>(wave, lane)] = r.re[Q];
             ex_im[Body::template waddr<decltype(Q)::value>(wave, lane)] = r.im[Q];
         });
+        PHAST_STAMP(true);   // 5: exchange written
         __syncthreads();
+        PHAST_STAMP(false);  // 6: barrier passed
         static_for<0, 16>([&](auto Q) {
             r.re[Q] = ex_re[Body::template raddr<decltype(Q)::value>(wave, lane)];
             r.im[Q] = ex_im[Body::template raddr<decltype(Q)::value>(wave, lane)];
         });
+        PHAST_STAMP(true);   // 7: exchange read
         Body::step3(l_twq, lane, r);
         quad_lane_exchange<V>(r.re, r.im);
         Body::step4(r);
+        PHAST_STAMP(false);  // 8: last two radix-4 steps
         Body::store(a, wave, lane, r);
+        PHAST_STAMP(false);  // 9: stores issued
+        PHAST_STAMP(true);   // 10: stores retired
         if constexpr (ONE) break;
         t += gridDim.x;
         if (t >= a.tiles_total) break;
         Body::locate(a, t, r);
         Body::load_raw(a, wave, lane, r);
     }
+#undef PHAST_STAMP
 }
 
 template <typename T>

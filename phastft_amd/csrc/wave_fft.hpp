@@ -435,6 +435,22 @@ __global__ void __launch_bounds__((wave_block_threads<T>())) wave_fft_kernel(con
     // tables are not staged at all: a lane needs six entries (two three-level look-ups), read straight from global
     // memory (a few KiB, L2-resident).
     using V = typename Body::V;
+    // phase stamps: -DPHAST_TRACE builds only (tools/trace_wave_quad.py); one row of 16 per WAVE, lane 0 writes
+#ifdef PHAST_TRACE
+    int stamp_i = 0;
+    auto stamp = [&](bool drain) {
+        if (a.trace != nullptr) {
+            if (drain) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            if (lane == 0 && stamp_i < 16) a.trace[((size_t)blockIdx.x * Body::WAVES + (size_t)wave) * 16 + stamp_i] = now;
+            ++stamp_i;
+        }
+    };
+#define PHAST_STAMP(d) stamp(d)
+#else
+#define PHAST_STAMP(d)
+#endif
+    PHAST_STAMP(false);  // 0: entry
     typename Body::Regs r;
     Body::locate(a, blockIdx.x, blocks_total, (unsigned)wave, r);
     const cx twr_stage = reinterpret_cast<const cx *>(a.twr)[lane & 31];
@@ -446,7 +462,10 @@ __global__ void __launch_bounds__((wave_block_threads<T>())) wave_fft_kernel(con
     // pass for the copy model with this pass's arithmetic; nothing lost when there is no arithmetic).
     for (unsigned k = ((((blockIdx.x & 1u) << 2) | (unsigned)wave) & (stagger >> 8)) * (stagger & 255u); k > 0; --k)
         __builtin_amdgcn_s_sleep(1);
+    PHAST_STAMP(false);  // 1: the stagger's sleep is over
     Body::load_raw(a, lane, r);
+    PHAST_STAMP(false);  // 2: loads issued
+    PHAST_STAMP(true);   // 3: loads back
 #ifdef PHAST_WAVE_WAIT_ALL  // tools only: every load back before anything else happens
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -475,6 +494,7 @@ __global__ void __launch_bounds__((wave_block_threads<T>())) wave_fft_kernel(con
 #endif
     Body::step2(r);
 #endif
+    PHAST_STAMP(true);   // 4: arithmetic done
     if constexpr (TRANSPOSE) {
         // wave-private transposition: this wave writes and then reads its own buffer; LDS operations of one wave
         // execute in order, and the compiler's s_waitcnt lgkmcnt covers the data dependency -- no barrier
@@ -483,10 +503,15 @@ __global__ void __launch_bounds__((wave_block_threads<T>())) wave_fft_kernel(con
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         Body::xp_pick(xp, lane, r);
+        PHAST_STAMP(true);   // 5: through the transposing buffer
         Body::store_runs(a, lane, r);
     } else {
+        PHAST_STAMP(false);  // 5: (no transposition)
         Body::store_rows(a, lane, r);
     }
+    PHAST_STAMP(false);  // 6: stores issued
+    PHAST_STAMP(true);   // 7: stores retired
+#undef PHAST_STAMP
 }
 
 // host-side launcher
