@@ -167,7 +167,7 @@ struct PassGeom {
 };
 
 // Default factorisations of L = log2 N (L > kSmallMaxLog), from the exhaustive MI355X sweeps in profiles/
-// (r01_sweep_all_*.log).  What the sweeps say: a pass runs at the copy rate of its access
+// (r01_sweep_all_*.log; profiles/HISTORY.md section 5).  What the sweeps say: a pass runs at the copy rate of its access
 // pattern, and that rate is set by the contiguous segment a tile row covers (64 B rows ~3.0-3.7 TB/s, 128 B ~4.4,
 // >= 256 B ~4.6-5.3; 64-byte-row WRITES are the worst case), so
 //   * `throughput` (>= kThroughputWork points in flight): as few passes as possible with the widest rows the
@@ -582,7 +582,7 @@ inline bool spec_from_string(const char *t, PlanSpec &s) {
 
 // What a candidate is expected to cost before anything is timed -- only to ORDER the candidates, so that a tuning run cut
 // short by its budget has seen the likely ones: a pass moves 4 * sizeof(T) bytes per point at the copy rate of its row width
-// (>= 256-byte rows 5.0 TB/s, 128 bytes 4.4, 64 bytes 3.3, 32 bytes 2.0) plus a kernel boundary.
+// (profiles/HISTORY.md section 5: >= 256-byte rows 5.0 TB/s, 128 bytes 4.4, 64 bytes 3.3, 32 bytes 2.0) plus a kernel boundary.
 inline double plan_model_us(const std::vector<PassGeom> &ps, unsigned L, size_t batch, size_t elem_bytes) {
     double us = 0;
     const double points = (double)batch * (double)(1ull << L);

@@ -5,7 +5,7 @@
 // The untangle pairs Z[k] with Z[h - k], h = N/2.  In the last pass a tile holds ALL rows kc of its columns g
 // (k = kc M + g, M = 2^log_s_in columns, R = 2^LR rows), and h - k = (R - 1 - kc) M + (M - g): the partner lives in the
 // MIRRORED column M - g, so no aligned tiling of the columns is closed under the pairing (an interval [g0, g0 + C) mirrors to
-// (M - g0 - C, M - g0]: always off by one; DESIGN.md section 10 has the dead ends this leads to: orphan columns, partial
+// (M - g0 - C, M - g0]: always off by one; profiles/HISTORY.md section 10 has the dead ends this leads to: orphan columns, partial
 // lines).  What makes the fusion cheap is an identity:
 //
 //     conj Z[R - 1 - kc][M - g]  =  sum_u conj(s[u][M - g]) W_N'^(u g) W_R^(u kc)           (N' = R M = h)

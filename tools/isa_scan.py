@@ -4,7 +4,7 @@ followed by `s_waitcnt vmcnt(0)` before the next load goes out, several times in
 round trip the wave sits through alone.  Round 4 found the one-pass kernel's Complex<T> pair loads (16 in a row, fixed:
 2^12 on pairs 11.7 -> 8.6 us) and the fused R2C untangle's table loads (16 in a row, now 4 x 4) this way.  A chain is not
 always a bug: the compiler serialises on purpose where keeping the loads in flight would cost registers past an occupancy
-step (the 32-point f32 first passes, the f64 fused C2R first pass: DESIGN.md section 9a) -- compare
+step (the 32-point f32 first passes, the f64 fused C2R first pass: profiles/HISTORY.md section 9a) -- compare
 phastft_amd/lib/kernel_resources.json before and after a change.
     python tools/isa_scan.py [--min 3] [--show KERNEL_SUBSTRING]"""
 import argparse, concurrent.futures as cf, os, re, subprocess, sys, tempfile
