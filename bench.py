@@ -180,7 +180,7 @@ def kernel_tags(plan_list: str, dtype: str = "double"):
         if kind == "w":
             tags.append(f"wave_fft_kernel<{dtype}, {flags}>")
         elif kind == "q":
-            tags.append(f"quad_fft_kernel<{dtype}>")
+            tags.append(f"quad_fft_kernel<{dtype}")   # (+ ", true>": one tile per workgroup, ", false>": the persistent form)
         else:
             tags.append(f"tile_fft_kernel<{dtype}, {int(math.log2(int(rows)))}, {int(math.log2(int(cols)))}, "
                         f"{int(math.log2(int(pts)))}, {flags},")

@@ -28,6 +28,8 @@ pmc single_2p26 2147483648 single2p26 python $R/tools/prof_workloads.py big --it
 pmc r2c_f32_2p24 134217728 r2c_f32_2p24 python $R/tools/prof_workloads.py r2c --iters 10
 pmc c2r_f32_2p24 134217728 c2r_f32_2p24 python $R/tools/prof_workloads.py c2r --iters 10
 pmc batch_2p20 34359738368 batch1024_2p20 python $R/tools/prof_workloads.py batch --batch 1024 --iters 3
+pmc f32_2p20 16777216 f32_2p20 python $R/tools/prof_workloads.py single --dtype f32 --iters 20
+pmc f32_2p26 1073741824 f32_2p26 python $R/tools/prof_workloads.py big --dtype f32 --iters 4
 # 3. where the wave cycles go (SQ counters, one pass of 8)
 for w in single big; do
     rm -rf /tmp/prof_sq
