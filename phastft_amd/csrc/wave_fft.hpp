@@ -89,7 +89,9 @@ template <typename T, bool PRE_TW, bool TRANSPOSE> struct WaveBody {
     // gets one contiguous run of workgroups (cf. TileBody::locate)
     PHAST_HD static void locate(const TileArgs &a, unsigned block, unsigned blocks_total, unsigned wave, Regs &r) {
         const unsigned b = ((blocks_total & 7u) == 0u) ? (block & 7u) * (blocks_total >> 3) + (block >> 3) : block;
-        const unsigned tile = b * WAVES + wave;
+        locate_tile(a, b * WAVES + wave, r);
+    }
+    PHAST_HD static void locate_tile(const TileArgs &a, unsigned tile, Regs &r) {
         r.xform = tile >> (unsigned)__builtin_ctz(a.tiles_per_xform);  // a power of two (plan.hpp: geom_to_args)
         const unsigned ti = tile & (a.tiles_per_xform - 1u);
         r.g0 = a.cs_bits ? (((ti >> a.cb_bits) << a.cs_bits) | ((ti & ((1u << a.cb_bits) - 1u)) << LC)) : (ti << LC);
@@ -514,6 +516,83 @@ __global__ void __launch_bounds__((wave_block_threads<T>())) wave_fft_kernel(con
 #undef PHAST_STAMP
 }
 
+// ---- two tiles per wave, software-pipelined ("build it, do not model it again") ----
+// Half as many waves, each owning the tiles (2 t, 2 t + 1): both tiles' loads go out back to back (64 loads in flight per
+// lane, two register sets), tile 2 t is computed and stored while tile 2 t + 1's loads are still arriving, then tile 2 t + 1.
+// One wave per SIMD leaves registers free (2 x 64 data VGPRs + temporaries), so the second set costs nothing in occupancy.
+// What the copy model promised (profiles/r02_pipelining_floor.log: 7.3 -> 6.8 us per pass at this pass's arithmetic) assumed
+// the arithmetic is what a pass waits for; measured on the real kernels -- PHAST_WAVE_PIPELINE=1, same-box A/B in
+// profiles/r06_pipelined_tiles_ab.log -- half the SIMDs idle costs more than the overlap gives.  Kept behind the switch.
+template <typename T, bool PRE_TW, bool TRANSPOSE>
+__global__ void __launch_bounds__((wave_block_threads<T>())) wave_fft2_kernel(const TileArgs a, unsigned blocks_total, unsigned stagger) {
+    using Body = WaveBody<T, PRE_TW, TRANSPOSE>;
+    using cx = cx_t<T>;
+    using V = typename Body::V;
+    pin_tile_args(a);
+    pin_scalars(blocks_total, stagger);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    cx *l_twr = reinterpret_cast<cx *>(smem + (size_t)wave * (64 * sizeof(cx) + (size_t)2 * Body::XP * sizeof(T)));
+    T *xp = reinterpret_cast<T *>(l_twr + 64);
+    // slot s of the launch = tiles 2 s and 2 s + 1; slots are dealt to the workgroups in the XCD-aware order of Body::locate
+    const unsigned b = ((blocks_total & 7u) == 0u) ? (blockIdx.x & 7u) * (blocks_total >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const unsigned slot = b * Body::WAVES + (unsigned)wave;
+    if (2u * slot >= a.tiles_total) return;
+    typename Body::Regs r0, r1;
+    Body::locate_tile(a, 2u * slot, r0);
+    Body::locate_tile(a, 2u * slot + 1u, r1);
+    const cx twr_stage = reinterpret_cast<const cx *>(a.twr)[lane & 31];
+    typename Body::TwRaw tw0, tw1;
+    if constexpr (PRE_TW) {
+        tw0 = Body::pre_twiddle_fetch(a, reinterpret_cast<const cx *>(a.tw3), lane, r0);
+        tw1 = Body::pre_twiddle_fetch(a, reinterpret_cast<const cx *>(a.tw3), lane, r1);
+    }
+    for (unsigned k = ((((blockIdx.x & 1u) << 2) | (unsigned)wave) & (stagger >> 8)) * (stagger & 255u); k > 0; --k)
+        __builtin_amdgcn_s_sleep(1);
+    Body::load_raw(a, lane, r0);
+    Body::load_raw(a, lane, r1);  // in flight while tile 0 is computed and stored (loads return in order: tile 0's first)
+    {
+        cx w = twr_stage;
+        if (lane & 32) {
+            w.x = -w.x;
+            w.y = -w.y;
+        }
+        l_twr[lane] = w;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    auto finish = [&](typename Body::Regs &r, const typename Body::TwRaw &tw) {
+        if constexpr (PRE_TW) Body::pre_twiddle_apply(tw, r);
+        Body::step1(l_twr, lane, r);
+        wave_exchange<V>(r.re, r.im);
+        Body::step2(r);
+        if constexpr (TRANSPOSE) {
+            Body::xp_park(xp, lane, r);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            Body::xp_pick(xp, lane, r);
+            Body::store_runs(a, lane, r);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the buffer is free again before the next tile parks
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else {
+            Body::store_rows(a, lane, r);
+        }
+    };
+    finish(r0, tw0);
+    finish(r1, tw1);
+}
+inline bool wave_pipeline_enabled() {  // PHAST_WAVE_PIPELINE=1: two tiles per wave (wave_fft2_kernel); tools, A/B
+    static const bool on = [] {
+        const char *e = getenv("PHAST_WAVE_PIPELINE");
+        return e && *e == '1';
+    }();
+    return on;
+}
+
 // host-side launcher
 template <typename T, bool PRE_TW, bool TRANSPOSE>
 hipError_t launch_wave_inst(hipStream_t stream, const TileArgs &a, bool query_only, int *blocks_per_cu, size_t *lds_out,
@@ -541,6 +620,18 @@ hipError_t launch_wave_inst(hipStream_t stream, const TileArgs &a, bool query_on
                                                       : ((unsigned long long)Body::COLS * a.out_s1 + 16ull * a.out_row_stride) * esz;
         if (in_span >= (1ull << 32) || out_span >= (1ull << 32)) return hipErrorInvalidValue;
         if (Body::VW == 2 && (TRANSPOSE ? a.out_row_stride != 1 : a.out_s1 != 1)) return hipErrorInvalidValue;
+    }
+    if (wave_pipeline_enabled() && (a.tiles_total % (2u * Body::WAVES)) == 0u) {  // two tiles per wave: half the waves
+        auto kern2 = wave_fft2_kernel<T, PRE_TW, TRANSPOSE>;
+        static PerDeviceLimit lds_limit2;
+        if (hipError_t e = raise_lds_limit(lds_limit2, reinterpret_cast<const void *>(kern2), lds); e != hipSuccess) return e;
+        const unsigned blocks2 = a.tiles_total / (2u * Body::WAVES);
+        const unsigned stagger2 = a.tiles_total <= 2048u ? wave_stagger_setting() : 0u;
+        if (ev_start && ev_stop)
+            hipExtLaunchKernelGGL(kern2, dim3(blocks2), dim3(Body::NT), (uint32_t)lds, stream, ev_start, ev_stop, 0, a, blocks2, stagger2);
+        else
+            hipLaunchKernelGGL(kern2, dim3(blocks2), dim3(Body::NT), lds, stream, a, blocks2, stagger2);
+        return hipGetLastError();
     }
     const unsigned blocks = (a.tiles_total + Body::WAVES - 1) / Body::WAVES;
     // the stagger pays when every wave of the launch is resident at once and they would all move in step: at most one
