@@ -933,6 +933,21 @@ def main():
         # steps work in place), reported beside ms_per_step, never instead of it
         head_stats = replay_stats(torch, graph.replay if graph is not None else (lambda: [step(warmup + i) for i in range(steps)]),
                                   steps, 1e3 * elapsed, refill=lambda: P.fill_uniform(re, im, N, seed=0xCAFE, first_id=0))
+        # ... and, for information only (never `value`): the same K-step region with the graph ALREADY QUEUED behind a running
+        # kernel when the start event is reached -- the host's launch of the graph (10-20 us, once per K steps: 0.5-1 us per
+        # step at K = 20) then happens while the GPU is busy with that kernel, outside the events
+        if graph is not None:
+            spin_re = torch.empty(8 << 20, dtype=torch.float64, device=dev)
+            spin_im = torch.empty_like(spin_re)
+            torch.cuda.synchronize()
+            q0, q1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            P.fill_uniform(spin_re, spin_im, 8 << 20, seed=1, first_id=0)   # ~128 MiB written: tens of microseconds of GPU work
+            q0.record()
+            graph.replay()
+            q1.record()
+            torch.cuda.synchronize()
+            head_stats["ms_per_step_queued"] = q0.elapsed_time(q1) / steps
+            del spin_re, spin_im
         samples_per_step = N
         workload = f"single f64 forward FFT N=2^{LOG_N}, in place, planar (BASELINE configs[1])"
         # --- roofline of the dominant pass kernel, HIP events bound to the dispatches (fresh buffers) ---
@@ -1103,6 +1118,7 @@ def main():
             r = c.get("roofline", {})
             vals = {"gsps": c["value"], "ms": c["ms_per_step"], "frac_transform": r.get("frac_transform"), "frac_pass": r.get("frac"),
                     "ms_min": c.get("ms_per_step_min"), "ms_median": c.get("ms_per_step_median"), "static_ms": c.get("static_ms"),
+                    "ms_queued": c.get("ms_per_step_queued"),
                     "cpu_gsps": c.get("cpu_baseline", {}).get("value"),
                     "traffic_x": (r["traffic"] / r["algorithmic_bytes_per_launch"]) if r.get("traffic") else None}
             for k in keys:
@@ -1111,7 +1127,7 @@ def main():
 
         head = {"value": value, "ms_per_step": ms_per_step, "roofline": roofline, **(head_stats if not multi else {}),
                 "cpu_baseline": out.get("cpu_baseline", {})}
-        flat("n2p20", head, ("gsps", "ms", "ms_min", "ms_median", "frac_transform", "frac_pass", "cpu_gsps", "traffic_x"))
+        flat("n2p20", head, ("gsps", "ms", "ms_min", "ms_median", "ms_queued", "frac_transform", "frac_pass", "cpu_gsps", "traffic_x"))
         names = {"n2p26_forward": "n2p26", "n2p26_roundtrip": "rt2p26", "r2c_f32_2p24": "r2c_f32_2p24", "c2r_f32_2p24": "c2r_f32_2p24",
                  "f32_2p20": "f32_2p20", "f32_2p26": "f32_2p26"}
         for name, c in out.get("configs", {}).items():
