@@ -158,3 +158,37 @@ def test_builtin_wisdom_is_not_slower_than_the_static_rules_on_this_box(gpu):
         with open(path, "w") as f:
             f.write("\n".join(report) + "\n")
     assert not bad, "built-in wisdom plans slower than the static rules on this box:\n" + "\n".join(bad)
+
+
+def test_set_plan_beats_builtin_wisdom_and_the_restore_form_brings_it_back(gpu, oracle):
+    """`phast_planner_*_set_plan` used to be silently ignored for every (kind, bucket) that had a tuned or
+    built-in-wisdom plan -- `choose()` asked the tuned table first.  On a length whose ONE-transform call has a built-in line:
+    the planner starts `tuned`, a forced plan runs (`describe_call` says `forced` and names ITS passes, for every batch and kind),
+    the result is still right, and the restore form (no passes) puts the tuned plan back."""
+    import torch
+
+    from tests import tolerances as tol
+
+    lines = [ln for ln in builtin_lines() if ln[0] == "f64" and ln[1] == "c2c" and ln[3] == 0 and 14 <= ln[2] <= 22]
+    if not lines:
+        pytest.skip("no built-in line for one f64 C2C transform")
+    L = lines[0][2]
+    n = 1 << L
+    was = gpu.wisdom_builtin(True)
+    try:
+        pl = gpu.PlannerDit64(n)
+    finally:
+        gpu.wisdom_builtin(was)
+    assert pl.describe_call(1, 0).startswith("tuned"), pl.describe_call(1, 0)
+    a, b = L // 2, L - L // 2
+    pl.set_plan((b, a), 12 if L <= 20 else 13, 3)
+    forced = pl.describe_call(1, 0)
+    assert forced.startswith("forced") and f"[{1 << b}x" in forced, forced
+    assert pl.describe_call(64, 0).startswith("forced") and pl.describe_call(1, 1).startswith("forced")
+    h_re, h_im = oracle.fill(n, np.float64, seed=0x5E7, transform_id=L)
+    z = np.fft.fft(h_re + 1j * h_im)
+    d_re, d_im = torch.from_numpy(h_re.copy()).cuda(), torch.from_numpy(h_im.copy()).cuda()
+    gpu.fft_64_dit_with_planner(d_re, d_im, gpu.Direction.Forward, pl)
+    tol.check("forced_over_wisdom", "f64", L, d_re.cpu().numpy(), d_im.cpu().numpy(), z.real, z.imag)
+    pl.set_plan()                      # the restore form: the library's own plans, wisdom in force again
+    assert pl.describe_call(1, 0).startswith("tuned"), pl.describe_call(1, 0)
