@@ -66,7 +66,22 @@ template <typename T, bool PRE_TW, bool TRANSPOSE> struct WaveBody {
 #ifndef PHAST_WQ_NT_STORES
 #define PHAST_WQ_NT_STORES 1
 #endif
-    static constexpr bool NT_LOAD = PHAST_WQ_NT_LOADS, NT_STORE = PHAST_WQ_NT_STORES;
+    // cache policy per pass position (tools: -DPHAST_WAVE_NT_A_STORES=0 etc.; measured in profiles/r06_cache_policy_ab.log):
+    // the first pass reads the caller's (cold) array and writes the scratch, the later passes read the scratch
+#ifndef PHAST_WAVE_NT_A_LOADS
+#define PHAST_WAVE_NT_A_LOADS PHAST_WQ_NT_LOADS
+#endif
+#ifndef PHAST_WAVE_NT_A_STORES
+#define PHAST_WAVE_NT_A_STORES PHAST_WQ_NT_STORES
+#endif
+#ifndef PHAST_WAVE_NT_C_LOADS
+#define PHAST_WAVE_NT_C_LOADS PHAST_WQ_NT_LOADS
+#endif
+#ifndef PHAST_WAVE_NT_C_STORES
+#define PHAST_WAVE_NT_C_STORES PHAST_WQ_NT_STORES
+#endif
+    static constexpr bool NT_LOAD = TRANSPOSE ? PHAST_WAVE_NT_A_LOADS : PHAST_WAVE_NT_C_LOADS;
+    static constexpr bool NT_STORE = TRANSPOSE ? PHAST_WAVE_NT_A_STORES : PHAST_WAVE_NT_C_STORES;
     // a register's worth in the caller's memory: aligned to ONE ELEMENT only (`&mut v[1..]` is a legal slice: no more than
     // element alignment may be assumed of a caller's pointer; the hardware takes unaligned dword-multiple accesses)
     typedef V VU __attribute__((aligned(sizeof(T))));
