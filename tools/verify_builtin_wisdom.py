@@ -6,7 +6,8 @@ the same kernels back to back without the launch gaps, and a plan that wins by 4
 the second (round 6: `f32 r2c 22 0` claimed +4.8 %, ran 41.7 us against the static rule's 36.4 us in the size ladder of
 profiles/r06_vs_r05_size_ladder.log).  This tool replays, for EVERY line, the interleaved A/B of tests/test_gpu_wisdom.py
 (wisdom plan against the static rule, HIP graph of the calls on a cold ring, medians of 7 rounds) and rewrites the table
-with the lines that are faster in BOTH protocols by at least --keep (default 2 %).  Lines too large to replay twice in
+with the lines that are faster in BOTH protocols by at least --keep (default 0.96: 4 %; --keep-large, 8 %, from 2^25 points in
+flight on).  Lines too large to replay twice in
 memory (more than 2^--max-points points in flight) are dropped.
 
     python tools/verify_builtin_wisdom.py [--inc phastft_amd/csrc/builtin_wisdom.inc] [--out gpurun_out/builtin_wisdom.verified.inc]
@@ -31,7 +32,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--inc", default=os.path.join(ROOT, "phastft_amd", "csrc", "builtin_wisdom.inc"))
 ap.add_argument("--out", default="gpurun_out/builtin_wisdom.verified.inc")
 ap.add_argument("--log", default="gpurun_out/wisdom_verify.log")
-ap.add_argument("--keep", type=float, default=0.98, help="a line stays if graph-protocol time(wisdom) <= keep * time(static)")
+ap.add_argument("--keep", type=float, default=0.96, help="a line stays if graph-protocol time(wisdom) <= keep * time(static)")
+ap.add_argument("--keep-large", type=float, default=1 / 1.08, help="the same from 2^25 points in flight on, where the placement of a planner's "
+                "scratch moves a call by +-5 %% whatever the plan (profiles/r04_placement_probe.log; bench.py read `f32 c2c 26 0`, +5 %% here, as -5 %% and 0 %%)")
 ap.add_argument("--max-points", type=int, default=28)
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--imported", action="store_true", help="--inc is a fresh table that is NOT compiled into the library yet: its lines are imported "
@@ -74,7 +77,7 @@ if a.imported:
     GPU = ImportedTable("\n".join(re.findall(r'^"(.*)\\n"$', "\n".join(src), flags=re.M)) + "\n")
 info = P.device_info()
 say(f"# {info['name']} {info['compute_units']} CUs; wisdom plan vs static rule, HIP graph on a cold ring, median of {a.rounds} interleaved rounds")
-say(f"# a line stays if on <= {a.keep} * off; input {os.path.relpath(a.inc, ROOT)}")
+say(f"# a line stays if on <= {a.keep} * off ({a.keep_large:.3f} from 2^25 points in flight on); input {os.path.relpath(a.inc, ROOT)}")
 kept, dropped, t0 = [], 0, time.time()
 for ln in src:
     m = LINE.match(ln)
@@ -106,7 +109,7 @@ for ln in src:
         dropped += 1
         torch.cuda.empty_cache()
         continue
-    ok = m_on <= a.keep * m_off
+    ok = m_on <= (a.keep_large if points >= 25 else a.keep) * m_off
     say(f"{tag}: {'keep' if ok else 'DROP'}  graph {m_on:.2f} vs static {m_off:.2f} us ({100 * (m_off / m_on - 1):+.1f} %); tuner said {us:.2f} vs {heur:.2f} "
         f"({100 * (heur / us - 1):+.1f} %)  {plan}")
     if ok:
@@ -119,6 +122,6 @@ with open(a.out, "w") as f:
     for ln in kept:
         if ln.startswith("// Plans the in-library tuner"):
             ln = ("// Plans the in-library tuner (tune.hpp) measured to beat the static rules of plan.hpp by more than 3 % AND that "
-                  "tools/verify_builtin_wisdom.py measured >= 2 % faster again as a HIP graph on a cold ring, in the text format of")
+                  "tools/verify_builtin_wisdom.py measured >= 4 % faster again (8 % from 2^25 points in flight on) as a HIP graph on a cold ring, in the text format of")
         f.write(ln + "\n")
 say(f"# kept {sum(1 for ln in kept if LINE.match(ln))} lines, dropped {dropped}, {time.time() - t0:.0f} s -> {a.out}")
