@@ -260,7 +260,8 @@ template <typename T> __device__ __forceinline__ void quad_lane_exchange(T (&re)
     });
 }
 
-// (Staggering the workgroups' or the waves' first loads, as wave_fft.hpp does, buys nothing here: profiles/r02_stagger.log.)
+// (Staggering the workgroups' or the waves' first loads, as wave_fft.hpp does, buys nothing here: profiles/r02_stagger.log, and again
+//  on this round's SGPR-base kernel with groups (block >> 3) & mask sleeping 2 .. 16 units: profiles/r06_quad_stagger_ab.log.)
 // ONE: the grid has one workgroup per tile (a single transform: 256 tiles on 256 CUs) -- no tile loop, so the second
 // load site, its hoisted 64-bit lane offsets and the SGPRs parked in VGPR lanes across the loop are gone.
 template <typename T, bool ONE> __global__ void __launch_bounds__(256) quad_fft_kernel(const TileArgs a) {
