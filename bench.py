@@ -207,15 +207,38 @@ def roofline_of(pass_ms, alg_bytes, names=None, plan_used="", traffic_key=None, 
     }, dom
 
 
-def replay_stats(torch, run, steps: int, first_ms: float, refill=None, extra: int = 2):
+_DRAIN = {}
+
+
+def settle(torch, P, refill=None):
+    """ONE defined state in front of every timed region: inputs as generated, resident in HBM -- and nothing of them, nor of
+    the kernel that wrote them, left in the caches.  Whatever ran last (the fill, the untimed replay) leaves up to 256 MiB of
+    DIRTY lines in the Infinity Cache; their write-back then competes with the timed steps, and how much of it lands inside
+    the region depends on what ran before (tools/replay_variance.py, profiles/r06_replay_variance.log: the same 20-step graph of
+    f32 2^20 transforms reads 18.5 / 20.8 / 23.7 / 22.4 us per step in a period of four behind `refill; synchronize`, and 17.9-18.1
+    every time behind refill + drain).  The drain READS 768 MiB of a buffer nothing else uses (the digest kernel: three times
+    the cache), so the dirty lines are written back before the region starts and the cache holds clean lines of no use to it."""
+    if refill is not None:
+        refill()
+    if os.environ.get("PHAST_BENCH_NO_DRAIN"):   # tools only: the protocol without the drain, for the A/B in profiles/r06_replay_variance.log
+        torch.cuda.synchronize()
+        return
+    dev = torch.cuda.current_device()
+    if dev not in _DRAIN:
+        re = torch.zeros(48 << 20, dtype=torch.float64, device="cuda")
+        _DRAIN[dev] = (re, torch.zeros_like(re))
+    P.digest(_DRAIN[dev][0], _DRAIN[dev][1], 1 << 20)
+    torch.cuda.synchronize()
+
+
+def replay_stats(torch, run, steps: int, first_ms: float, before=None, extra: int = 2):
     """"median and min".  `first_ms` is the contract's timed region (EXACTLY K steps, once); `extra` more
-    K-step regions are timed after it -> per-step min / median over the 1 + extra regions.  The regions run back to back on
-    the same ring WITHOUT a refill in between (in-place steps transform their buffers again: values grow by <= N per step,
-    three regions stay far from overflow in either type) -- a refill's write-back tail would run into the timed region and
-    the regions would not start from the state the first one started from (the untimed replay before it)."""
-    del refill
+    K-step regions are timed after it -> per-step min / median over the 1 + extra regions.  `before()` puts every region into
+    the state the first one started from (`settle`: inputs re-generated where the steps work in place, caches drained)."""
     per = [first_ms / steps]
     for _ in range(extra):
+        if before is not None:
+            before()
         torch.cuda.synchronize()
         per.append(event_ms(torch, run) / steps)
     per.sort()
@@ -238,7 +261,11 @@ def static_rule_ms(P, torch, used: str, make_planner, make_step, steps: int):
     torch.cuda.synchronize()
     graph, _ = capture_steps(torch, P, step, 3, steps, touch=lambda: step(0))
     run = graph.replay if graph is not None else (lambda: [step(3 + i) for i in range(steps)])
-    per = sorted(event_ms(torch, run) / steps for _ in range(3))
+    per = []
+    for _ in range(3):
+        settle(torch, P)
+        per.append(event_ms(torch, run) / steps)
+    per.sort()
     del graph, q
     return per[1]
 
@@ -347,11 +374,11 @@ def config_f32(P, torch, dev, log_n: int, steps: int, cpu: bool):
         step(i)
     torch.cuda.synchronize()
     graph, launch = capture_steps(torch, P, step, 3, steps, touch=lambda: step(0))
-    P.fill_uniform(re, im, n, seed=0xCAFE, first_id=0)
-    torch.cuda.synchronize()
+    fresh = lambda: settle(torch, P, refill=lambda: P.fill_uniform(re, im, n, seed=0xCAFE, first_id=0))
+    fresh()
     run = graph.replay if graph is not None else (lambda: [step(3 + i) for i in range(steps)])
     ms = event_ms(torch, run) / steps
-    stats = replay_stats(torch, run, steps, ms * steps, refill=lambda: P.fill_uniform(re, im, n, seed=0xCAFE, first_id=0))
+    stats = replay_stats(torch, run, steps, ms * steps, before=fresh)
     P.fill_uniform(re, im, n, seed=0xCAFE, first_id=0)
     torch.cuda.synchronize()
     acc, reps = None, min(ring, 16)
@@ -404,7 +431,7 @@ def config_n2p26(P, torch, dev, steps: int, cpu: bool):
 
     ms = event_ms(torch, forward_all) / steps
     stats = replay_stats(torch, forward_all, steps, ms * steps,
-                         refill=lambda: P.fill_uniform(ring_re, ring_im, n, seed=0xCAFE, first_id=0))
+                         before=lambda: settle(torch, P, refill=lambda: P.fill_uniform(ring_re, ring_im, n, seed=0xCAFE, first_id=0)))
     P.fill_uniform(re, im, n, seed=0xCAFE)
     pass_ms = pl.time_passes(re, im, n, reps=3)
     used, plan_list = plan_used(pl, 1)
@@ -477,8 +504,9 @@ def config_r2c(P, torch, dev, steps: int, cpu: bool):
     # the launch stream) -- the Python + ctypes launch path is not the product
     graph, launch = capture_steps(torch, P, step, 0, steps, touch=lambda: step(0))
     run = graph.replay if graph is not None else (lambda: [step(i) for i in range(steps)])
+    settle(torch, P)   # (inputs are read-only: nothing to re-generate; the outputs of the untimed replay leave the caches)
     ms = event_ms(torch, run) / steps
-    stats = replay_stats(torch, run, steps, ms * steps)
+    stats = replay_stats(torch, run, steps, ms * steps, before=lambda: settle(torch, P))
     acc = None
     for i in range(ring):
         t = pl.time_passes(*sets[i], reps=1)
@@ -546,8 +574,9 @@ def config_c2r(P, torch, dev, steps: int, cpu: bool):
     torch.cuda.synchronize()
     graph, launch = capture_steps(torch, P, step, 0, steps, touch=lambda: step(0))   # the headline's protocol (config_r2c)
     run = graph.replay if graph is not None else (lambda: [step(i) for i in range(steps)])
+    settle(torch, P)   # (inputs are read-only: nothing to re-generate; the outputs of the untimed replay leave the caches)
     ms = event_ms(torch, run) / steps
-    stats = replay_stats(torch, run, steps, ms * steps)
+    stats = replay_stats(torch, run, steps, ms * steps, before=lambda: settle(torch, P))
     acc = None
     for i in range(ring):
         t = pl.time_c2r_passes(*sets[i], reps=1)
@@ -911,8 +940,10 @@ def main():
             graph, launch = capture_steps(
                 torch, P, step, warmup, steps,
                 touch=lambda: P.fft_64_dit_with_planner(*views[0], P.Direction.Forward, planner))
-            P.fill_uniform(views[0][0], views[0][1], N, seed=0xCAFE, first_id=0)
-        torch.cuda.synchronize()
+        # every buffer of the ring as generated again (the warm-up steps and the untimed replay transformed theirs), and the caches
+        # drained of what those left behind: the K timed steps find their inputs in HBM and nowhere else (`settle`)
+        fresh = lambda: settle(torch, P, refill=lambda: P.fill_uniform(re, im, N, seed=0xCAFE, first_id=0))
+        fresh()
         # HIP events around the K timed steps, on the stream they are launched on (torch's current
         # stream: the graph replay / the library's launches go there); the wall clock around the same region --
         # synchronize, K steps, synchronize -- is kept beside it as ms_per_step_wall (it adds the fixed ~50 us of one graph
@@ -932,7 +963,7 @@ def main():
         # SURVEY.md 8(d) "median and min": two more K-step regions after the contract's one (ring re-filled before each: the
         # steps work in place), reported beside ms_per_step, never instead of it
         head_stats = replay_stats(torch, graph.replay if graph is not None else (lambda: [step(warmup + i) for i in range(steps)]),
-                                  steps, 1e3 * elapsed, refill=lambda: P.fill_uniform(re, im, N, seed=0xCAFE, first_id=0))
+                                  steps, 1e3 * elapsed, before=fresh)
         # ... and, for information only (never `value`): the same K-step region with the graph ALREADY QUEUED behind a running
         # kernel when the start event is reached -- the host's launch of the graph (10-20 us, once per K steps: 0.5-1 us per
         # step at K = 20) then happens while the GPU is busy with that kernel, outside the events

@@ -113,7 +113,16 @@ def _bench_call(gpu, torch, dt, kind, L, bucket, wisdom_on, reuse=None):
     return run, steps, pl.describe_call(batch, kind_id), (pl, keep, g)
 
 
-def _time(torch, run, steps):
+def _time(torch, run, steps, gpu=None):
+    """us per call of one replay; with `gpu` (the module) the caches are drained first (bench.py: settle -- what the previous
+    replay left dirty in the Infinity Cache would otherwise be written back inside this one)"""
+    if gpu is not None:
+        import sys
+
+        sys.path.insert(0, ROOT)
+        from bench import settle
+
+        settle(torch, gpu)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     run()
@@ -142,8 +151,8 @@ def test_builtin_wisdom_is_not_slower_than_the_static_rules_on_this_box(gpu):
         def measure(rounds):
             t_on, t_off = [], []
             for _ in range(rounds):      # interleaved: what drifts (clocks, neighbours) hits both alike
-                t_on.append(_time(torch, on[0], on[1]))
-                t_off.append(_time(torch, off[0], off[1]))
+                t_on.append(_time(torch, on[0], on[1], gpu))
+                t_off.append(_time(torch, off[0], off[1], gpu))
             return float(np.median(t_on)), float(np.median(t_off))
 
         m_on, m_off = measure(5)

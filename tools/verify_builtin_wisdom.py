@@ -5,7 +5,7 @@ The in-library tuner (csrc/tune.hpp) ranks plans by eager launches over a ring; 
 the same kernels back to back without the launch gaps, and a plan that wins by 4 % in the first protocol can lose by 10 % in
 the second (round 6: `f32 r2c 22 0` claimed +4.8 %, ran 41.7 us against the static rule's 36.4 us in the size ladder of
 profiles/r06_vs_r05_size_ladder.log).  This tool replays, for EVERY line, the interleaved A/B of tests/test_gpu_wisdom.py
-(wisdom plan against the static rule, HIP graph of the calls on a cold ring, medians of 7 rounds) and rewrites the table
+(wisdom plan against the static rule, HIP graph of the calls on a cold ring, caches drained before every replay, medians of 7 rounds) and rewrites the table
 with the lines that are faster in BOTH protocols by at least --keep (default 0.96: 4 %; --keep-large, 8 %, from 2^25 points in
 flight on); a line between 2 % and 4 % stays if the tuner's own margin was 8 % or more.  Lines too large to replay twice in
 memory (more than 2^--max-points points in flight) are dropped.
@@ -101,8 +101,8 @@ for ln in src:
         off = _bench_call(GPU, torch, dt, kind, L, bucket, False, reuse=on[3])
         t_on, t_off = [], []
         for _ in range(a.rounds):
-            t_on.append(_time(torch, on[0], on[1]))
-            t_off.append(_time(torch, off[0], off[1]))
+            t_on.append(_time(torch, on[0], on[1], P))
+            t_off.append(_time(torch, off[0], off[1], P))
         m_on, m_off = float(np.median(t_on)), float(np.median(t_off))
     except (P.PhastHipError, P.PhastPanic, RuntimeError) as e:
         say(f"{tag}: DROP ({type(e).__name__}: {str(e)[:80]})")
