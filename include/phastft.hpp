@@ -14,6 +14,7 @@
 //   c2r_fft_f64/f32[_with_planner[_and_scratch]]    r2c.rs:695,710,740,804,813,836
 //   fft_*_interleaved[_with_planner[_and_opts]]     lib.rs:50,87,120 (feature complex-nums)
 //   bit_rev_bravo_f64/f32                           bravo.rs:303,317 (feature bench-internals)
+//   deinterleave[_complex64/32], combine_re_im      complex_nums.rs:11,25,37,47 (feature bench-internals)
 //
 // A Rust `&mut [T]` is a (pointer, length) pair here -- `Slice<T>` converts from std::vector / std::array /
 // raw pointer + length.  Where the reference panics (`assert!`), these functions throw `phastft::Panic` whose
@@ -25,6 +26,7 @@
 #include <cstddef>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "phastft_hip.h"
@@ -212,6 +214,37 @@ inline void bit_rev_bravo_f32(Slice<float> data, unsigned n) {
     if (n >= 8 * sizeof(std::size_t) || data.len != (std::size_t(1) << n))
         throw Panic(PHAST_ERR_INVALID_ARG, "Data length must be 2^n");
     check(phast_bit_rev_f32(data.ptr, data.len, n));
+}
+
+// ---- Complex<T> <-> planes (complex_nums.rs:11-56; feature bench-internals) ----
+template <typename T> struct ComplexNumsAbi;
+template <> struct ComplexNumsAbi<double> {
+    static int deinterleave(const double *in, std::size_t len, double *a, double *b) { return phast_deinterleave_f64(in, len, a, len / 2, b, len / 2); }
+    static int combine(const double *re, std::size_t n, const double *im, std::size_t m, double *out) { return phast_combine_re_im_f64(re, n, im, m, out, 2 * n); }
+};
+template <> struct ComplexNumsAbi<float> {
+    static int deinterleave(const float *in, std::size_t len, float *a, float *b) { return phast_deinterleave_f32(in, len, a, len / 2, b, len / 2); }
+    static int combine(const float *re, std::size_t n, const float *im, std::size_t m, float *out) { return phast_combine_re_im_f32(re, n, im, m, out, 2 * n); }
+};
+// complex_nums.rs:11 -- [1, 2, 3, 4] -> ([1, 3], [2, 4]); an odd last element is dropped (chunks_exact(2))
+template <typename T> inline std::pair<std::vector<T>, std::vector<T>> deinterleave(Slice<const T> input) {
+    std::pair<std::vector<T>, std::vector<T>> out{std::vector<T>(input.len / 2), std::vector<T>(input.len / 2)};
+    check(ComplexNumsAbi<T>::deinterleave(input.ptr, input.len, out.first.data(), out.second.data()));
+    return out;
+}
+// complex_nums.rs:25,37 -- std::complex<T> is layout-compatible with T[2] (re, im), as Complex<T> is repr(C)
+inline std::pair<std::vector<double>, std::vector<double>> deinterleave_complex64(Slice<const std::complex<double>> signal) {
+    return deinterleave<double>(Slice<const double>(reinterpret_cast<const double *>(signal.ptr), 2 * signal.len));
+}
+inline std::pair<std::vector<float>, std::vector<float>> deinterleave_complex32(Slice<const std::complex<float>> signal) {
+    return deinterleave<float>(Slice<const float>(reinterpret_cast<const float *>(signal.ptr), 2 * signal.len));
+}
+// complex_nums.rs:47 -- panics unless reals.len() == imags.len()
+template <typename T> inline std::vector<std::complex<T>> combine_re_im(Slice<const T> reals, Slice<const T> imags) {
+    if (reals.len != imags.len) throw Panic(PHAST_ERR_LEN_MISMATCH, "assertion `left == right` failed");  // complex_nums.rs:48
+    std::vector<std::complex<T>> out(reals.len);
+    check(ComplexNumsAbi<T>::combine(reals.ptr, reals.len, imags.ptr, imags.len, reinterpret_cast<T *>(out.data())));
+    return out;
 }
 
 // ---- R2C / C2R (algorithms/r2c.rs:521-895) ----

@@ -246,6 +246,20 @@ int phast_bit_rev_f32(float *data, size_t len, unsigned log_n);
 int phast_bit_rev_f64_dev(double *d_data, unsigned log_n, size_t batch, size_t dist, void *stream);
 int phast_bit_rev_f32_dev(float *d_data, unsigned log_n, size_t batch, size_t dist, void *stream);
 
+/* ---- Complex<T> <-> planes: complex_nums.rs (public with feature bench-internals, like the bit reversal) ----
+ * deinterleave: [1, 2, 3, 4] -> ([1, 3], [2, 4]) for any length; `chunks_exact(2)` drops an odd last element
+ * (complex_nums.rs:11-17).  deinterleave_complex64 / _complex32 (:25-39) are this on the cast slice: pass the n Complex<T>
+ * as 2 n scalars.  combine_re_im (:47-56): `assert_eq!(reals.len(), imags.len())` -> PHAST_ERR_LEN_MISMATCH.  The reference
+ * returns new Vecs; a C caller brings the outputs, and the host-slice forms check their lengths (len / 2 each; 2 n). */
+int phast_deinterleave_f64(const double *input, size_t len, double *out_a, size_t a_len, double *out_b, size_t b_len);
+int phast_deinterleave_f32(const float *input, size_t len, float *out_a, size_t a_len, float *out_b, size_t b_len);
+int phast_deinterleave_f64_dev(const double *d_input, size_t len, double *d_out_a, double *d_out_b, void *stream);
+int phast_deinterleave_f32_dev(const float *d_input, size_t len, float *d_out_a, float *d_out_b, void *stream);
+int phast_combine_re_im_f64(const double *reals, size_t reals_len, const double *imags, size_t imags_len, double *out, size_t out_len);
+int phast_combine_re_im_f32(const float *reals, size_t reals_len, const float *imags, size_t imags_len, float *out, size_t out_len);
+int phast_combine_re_im_f64_dev(const double *d_reals, const double *d_imags, size_t n, double *d_out, void *stream);
+int phast_combine_re_im_f32_dev(const float *d_reals, const float *d_imags, size_t n, float *d_out, void *stream);
+
 /* ---- R2C: algorithms/r2c.rs:521-662 ---- */
 int phast_r2c_fft_f64(const double *input_re, size_t input_len, double *output_re, size_t output_re_len,
                       double *output_im, size_t output_im_len); /* r2c.rs:521 */

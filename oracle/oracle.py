@@ -203,6 +203,25 @@ def bit_rev_bravo_f32(data, log_n, regime=""):
     getattr(lib(), "pho_bit_rev" + regime + "_f32")(_p(data), C.c_uint(log_n))
 
 
+# ---- Complex<T> <-> planes (complex_nums.rs:11-56) ----
+def deinterleave(data):
+    """complex_nums.rs:11: (a, b) = (data[0::2], data[1::2]) over the complete pairs"""
+    fs = "f64" if data.dtype == np.float64 else "f32"
+    _req(data, data.dtype.type)
+    a, b = np.empty(data.size // 2, data.dtype), np.empty(data.size // 2, data.dtype)
+    getattr(lib(), "pho_deinterleave_" + fs)(_p(data), C.c_size_t(data.size), _p(a), _p(b))
+    return a, b
+
+
+def combine_re_im(reals, imags):
+    """complex_nums.rs:47: the 2 n scalars of the Complex<T> array"""
+    assert reals.size == imags.size  # complex_nums.rs:48
+    fs = "f64" if reals.dtype == np.float64 else "f32"
+    out = np.empty(2 * reals.size, reals.dtype)
+    getattr(lib(), "pho_combine_re_im_" + fs)(_p(reals), _p(imags), C.c_size_t(reals.size), _p(out))
+    return out
+
+
 # ---- kernels for the pin tests ----
 def codelet_16_f64(re, im):
     lib().pho_codelet_16_f64(_p(_req(re, np.float64)), _p(_req(im, np.float64)), _sz(re.size))

@@ -281,3 +281,20 @@ double pho_time_c2r_fft_f32(size_t n, int iters, unsigned long long seed) {
     pho_planner_r2c32_free(planner);
     return total;
 }
+
+/* ---- complex_nums.rs:11-56: Complex<T> <-> planes ---- */
+#define PHO_COMPLEX_NUMS(T, FS)                                                                         \
+    void pho_deinterleave_##FS(const T *input, size_t len, T *out_a, T *out_b) { /* complex_nums.rs:16 */ \
+        for (size_t k = 0; k + 1 < len; k += 2) {                                                       \
+            out_a[k / 2] = input[k];                                                                    \
+            out_b[k / 2] = input[k + 1];                                                                \
+        }                                                                                               \
+    }                                                                                                   \
+    void pho_combine_re_im_##FS(const T *reals, const T *imags, size_t n, T *out) { /* complex_nums.rs:50-55 */ \
+        for (size_t k = 0; k < n; ++k) {                                                                \
+            out[2 * k] = reals[k];                                                                      \
+            out[2 * k + 1] = imags[k];                                                                  \
+        }                                                                                               \
+    }
+PHO_COMPLEX_NUMS(double, f64)
+PHO_COMPLEX_NUMS(float, f32)

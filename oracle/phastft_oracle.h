@@ -93,6 +93,13 @@ int pho_fft_64_dit_with_planner_parallel(double *reals, size_t re_len, double *i
 int pho_fft_32_dit_with_planner_parallel(float *reals, size_t re_len, float *imags, size_t im_len, int direction,
                                          const pho_planner_dit32 *planner);
 
+/* complex_nums.rs:11-56 (bench-internals surface): deinterleave = `input.chunks_exact(2).map(|c| (c[0], c[1])).unzip()` -- an odd
+ * last element is dropped; out_a / out_b hold len / 2 elements.  combine_re_im: out[k] = Complex::new(reals[k], imags[k]). */
+void pho_deinterleave_f64(const double *input, size_t len, double *out_a, double *out_b);
+void pho_deinterleave_f32(const float *input, size_t len, float *out_a, float *out_b);
+void pho_combine_re_im_f64(const double *reals, const double *imags, size_t n, double *out);
+void pho_combine_re_im_f32(const float *reals, const float *imags, size_t n, float *out);
+
 /* algorithms/bravo.rs:303-345 (bench-internals surface) */
 void pho_bit_rev_f64(double *data, unsigned log_n);
 void pho_bit_rev_f32(float *data, unsigned log_n);

@@ -15,6 +15,8 @@ the reference tree) over the C ABI of ``include/phastft_hip.h``:
     r2c_fft_f32/f64[_with_planner]    r2c.rs:521-662 same names
     c2r_fft_*[_with_planner[_and_scratch]] r2c.rs:695 same names
     bit_rev_bravo_f32/f64             bravo.rs:303   bit_rev_bravo_f32/f64(data, n)
+    deinterleave[_complex64/32]       complex_nums.rs:11   deinterleave(data) -> (a, b)
+    combine_re_im                     complex_nums.rs:47   combine_re_im(reals, imags) -> Complex<T> array
     ==============================================  ==========================================
 
 Slices are 1-D contiguous arrays: ``numpy.ndarray`` (host slices -- staged through device memory, the
@@ -46,7 +48,7 @@ __all__ = [
     "c2r_fft_f64_with_planner_and_scratch", "c2r_fft_f32_with_planner_and_scratch",
     "fft_dit_strided", "fft_64_interleaved", "fft_32_interleaved", "fft_64_interleaved_with_planner", "fft_32_interleaved_with_planner",
     "fft_64_interleaved_with_planner_and_opts", "fft_32_interleaved_with_planner_and_opts",
-    "bit_rev_bravo_f64", "bit_rev_bravo_f32", "fft_dit_batched", "r2c_fft_batched", "c2r_fft_batched", "fill_uniform", "digest", "device_info",
+    "bit_rev_bravo_f64", "bit_rev_bravo_f32", "deinterleave", "deinterleave_complex64", "deinterleave_complex32", "combine_re_im", "fft_dit_batched", "r2c_fft_batched", "c2r_fft_batched", "fill_uniform", "digest", "device_info",
     "TwiddleGrid64", "TwiddleGrid32",
 ]
 
@@ -671,6 +673,82 @@ def bit_rev_bravo_f64(data, n: int) -> None:
 def bit_rev_bravo_f32(data, n: int) -> None:
     """bravo.rs:303"""
     _bit_rev("f32", np.float32, data, n)
+
+
+# ---------------------------------------------------------------------------------------------
+# Complex<T> <-> planes  (complex_nums.rs:11-56; public with feature bench-internals)
+# ---------------------------------------------------------------------------------------------
+def _np_dtype(x):
+    if _is_torch(x):
+        import torch
+
+        return np.float64 if x.dtype == torch.float64 else np.float32
+    return np.float64 if x.dtype == np.float64 else np.float32
+
+
+def _scalars(x):
+    """a Complex<T> array as its 2 n scalars (`bytemuck::cast_slice`, complex_nums.rs:26,38); real arrays pass through"""
+    if _is_torch(x):
+        import torch
+
+        return torch.view_as_real(x).reshape(-1) if x.is_complex() else x
+    return x.view(np.float64 if x.dtype == np.complex128 else np.float32) if np.iscomplexobj(x) else x
+
+
+def _like(x, n, dtype):
+    if _is_torch(x):
+        import torch
+
+        return torch.empty(n, dtype=torch.float64 if dtype == np.float64 else torch.float32, device=x.device)
+    return np.empty(n, dtype)
+
+
+def deinterleave(data):
+    """complex_nums.rs:11-17: ``[1, 2, 3, 4] -> ([1, 3], [2, 4])`` for any length (an odd last element is dropped, as
+    `chunks_exact(2)` does).  A numpy array (host slice) or a torch cuda tensor (device, asynchronous on the current stream);
+    returns two new arrays of the same kind."""
+    data = _scalars(data)
+    dtype = _np_dtype(data)
+    fs = "f64" if dtype == np.float64 else "f32"
+    d = _Slice(data, dtype, "input")
+    a, b = _like(data, d.len // 2, dtype), _like(data, d.len // 2, dtype)
+    sa, sb = _Slice(a, dtype, "out_a"), _Slice(b, dtype, "out_b")
+    if d.dev:
+        _check(getattr(_lib.lib(), f"phast_deinterleave_{fs}_dev")(d.ptr, C.c_size_t(d.len), sa.ptr, sb.ptr, _stream()))
+    else:
+        _check(getattr(_lib.lib(), f"phast_deinterleave_{fs}")(d.ptr, C.c_size_t(d.len), sa.ptr, C.c_size_t(sa.len), sb.ptr, C.c_size_t(sb.len)))
+    return a, b
+
+
+def deinterleave_complex64(signal):
+    """complex_nums.rs:25-28: a `&[Complex<f64>]` (numpy complex128 / torch complex128) into (reals, imags)"""
+    return deinterleave(signal)
+
+
+def deinterleave_complex32(signal):
+    """complex_nums.rs:37-40: a `&[Complex<f32>]` (numpy complex64 / torch complex64) into (reals, imags)"""
+    return deinterleave(signal)
+
+
+def combine_re_im(reals, imags):
+    """complex_nums.rs:47-56: (reals, imags) -> one Complex<T> array; panics (PhastPanic) unless the lengths agree"""
+    dtype = _np_dtype(reals)
+    fs = "f64" if dtype == np.float64 else "f32"
+    r, m = _Slice(reals, dtype, "reals"), _Slice(imags, dtype, "imags")
+    dev = _same_place(r, m)
+    if r.len != m.len:
+        raise PhastPanic(2, "assertion `left == right` failed")  # complex_nums.rs:48
+    out = _like(reals, 2 * r.len, dtype)
+    so = _Slice(out, dtype, "out")
+    if dev:
+        _check(getattr(_lib.lib(), f"phast_combine_re_im_{fs}_dev")(r.ptr, m.ptr, C.c_size_t(r.len), so.ptr, _stream()))
+    else:
+        _check(getattr(_lib.lib(), f"phast_combine_re_im_{fs}")(r.ptr, C.c_size_t(r.len), m.ptr, C.c_size_t(m.len), so.ptr, C.c_size_t(so.len)))
+    if _is_torch(out):
+        import torch
+
+        return torch.view_as_complex(out.reshape(-1, 2))
+    return out.view(np.complex128 if dtype == np.float64 else np.complex64)
 
 
 # ---------------------------------------------------------------------------------------------

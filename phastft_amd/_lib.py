@@ -27,6 +27,8 @@ phast_fft_64_interleaved phast_fft_32_interleaved phast_fft_64_interleaved_with_
 phast_fft_32_interleaved_with_planner phast_fft_64_interleaved_with_planner_and_opts
 phast_fft_32_interleaved_with_planner_and_opts phast_fft_64_interleaved_dev phast_fft_32_interleaved_dev
 phast_bit_rev_f64 phast_bit_rev_f32 phast_bit_rev_f64_dev phast_bit_rev_f32_dev
+phast_deinterleave_f64 phast_deinterleave_f32 phast_deinterleave_f64_dev phast_deinterleave_f32_dev
+phast_combine_re_im_f64 phast_combine_re_im_f32 phast_combine_re_im_f64_dev phast_combine_re_im_f32_dev
 phast_r2c_fft_f64 phast_r2c_fft_f32 phast_r2c_fft_f64_with_planner phast_r2c_fft_f32_with_planner
 phast_r2c_fft_f64_dev phast_r2c_fft_f32_dev
 phast_c2r_fft_f64 phast_c2r_fft_f32 phast_c2r_fft_f64_with_planner phast_c2r_fft_f32_with_planner

@@ -23,7 +23,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIB_DIR, "libphastft_hip.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
-UNITS = ["c_abi", "tile_f64_a", "tile_f64_bc", "tile_f64_bc_wide", "tile_f32_a", "tile_f32_bc", "tile_f32_bc_wide", "tile_f64_r2c", "tile_f32_r2c", "tile_f64_c2r", "tile_f32_c2r", "wave_f64", "wave_f32", "quad_f64", "quad_f32", "small_fft", "bitrev", "r2c", "fill", "probe", "twiddle"]
+UNITS = ["c_abi", "tile_f64_a", "tile_f64_bc", "tile_f64_bc_wide", "tile_f32_a", "tile_f32_bc", "tile_f32_bc_wide", "tile_f64_r2c", "tile_f32_r2c", "tile_f64_c2r", "tile_f32_c2r", "wave_f64", "wave_f32", "quad_f64", "quad_f32", "small_fft", "bitrev", "complex_nums", "r2c", "fill", "probe", "twiddle"]
 # built only with --experimental (lib/libphastft_hip_exp.so): nothing at present (round 6: the f32 wave tiles were rebuilt on
 # float2 column pairs and moved into the product)
 EXPERIMENTAL_UNITS = []

@@ -381,6 +381,28 @@ PHAST_PLANNER_API(32, float)
         PHAST_HIP(launch_bitrev<T>(d, log_n, batch, dist, static_cast<hipStream_t>(stream)));                           \
         return PHAST_OK;                                                                                                \
     } PHAST_CATCH_RC                                                                                                    \
+    int phast_deinterleave_##FS(const T *in, size_t len, T *a, size_t a_len, T *b, size_t b_len) try {                  \
+        return deinterleave_host<T>(in, len, a, a_len, b, b_len);                                                       \
+    } PHAST_CATCH_RC                                                                                                    \
+    int phast_deinterleave_##FS##_dev(const T *d_in, size_t len, T *d_a, T *d_b, void *stream) try {                    \
+        if (len < 2) return PHAST_OK; /* chunks_exact(2) of fewer than two elements: nothing */                         \
+        if (!d_in || !d_a || !d_b) return PHAST_ERR_INVALID_ARG;                                                        \
+        int rc = ensure_device();                                                                                       \
+        if (rc) return rc;                                                                                              \
+        PHAST_HIP(launch_deinterleave<T>(d_in, d_a, d_b, len / 2, static_cast<hipStream_t>(stream)));                   \
+        return PHAST_OK;                                                                                                \
+    } PHAST_CATCH_RC                                                                                                    \
+    int phast_combine_re_im_##FS(const T *re, size_t re_len, const T *im, size_t im_len, T *out, size_t out_len) try {  \
+        return combine_host<T>(re, re_len, im, im_len, out, out_len);                                                   \
+    } PHAST_CATCH_RC                                                                                                    \
+    int phast_combine_re_im_##FS##_dev(const T *d_re, const T *d_im, size_t n, T *d_out, void *stream) try {            \
+        if (n == 0) return PHAST_OK;                                                                                    \
+        if (!d_re || !d_im || !d_out) return PHAST_ERR_INVALID_ARG;                                                     \
+        int rc = ensure_device();                                                                                       \
+        if (rc) return rc;                                                                                              \
+        PHAST_HIP(launch_combine<T>(d_re, d_im, d_out, n, static_cast<hipStream_t>(stream)));                           \
+        return PHAST_OK;                                                                                                \
+    } PHAST_CATCH_RC                                                                                                    \
     int phast_r2c_fft_##FS(const T *in, size_t in_len, T *ore, size_t ore_len, T *oim, size_t oim_len) try {            \
         std::shared_ptr<PlannerR2c<T>> pl; /* r2c.rs:522: planner from input_re.len() */                                \
         int rc = PlannerCache<PlannerR2c<T>>::instance().get(                                                           \

@@ -329,6 +329,46 @@ template <typename T> static int bitrev_host(T *data, size_t len, unsigned log_n
     return PHAST_OK;
 }
 
+// complex_nums.rs:11-17: `input.chunks_exact(2)` -- an odd last element is dropped; the reference returns two new Vecs of
+// len / 2, here the caller brings them (their lengths are checked: a C caller cannot receive a Vec)
+template <typename T> static int deinterleave_host(const T *in, size_t len, T *a, size_t a_len, T *b, size_t b_len) {
+    const size_t pairs = len / 2;
+    if (a_len != pairs || b_len != pairs) return PHAST_ERR_LEN_MISMATCH;
+    if (pairs == 0) return PHAST_OK;
+    if (!in || !a || !b) return PHAST_ERR_INVALID_ARG;
+    int rc = ensure_device();
+    if (rc) return rc;
+    DevBuf buf;
+    rc = buf.alloc(4 * pairs * sizeof(T));
+    if (rc) return rc;
+    T *d_in = reinterpret_cast<T *>(buf.p), *d_a = d_in + 2 * pairs, *d_b = d_a + pairs;
+    PHAST_HIP(hipMemcpy(d_in, in, 2 * pairs * sizeof(T), hipMemcpyHostToDevice));
+    PHAST_HIP(launch_deinterleave<T>(d_in, d_a, d_b, pairs, nullptr));
+    PHAST_HIP(hipStreamSynchronize(nullptr));
+    PHAST_HIP(hipMemcpy(a, d_a, pairs * sizeof(T), hipMemcpyDeviceToHost));
+    PHAST_HIP(hipMemcpy(b, d_b, pairs * sizeof(T), hipMemcpyDeviceToHost));
+    return PHAST_OK;
+}
+
+// complex_nums.rs:47-56: `assert_eq!(reals.len(), imags.len())`
+template <typename T> static int combine_host(const T *re, size_t re_len, const T *im, size_t im_len, T *out, size_t out_len) {
+    if (re_len != im_len || out_len != 2 * re_len) return PHAST_ERR_LEN_MISMATCH;
+    if (re_len == 0) return PHAST_OK;
+    if (!re || !im || !out) return PHAST_ERR_INVALID_ARG;
+    int rc = ensure_device();
+    if (rc) return rc;
+    DevBuf buf;
+    rc = buf.alloc(4 * re_len * sizeof(T));
+    if (rc) return rc;
+    T *d_re = reinterpret_cast<T *>(buf.p), *d_im = d_re + re_len, *d_out = d_im + re_len;
+    PHAST_HIP(hipMemcpy(d_re, re, re_len * sizeof(T), hipMemcpyHostToDevice));
+    PHAST_HIP(hipMemcpy(d_im, im, re_len * sizeof(T), hipMemcpyHostToDevice));
+    PHAST_HIP(launch_combine<T>(d_re, d_im, d_out, re_len, nullptr));
+    PHAST_HIP(hipStreamSynchronize(nullptr));
+    PHAST_HIP(hipMemcpy(out, d_out, 2 * re_len * sizeof(T), hipMemcpyDeviceToHost));
+    return PHAST_OK;
+}
+
 template <typename T> static int describe_to(const Planner<T> *p, char *buf, size_t len) {
     if (!p || !buf || !len) return PHAST_ERR_INVALID_ARG;
     std::string s = p->describe();

@@ -80,6 +80,9 @@ hipError_t launch_fill(T *re, T *im, size_t n, size_t batch, size_t dist, unsign
 template <typename T>
 hipError_t launch_digest(const T *re, const T *im, size_t n, size_t batch, size_t dist, size_t probe, double *digest,
                          hipStream_t stream);
+// ---- complex_nums.hip: Complex<T> <-> planes (complex_nums.rs:11-56) ----
+template <typename T> hipError_t launch_deinterleave(const T *in, T *a, T *b, size_t pairs, hipStream_t stream);
+template <typename T> hipError_t launch_combine(const T *re, const T *im, T *out, size_t n, hipStream_t stream);
 // harness: this box's streaming ceilings (probe.hip) -- out_gbps = {read, write, copy}
 hipError_t stream_probe(const void *d_a, void *d_b, size_t bytes, int reps, int cus, double *out_gbps, hipStream_t stream);
 

@@ -60,6 +60,14 @@ extern "C" {
         sim: *mut f32, sim_len: usize) -> c_int;
     pub(crate) fn phast_bit_rev_f64(data: *mut f64, len: usize, log_n: c_uint) -> c_int;
     pub(crate) fn phast_bit_rev_f32(data: *mut f32, len: usize, log_n: c_uint) -> c_int;
+    pub(crate) fn phast_deinterleave_f64(input: *const f64, len: usize, a: *mut f64, a_len: usize, b: *mut f64,
+        b_len: usize) -> c_int;
+    pub(crate) fn phast_deinterleave_f32(input: *const f32, len: usize, a: *mut f32, a_len: usize, b: *mut f32,
+        b_len: usize) -> c_int;
+    pub(crate) fn phast_combine_re_im_f64(re: *const f64, re_len: usize, im: *const f64, im_len: usize, out: *mut f64,
+        out_len: usize) -> c_int;
+    pub(crate) fn phast_combine_re_im_f32(re: *const f32, re_len: usize, im: *const f32, im_len: usize, out: *mut f32,
+        out_len: usize) -> c_int;
     pub(crate) fn phast_fft_64_dit_dev(re: *mut f64, im: *mut f64, n: usize, batch: usize, dist: usize,
         direction: c_int, planner: *const Opaque, stream: *mut c_void) -> c_int;
     pub(crate) fn phast_fft_32_dit_dev(re: *mut f32, im: *mut f32, n: usize, batch: usize, dist: usize,

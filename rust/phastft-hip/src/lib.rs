@@ -22,6 +22,11 @@
 mod algorithms;
 #[cfg(feature = "bench-internals")]
 pub mod algorithms;
+// lib.rs:23-27 of the reference: complex_nums is private with `complex-nums` alone, public with `bench-internals`
+#[cfg(all(feature = "complex-nums", not(feature = "bench-internals")))]
+mod complex_nums;
+#[cfg(feature = "bench-internals")]
+pub mod complex_nums;
 mod ffi;
 pub mod options;
 pub mod planner;

@@ -261,6 +261,26 @@ int main(int argc, char **argv) {
         }
         EXPECT(ok);
     }
+    // ---- Complex<T> <-> planes (complex_nums.rs:73-118): the reference's list of lengths, then separate -> combine ----
+    for (size_t n : {size_t(0), size_t(1), size_t(2), size_t(3), size_t(15), size_t(16), size_t(17), size_t(127), size_t(128), size_t(129),
+                     size_t(130), size_t(135), size_t(100500)}) {
+        std::vector<double> in(n);
+        for (size_t i = 0; i < n; ++i) in[i] = double(i);
+        const auto ab = deinterleave<double>(Slice<const double>(in.data(), in.size()));
+        bool ok = ab.first.size() == n / 2 && ab.second.size() == n / 2;
+        for (size_t i = 0; i < n / 2 && ok; ++i) ok = ab.first[i] == in[2 * i] && ab.second[i] == in[2 * i + 1];
+        EXPECT(ok);
+    }
+    {
+        std::vector<std::complex<float>> z(1000);
+        for (size_t i = 0; i < z.size(); ++i) z[i] = {float(i) * 0.5f, -float(i)};
+        const auto ri = deinterleave_complex32(Slice<const std::complex<float>>(z.data(), z.size()));
+        const auto back = combine_re_im<float>(Slice<const float>(ri.first.data(), ri.first.size()), Slice<const float>(ri.second.data(), ri.second.size()));
+        EXPECT(back == z);
+        std::vector<float> shorter(999);
+        EXPECT(panic_message([&] { combine_re_im<float>(Slice<const float>(ri.first.data(), ri.first.size()), Slice<const float>(shorter.data(), shorter.size())); }) ==
+               "assertion `left == right` failed");
+    }
     std::printf("host_api_test (GPU): %d failure(s)\n", failures);
     phast_test_exit(failures ? 1 : 0);
 }

@@ -107,6 +107,12 @@ def test_reference_module_paths_exist():
     assert re.search(r'#\[cfg\(feature = "bench-internals"\)\]\s*pub mod algorithms;', lib_rs)
     assert re.search(r'#\[cfg\(not\(feature = "bench-internals"\)\)\]\s*mod algorithms;', lib_rs)
     assert "pub mod options;" in lib_rs and "pub mod planner;" in lib_rs
+    # lib.rs:23-27: complex_nums private with `complex-nums` alone, public with `bench-internals`
+    assert re.search(r'#\[cfg\(feature = "bench-internals"\)\]\s*pub mod complex_nums;', lib_rs)
+    assert re.search(r'#\[cfg\(all\(feature = "complex-nums", not\(feature = "bench-internals"\)\)\)\]\s*mod complex_nums;', lib_rs)
+    cn = read("complex_nums.rs")
+    for item in ("pub fn deinterleave<", "pub fn deinterleave_complex64(", "pub fn deinterleave_complex32(", "pub fn combine_re_im<"):
+        assert item in cn, item
     # lib.rs:33-38: root re-exports
     for item in ("fft_32_dit_with_planner_and_opts", "fft_64_dit_with_planner_and_opts", "c2r_fft_f32",
                  "c2r_fft_f32_with_planner", "c2r_fft_f32_with_planner_and_scratch", "c2r_fft_f64",
