@@ -49,7 +49,9 @@ template <typename V>
 static hipError_t run_variant(ProbeKernel<V> k, int wg_per_cu, int cus, const void *a, void *b, size_t bytes, double moved,
                               int reps, hipStream_t stream, hipEvent_t e0, hipEvent_t e1, double *best) {
     const size_t n = bytes / sizeof(V);
-    const dim3 grid((unsigned)(cus * wg_per_cu)), block(256);
+    // wg_per_cu == 0: no persistent workgroups -- one element per thread, workgroups dispatched in address order (round 6: the form
+    // csrc/complex_nums.hip's sweeps run fastest in; a yardstick must not be slower than what is measured against it)
+    const dim3 grid(wg_per_cu ? (unsigned)(cus * wg_per_cu) : (unsigned)((n + 255) / 256)), block(256);
     hipLaunchKernelGGL(k, grid, block, 0, stream, (const V *)a, (V *)b, n);  // warm
     hipError_t e = hipEventRecord(e0, stream);
     if (e != hipSuccess) return e;
@@ -75,17 +77,17 @@ hipError_t stream_probe(const void *d_a, void *d_b, size_t bytes, int reps, int 
     const double B = (double)bytes;
 #define PHAST_PROBE(K, V, NT, WG, MOVED, BEST) \
     if (e == hipSuccess) e = run_variant<V>(K<V, NT>, WG, cus, d_a, d_b, bytes, MOVED, reps, stream, e0, e1, &BEST)
-    for (int wg : {8, 16}) {
+    for (int wg : {0, 8, 16}) {
         PHAST_PROBE(probe_read_kernel, double, true, wg, B, rd);
         PHAST_PROBE(probe_read_kernel, double2_t, true, wg, B, rd);
         PHAST_PROBE(probe_read_kernel, double, false, wg, B, rd);
     }
-    for (int wg : {16, 32}) {
+    for (int wg : {0, 16, 32}) {
         PHAST_PROBE(probe_write_kernel, double, false, wg, B, wr);
         PHAST_PROBE(probe_write_kernel, double2_t, false, wg, B, wr);
         PHAST_PROBE(probe_write_kernel, double2_t, true, wg, B, wr);
     }
-    for (int wg : {4, 8, 16}) {
+    for (int wg : {0, 4, 8, 16}) {
         PHAST_PROBE(probe_copy_kernel, double, true, wg, 2 * B, cp);
         PHAST_PROBE(probe_copy_kernel, double2_t, true, wg, 2 * B, cp);
         PHAST_PROBE(probe_copy_kernel, double, false, wg, 2 * B, cp);
