@@ -2,12 +2,19 @@
 precision and direction of device-resident batches -- in particular the batch counts around which the planner switches
 between its single / latency / mid / throughput plans (planner_plans.hpp: Planner::plan_for) -- each against numpy's pocketfft
 in double precision (forward unnormalised, reverse scaled by 1/N: algorithms/dit.rs:297-331)."""
+import os
+
 import numpy as np
 import pytest
 
 from tests import tolerances as tol
 
 pytestmark = pytest.mark.gpu
+
+# PHAST_FUZZ_SEED=<int> shifts every seed, PHAST_FUZZ_SCALE=<int> multiplies the number of cases per chunk: the suite runs seed 0 x 1;
+# tools/extended_fuzz.sh runs other seeds at x 4 (profiles/r06_extended_fuzz.log)
+SEED = int(os.environ.get("PHAST_FUZZ_SEED", "0"))
+SCALE = int(os.environ.get("PHAST_FUZZ_SCALE", "1"))
 
 
 def _cases(seed, count):
@@ -28,7 +35,7 @@ def test_random_batches_against_pocketfft(gpu, chunk):
     import torch
 
     planners = {}
-    for k, batch, pad, dt, reverse in _cases(0xF022 + chunk, 30):
+    for k, batch, pad, dt, reverse in _cases(0xF022 + chunk + 1000 * SEED, 30 * SCALE):
         n = 1 << k
         dist = n + pad
         np_t, t_t = (np.float64, torch.float64) if dt == "f64" else (np.float32, torch.float32)
@@ -64,8 +71,8 @@ def test_random_real_batches_against_pocketfft(gpu, chunk):
     separately)."""
     import torch
 
-    rng0 = np.random.default_rng(0xBEA1 + chunk)
-    for _ in range(20):
+    rng0 = np.random.default_rng(0xBEA1 + chunk + 1000 * SEED)
+    for _ in range(20 * SCALE):
         k = int(rng0.integers(2, 22))
         n = 1 << k
         batch = int(min(rng0.choice([1, 2, 3, 5, 8, 16, 17, 33]), max(1, (1 << 23) >> k)))
