@@ -970,18 +970,15 @@ def main():
         # ... and, for information only (never `value`): the same K-step region with the graph ALREADY QUEUED behind a running
         # kernel when the start event is reached -- the host's launch of the graph (10-20 us, once per K steps: 0.5-1 us per
         # step at K = 20) then happens while the GPU is busy with that kernel, outside the events
-        if graph is not None:
-            spin_re = torch.empty(8 << 20, dtype=torch.float64, device=dev)
-            spin_im = torch.empty_like(spin_re)
-            torch.cuda.synchronize()
+        if graph is not None and torch.cuda.current_device() in _DRAIN:
+            fresh()                                                     # the region's usual starting state ...
             q0, q1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            P.fill_uniform(spin_re, spin_im, 8 << 20, seed=1, first_id=0)   # ~128 MiB written: tens of microseconds of GPU work
-            q0.record()
-            graph.replay()
+            P.digest(_DRAIN[torch.cuda.current_device()][0], _DRAIN[torch.cuda.current_device()][1], 1 << 20)   # ... and ~130 us of
+            q0.record()                                                 # READ-ONLY work in front (a kernel that writes would leave
+            graph.replay()                                              # its write-back to the timed steps: settle())
             q1.record()
             torch.cuda.synchronize()
             head_stats["ms_per_step_queued"] = q0.elapsed_time(q1) / steps
-            del spin_re, spin_im
         samples_per_step = N
         workload = f"single f64 forward FFT N=2^{LOG_N}, in place, planar (BASELINE configs[1])"
         # --- roofline of the dominant pass kernel, HIP events bound to the dispatches (fresh buffers) ---
