@@ -421,8 +421,8 @@ def config_n2p26(P, torch, dev, steps: int, cpu: bool):
     P.fill_uniform(re, im, n, seed=0xCAFE)
     for _ in range(3):  # untimed warm-up: scratch allocation, clocks (the CPU legs above left the GPU idle for seconds)
         P.fft_64_dit_with_planner(re, im, P.Direction.Forward, pl)
-    P.fill_uniform(ring_re, ring_im, n, seed=0xCAFE, first_id=0)
-    torch.cuda.synchronize()
+    settle(torch, P, refill=lambda: P.fill_uniform(ring_re, ring_im, n, seed=0xCAFE, first_id=0))   # (256 MiB of the fill's
+    # lines would otherwise be written back under the first transform's passes: ~4 % of its traffic)
 
     def forward_all():  # the K timed steps back to back, one event pair around them (as the headline's K-step region)
         for i in range(steps):
@@ -431,7 +431,7 @@ def config_n2p26(P, torch, dev, steps: int, cpu: bool):
     ms = event_ms(torch, forward_all) / steps
     stats = replay_stats(torch, forward_all, steps, ms * steps,
                          before=lambda: settle(torch, P, refill=lambda: P.fill_uniform(ring_re, ring_im, n, seed=0xCAFE, first_id=0)))
-    P.fill_uniform(re, im, n, seed=0xCAFE)
+    settle(torch, P, refill=lambda: P.fill_uniform(re, im, n, seed=0xCAFE))
     pass_ms = pl.time_passes(re, im, n, reps=3)
     used, plan_list = plan_used(pl, 1)
     roof, dom = roofline_of(pass_ms, BYTES_PER_SAMPLE * n, plan_used=f"{used} plan {plan_list}", step_ms=ms)
@@ -441,8 +441,8 @@ def config_n2p26(P, torch, dev, steps: int, cpu: bool):
            "value": n / (ms * 1e-3) / 1e9, "unit": "GSamples/s", "steps": steps, "ms_per_step": ms, **stats, "dtype": "f64",
            "plan": plan_text, "plan_ran": f"{used} {plan_list}", "roofline": roof}
     # configs[2]: forward then inverse on the same buffers; the error against the regenerated input is part of it
-    P.fill_uniform(ring_re, ring_im, n, seed=0xBEEF, first_id=0)
-    torch.cuda.synchronize()
+    settle(torch, P, refill=lambda: P.fill_uniform(ring_re, ring_im, n, seed=0xBEEF, first_id=0))
+
     def roundtrip_all():
         for i in range(steps):
             r_i, m_i = ring_re[i * n:(i + 1) * n], ring_im[i * n:(i + 1) * n]
